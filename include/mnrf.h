@@ -1,0 +1,134 @@
+/*
+ * mnrf.h -- C ABI of the MI355X-native Mirror-NeRF rendering hot path.
+ *
+ * The reference has no C/FFI boundary on this path: its boundary is two Python
+ * call signatures,
+ *     render_rays(models, embeddings, rays, N_samples, use_disp, perturb, noise_std,
+ *                 N_importance, chunk, white_back, test_time, **kwargs)   models/rendering.py:54-67
+ *     MirrorNeRF.forward(x, compute_normal, sigma_only, embedding_xyz, ...)  models/mirror_nerf.py:101-112
+ * which `mirror_nerf_amd/rendering.py` and `mirror_nerf_amd/mirror_nerf.py` keep.
+ * Those Python shims do no arithmetic; every number is produced by the entry
+ * points below (libmnrf_hip.so), which take plain device pointers and sizes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every
+ *     buffer (the library never allocates device memory);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - return value 0 = ok, negative = error (see mnrf_last_error()); nothing throws;
+ *   - re-entrant; no global stream or global device state.
+ *   - the field architecture is the reference default (train.py:44-66): D=8, W=256,
+ *     skip at layer 5, Embedding(10) for xyz (63 ch), Embedding(4) for dir (27 ch),
+ *     normal_net and is_mirror_net present.
+ */
+#ifndef MNRF_H
+#define MNRF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNRF_OK 0
+#define MNRF_ERR_ARG (-1)      /* bad argument (null pointer, size, flag combination) */
+#define MNRF_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
+#define MNRF_ERR_UNSUPPORTED (-3)
+
+/* number of parameter tensors of one MirrorNeRF in state_dict order
+ * (xyz_encoding_{1..8}.0.{weight,bias}, xyz_encoding_final, dir_encoding.0, sigma,
+ *  rgb.0, normal_net.{0,1}, is_mirror_net.{0,2});  utils/__init__.py:109-136 */
+#define MNRF_N_PARAMS 32
+
+/* flags of mnrf_field_forward */
+#define MNRF_SIGMA_ONLY 1u     /* stop after sigma (rendering.py:139-150) */
+#define MNRF_GRAD_NORMAL 2u    /* also emit normal = l2n(-d sigma/d xyz) (mirror_nerf.py:136-146) */
+
+const char* mnrf_last_error(void);
+int mnrf_version(void);
+
+/* Size in floats of the packed weight image of one model (forward stream, bias block,
+ * transposed trunk stream for the density gradient). */
+int64_t mnrf_packed_floats(void);
+
+/* Re-lay one model's parameters into the MFMA-fragment order the field kernel streams
+ * through LDS.  `params` is a HOST array of MNRF_N_PARAMS device pointers in state_dict
+ * order (nn.Linear layout (out,in) row-major, models/mirror_nerf.py:59-99).
+ * Replaces: the implicit weight reads of nn.Linear at call time. */
+int mnrf_pack_weights(const float* const* params, float* packed, void* stream);
+
+/* Embedding.forward (models/mirror_nerf.py:20-38): x (n, c) -> out (n, c*(2*n_freqs+1)). */
+int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* stream);
+
+/* MirrorNeRF.forward on B samples (models/mirror_nerf.py:101-187).
+ * Positions: either `xyz` (B rows, `xyz_stride` floats apart), or -- when xyz is null --
+ * generated as o + d*z from `rays` (n_rays, 8) and `z_vals` (n_rays, spr) with B = n_rays*spr
+ * (rendering.py:302; separate multiply and add).
+ * View encoding: `dir_emb` rows of 27 floats, `dir_stride` floats apart; row index is
+ * sample/spr (spr = 1 when every sample carries its own row, as in forward(x)).
+ * Outputs may be null when not wanted: sigma (B), rgb (B,3), pred_normal (B,3),
+ * is_mirror (B), normal (B,3), geo_feat (B,256). */
+int mnrf_field_forward(const float* packed, unsigned flags, int64_t B,
+                       const float* xyz, int64_t xyz_stride,
+                       const float* rays, const float* z_vals, int spr,
+                       const float* dir_emb, int64_t dir_stride,
+                       float* sigma, float* rgb, float* pred_normal, float* is_mirror,
+                       float* normal, float* geo_feat, void* stream);
+
+/* Coarse depths (rendering.py:283-300): z = near*(1-t)+far*t, or in disparity;
+ * `z_steps` (n_samples) is torch.linspace(0,1,n) from the host (not recomputed: SURVEY 8a
+ * hazard 2); `perturb_rand` (n_rays, n_samples) may be null (perturb == 0). */
+int mnrf_sample_coarse(const float* rays, int64_t n_rays, const float* z_steps, int n_samples,
+                       int use_disp, float perturb, const float* perturb_rand, float* z_vals,
+                       void* stream);
+
+/* Alpha compositing along each ray (rendering.py:181-264, 362-367).
+ * Inputs per sample: sigma, z_vals (n_rays, S); optional noise (already scaled by noise_std);
+ * optional rgb (.,3), is_mirror, pred_normal (.,3), normal (.,3).
+ * Outputs (null = skip): weights (n_rays,S), opacity, rgb_map (.,3), depth, mirror_mask,
+ * surf_normal (.,3) [sum w*pred_normal], surf_normal_grad (.,3) [sum w*normal],
+ * normal_dif [sum w*|normal-pred_normal|^2], x_surface (.,3) = o + d*depth. */
+int mnrf_composite(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                   const float* noise, const float* rgb, const float* is_mirror,
+                   const float* pred_normal, const float* normal, int white_back,
+                   float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
+                   float* surf_normal, float* surf_normal_grad, float* normal_dif, float* x_surface,
+                   void* stream);
+
+/* Hierarchical resampling (rendering.py:7-51, 312-326): inverse-CDF samples from
+ * weights[:,1:-1] over the mid-points of z_coarse, merged and sorted with z_coarse.
+ * `u`: (n_importance) shared by all rays when u_per_ray == 0 (torch.linspace(0,1,n), det=True)
+ * or (n_rays, n_importance) when u_per_ray != 0.  z_fine: (n_rays, S + n_importance). */
+int mnrf_sample_fine(const float* z_coarse, const float* weights, int64_t n_rays, int S,
+                     const float* u, int u_per_ray, int n_importance, float* z_fine, void* stream);
+
+/* Reflected-ray construction + order-preserving compaction
+ * (train.py:192-252, eval.py:336-360, 513-548).
+ * mask (n_rays) is the 0/1 (or soft) mirror mask; a ray is selected iff mask != 0 (the
+ * `.bool()` of the reference).  compact == 0 keeps all rays (count = n_rays).
+ * normal_noise (n_rays,3) may be null (eval.py:506-511 roughness).
+ * Writes sec_rays (count, 8) = [x_surface, r, near2, far], index (count) int32 of the source
+ * ray, *count (int32, device), and optionally reflect_dir (n_rays, 3) for all rays. */
+int mnrf_reflect_compact(const float* rays, const float* x_surface, const float* normal,
+                         const float* normal_noise, float noise_std, const float* mask,
+                         int64_t n_rays, int compact, float near2, float* sec_rays, int32_t* index,
+                         int32_t* count, float* reflect_dir, void* stream);
+
+/* Threshold in place exactly like `m[m>0.5]=1; m[m<0.5]=0` (train.py:165-166, eval.py:305-306)
+ * and OR-reduce `m != 0` into *any (int32, device, caller zeroes it). */
+int mnrf_threshold_mask(float* mask, int64_t n, int32_t* any, void* stream);
+
+/* Blend (train.py:261-296, eval.py:676-697): out = m*part + (1-m)*base, where part is
+ * `sec` scattered through `index` (compacted, rows without a source keep `base`) or `sec`
+ * itself (index == null).  Optionally writes reflect_out (n,c) = scattered sec (zeros elsewhere). */
+int mnrf_blend_scatter(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                       const float* mask, int64_t n, int c, float* out, float* reflect_out,
+                       void* stream);
+
+/* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
+int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
+                       float* rays, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNRF_H */

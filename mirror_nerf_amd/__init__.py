@@ -1,0 +1,15 @@
+"""mirror_nerf_amd -- MI355X-native (gfx950) implementation of Mirror-NeRF's volumetric
+rendering hot path behind the reference's own Python interfaces.
+
+    from mirror_nerf_amd import render_rays, MirrorNeRF, Embedding      # models/rendering.py, models/mirror_nerf.py
+    from mirror_nerf_amd import NeRFSystem, batched_inference          # train.py:102-348, eval.py:114-740
+
+All arithmetic runs in libmnrf_hip.so (include/mnrf.h).  There is no CPU fallback.
+"""
+from .mirror_nerf import Embedding, MirrorNeRF  # noqa: F401
+from .rendering import render_rays, sample_pdf  # noqa: F401
+from .recursion import NeRFSystem, batched_inference, render_rays_chunk_recursively  # noqa: F401
+from . import _lib  # noqa: F401
+
+__all__ = ["Embedding", "MirrorNeRF", "render_rays", "sample_pdf", "NeRFSystem", "batched_inference",
+           "render_rays_chunk_recursively"]

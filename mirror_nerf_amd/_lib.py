@@ -1,0 +1,98 @@
+"""ctypes binding of libmnrf_hip.so (the C ABI declared in include/mnrf.h).
+
+There is no CPU fallback: if the shared library is missing, or a call fails,
+a RuntimeError is raised.  torch is imported first so that the HIP runtime
+already loaded by torch (same SONAME libamdhip64.so.7) is the one the library
+binds to -- device pointers and streams then belong to one runtime.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmnrf_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c_f = ctypes.c_void_p      # device float*
+_c_i = ctypes.c_void_p      # device int32*
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_u32 = ctypes.c_uint
+_flt = ctypes.c_float
+_str = ctypes.c_void_p      # hipStream_t
+
+MNRF_SIGMA_ONLY = 1
+MNRF_GRAD_NORMAL = 2
+N_PARAMS = 32
+
+# name -> (restype, argtypes): exactly the prototypes of include/mnrf.h
+SIGNATURES = {
+    "mnrf_last_error": (ctypes.c_char_p, []),
+    "mnrf_version": (_int, []),
+    "mnrf_packed_floats": (_i64, []),
+    "mnrf_pack_weights": (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),
+    "mnrf_embed": (_int, [_c_f, _i64, _int, _int, _c_f, _str]),
+    "mnrf_field_forward": (_int, [_c_f, _u32, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64,
+                                  _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
+    "mnrf_sample_coarse": (_int, [_c_f, _i64, _c_f, _int, _int, _flt, _c_f, _c_f, _str]),
+    "mnrf_composite": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
+                              _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
+    "mnrf_sample_fine": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _str]),
+    "mnrf_threshold_mask": (_int, [_c_f, _i64, _c_i, _str]),
+    "mnrf_reflect_compact": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i,
+                                    _c_i, _c_f, _str]),
+    "mnrf_blend_scatter": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _int, _c_f, _c_f, _str]),
+    "mnrf_generate_rays": (_int, [_int, _int, _flt, ctypes.POINTER(ctypes.c_float), _flt, _flt, _c_f, _str]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libmnrf_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout + r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("building libmnrf_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with typed entry points; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension must be built "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mnrf_last_error()
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int32, contiguous, on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mirror_nerf_amd runs on the GPU only (tensor is on %s)" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

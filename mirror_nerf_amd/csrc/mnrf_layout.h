@@ -1,0 +1,95 @@
+// mnrf_layout.h -- the packed weight image shared by the packer and the field kernel.
+//
+// The field kernel evaluates every Linear of MirrorNeRF (models/mirror_nerf.py:59-99) in
+// the TRANSPOSED form  Out^T[N x M] = W[N x K] . In^T[K x M]  with v_mfma_f32_16x16x4_f32:
+//   A operand (one VGPR): lane l holds W[n = 16*nb + (l&15)][k-slot (l>>4)]      (weights)
+//   B operand (one VGPR): lane l holds In^T[k-slot (l>>4)][sample (l&15)]        (activations)
+//   C/D (4 VGPRs):        lane l, reg r holds Out^T[n = 16*nb + 4*(l>>4) + r][sample (l&15)]
+// The contraction order is free, so k-step t of a 256-wide input uses, for lane group
+// g = l>>4, the logical column  kmap(t,g) = 16*(t>>2) + 4*g + (t&3).  With that choice
+// accumulator register r of block nb of one layer IS the B operand of k-step 4*nb+r of the
+// next layer: activations never leave their lane between layers (no LDS round trip, no
+// shuffles), and only the weights stream.
+//
+// A "tile" is the A operand of 4 consecutive k-steps for one 16-row block: 64 lanes x 4
+// floats = 1 KiB, read with one conflict-free ds_read_b128 per lane.  Float j of lane l of
+// tile (tq, nb) is  W[16*nb + (l&15)][col(4*tq + j, l>>4)].  Tiles are stored in exactly the
+// order the kernel consumes them (stage by stage, k-block by k-block, row block by row
+// block), so the global->LDS stream is one linear, fully coalesced read.
+#pragma once
+#include <stdint.h>
+
+namespace mnrf {
+
+constexpr int W = 256;          // hidden width (mirror_nerf.py:43)
+constexpr int ENC_XYZ = 63;     // 3 + 3*2*10
+constexpr int ENC_DIR = 27;     // 3 + 3*2*4
+constexpr int NFREQ_XYZ = 10;
+constexpr int NFREQ_DIR = 4;
+
+constexpr int TILE_FLOATS = 256;
+constexpr int TILE_BYTES = 1024;
+constexpr int CHUNK_TILES = 8;   // LDS staging granule: 8 KiB
+constexpr int CHUNK_BYTES = CHUNK_TILES * TILE_BYTES;
+
+// how the 4*ntq k-steps of a part map to columns of the nn.Linear weight
+enum PartKind : int {
+    KIND_H = 0,    // 16*(t>>2) + 4*g + (t&3)                       (hidden activations)
+    KIND_ENC = 1,  // xyz encoding in (sin,cos) pairs: P = 8*g + (t>>1), s = t&1   (see enc_col)
+    KIND_DIR = 2,  // dir encoding padded to 32: e = 16*(t>>2) + 4*g + (t&3), e >= 27 -> zero
+};
+
+// Column of the 63-wide xyz encoding held by lane group g at k-step t of an ENC part.
+// Pair P < 30 is frequency f = P/3, axis a = P%3: sin at 3+6f+a, cos at 6+6f+a
+// (channel order of Embedding.forward, mirror_nerf.py:31-38); P = 30 -> (x, y); P = 31 -> (z, pad).
+__host__ __device__ inline int enc_col(int t, int g) {
+    const int P = 8 * g + (t >> 1);
+    const int s = t & 1;
+    if (P < 30) return 3 + 6 * (P / 3) + 3 * s + (P % 3);
+    if (P == 30) return s;
+    return s == 0 ? 2 : -1;
+}
+
+struct Part {
+    int param;      // index into the state_dict-ordered parameter list (weight tensor)
+    int n_true;     // rows of the nn.Linear weight (out features)
+    int ld;         // in features (row stride of the weight)
+    int ntq;        // k-blocks of 16 in this part
+    int nb;         // 16-row blocks of the stage output
+    int col_off;    // first weight column of this part
+    int kind;       // PartKind
+    int tile0;      // first tile of the part inside its stream
+};
+
+// ---- forward stream -------------------------------------------------------------------
+// stage:       L1   L2..L4  L5(enc,h)  L6..L8  SIG | NRM1 NRM2 MIR1 MIR2 FIN  DIR(h,dir)  RGB
+// (the heads that only read geo_feat come first so that geo_feat dies before the colour branch)
+constexpr int N_FWD_PARTS = 18;
+constexpr int N_BWD_PARTS = 9;
+constexpr int FWD_TILES_SIGMA = 64 + 3 * 256 + 320 + 3 * 256 + 16;               // 1936
+constexpr int FWD_TILES = FWD_TILES_SIGMA + 128 + 8 + 128 + 8 + 256 + 144 + 8;   // 2616
+// ---- backward (density-gradient) stream: A = W_i^T for i = 8..1 ------------------------
+constexpr int BWD_TILES = 3 * 256 + 320 + 3 * 256 + 64;                           // 1920
+
+// bias block (floats): per stage, padded to the stage's 16*nb rows; then w_sigma (256)
+constexpr int BIAS_L = 0;             // 8 x 256
+constexpr int BIAS_SIG = 2048;        // 16
+constexpr int BIAS_FIN = 2064;        // 256
+constexpr int BIAS_DIR = 2320;        // 128
+constexpr int BIAS_RGB = 2448;        // 16
+constexpr int BIAS_NRM1 = 2464;       // 128
+constexpr int BIAS_NRM2 = 2592;       // 16
+constexpr int BIAS_MIR1 = 2608;       // 128
+constexpr int BIAS_MIR2 = 2736;       // 16
+constexpr int BIAS_WSIG = 2752;       // 256: sigma.weight, seed of the density gradient
+constexpr int BIAS_FLOATS = 3072;     // padded to 12 KiB
+
+constexpr int64_t OFF_FWD = 0;
+constexpr int64_t OFF_BIAS = (int64_t)FWD_TILES * TILE_FLOATS;
+constexpr int64_t OFF_BWD = OFF_BIAS + BIAS_FLOATS;
+constexpr int64_t PACKED_FLOATS = OFF_BWD + (int64_t)BWD_TILES * TILE_FLOATS;
+
+static_assert(FWD_TILES % CHUNK_TILES == 0 && FWD_TILES_SIGMA % CHUNK_TILES == 0, "chunking");
+static_assert(BWD_TILES % CHUNK_TILES == 0, "chunking");
+
+}  // namespace mnrf

@@ -1,0 +1,494 @@
+// mnrf_render.hip -- the ray-side kernels of the rendering hot path for gfx950:
+// view/position embedding, coarse depth sampling, alpha compositing with a wavefront
+// prefix product, hierarchical resampling (inverse CDF + sort), mirror-mask thresholding,
+// reflected-ray construction with order-preserving compaction, blend/scatter, pin-hole
+// ray generation.  All of them are HBM-bound streaming kernels (a few dozen bytes per
+// sample); they exist so that nothing on the path runs as a chain of framework ops.
+// Compiled with -ffp-contract=off (separate multiply and add as in the reference).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mnrf.h"
+#include "mnrf_error.h"
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+
+int mnrf_fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int mnrf_check_launch(const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+        return MNRF_ERR_LAUNCH;
+    }
+    return MNRF_OK;
+}
+
+extern "C" const char* mnrf_last_error(void) { return g_err; }
+extern "C" int mnrf_version(void) { return 1; }
+
+namespace {
+
+constexpr float EPS32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps, utils/func.py:5
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ Embedding.forward
+// models/mirror_nerf.py:20-38: out = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)]
+__global__ void embed_kernel(const float* __restrict__ x, long long n, int c, int n_freqs, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const long long row = i / c;
+    const int ch = (int)(i % c);
+    const int ld = c * (2 * n_freqs + 1);
+    const float v = x[i];
+    float* o = out + row * ld;
+    o[ch] = v;
+    for (int f = 0; f < n_freqs; ++f) {
+        float s, co;
+        sincosf(ldexpf(v, f), &s, &co);
+        o[c * (1 + 2 * f) + ch] = s;
+        o[c * (2 + 2 * f) + ch] = co;
+    }
+}
+
+// ------------------------------------------------------------------ coarse depths
+// models/rendering.py:283-300
+__global__ void sample_coarse_kernel(const float* __restrict__ rays, long long n_rays, const float* __restrict__ z_steps,
+                                     int ns, int use_disp, float perturb, const float* __restrict__ prand,
+                                     float* __restrict__ z_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * ns) return;
+    const long long r = i / ns;
+    const int s = (int)(i % ns);
+    const float near = rays[r * 8 + 6], far = rays[r * 8 + 7];
+    auto zat = [&](int k) -> float {
+        const float t = z_steps[k];
+        if (!use_disp) return near * (1.f - t) + far * t;
+        return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);
+    };
+    float z = zat(s);
+    if (perturb > 0.f) {
+        const float lower = s == 0 ? z : 0.5f * (zat(s - 1) + z);
+        const float upper = s == ns - 1 ? z : 0.5f * (z + zat(s + 1));
+        z = lower + (upper - lower) * (perturb * prand[i]);
+    }
+    z_out[i] = z;
+}
+
+// ------------------------------------------------------------------ alpha compositing
+// models/rendering.py:181-264, 362-367.  One wavefront per ray; the transmittance
+// T_i = prod_{j<i} (1 - alpha_j + 1e-10) is an exclusive prefix product over the lanes
+// (Hillis-Steele over __shfl_up), carried across 64-sample blocks.
+struct CompArgs {
+    const float* rays; long long n_rays; int S;
+    const float* sigma; const float* z; const float* noise; const float* rgb; const float* is_mirror;
+    const float* pred_normal; const float* normal; int white_back;
+    float* weights; float* opacity; float* rgb_map; float* depth; float* mirror_mask;
+    float* surf_normal; float* surf_normal_grad; float* normal_dif; float* x_surface;
+};
+
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= A.n_rays) return;
+    const int S = A.S;
+    const float* sg = A.sigma + ray * S;
+    const float* zz = A.z + ray * S;
+    float carry = 1.f;
+    float a_op = 0.f, a_d = 0.f, a_m = 0.f, a_nd = 0.f;
+    float a_c[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f}, a_g[3] = {0.f, 0.f, 0.f};
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool in = s < S;
+        float alpha = 0.f, zv = 0.f;
+        if (in) {
+            zv = zz[s];
+            const float delta = s + 1 < S ? zz[s + 1] - zv : 1e10f;   // rendering.py:182-186
+            float sv = sg[s];
+            if (A.noise) sv = sv + A.noise[ray * S + s];
+            alpha = 1.f - expf(-delta * fmaxf(sv, 0.f));                 // 190-192
+        }
+        const float t = in ? (1.f - alpha) + 1e-10f : 1.f;              // 195
+        float incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o);
+            if (lane >= o) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float w = alpha * (carry * excl);                         // 197-199
+        carry = carry * __shfl(incl, 63);
+        if (in) {
+            if (A.weights) A.weights[ray * S + s] = w;
+            a_op += w;
+            a_d += w * zv;
+            const long long i3 = (ray * S + s) * 3;
+            if (A.rgb) { a_c[0] += w * A.rgb[i3]; a_c[1] += w * A.rgb[i3 + 1]; a_c[2] += w * A.rgb[i3 + 2]; }
+            if (A.is_mirror) a_m += w * A.is_mirror[ray * S + s];
+            float pn[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+            if (A.pred_normal) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pn[k] = A.pred_normal[i3 + k]; a_n[k] += pn[k] * w; }
+            }
+            if (A.normal) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gn[k] = A.normal[i3 + k]; a_g[k] += gn[k] * w; }
+            }
+            if (A.pred_normal && A.normal) {
+                const float d0 = gn[0] - pn[0], d1 = gn[1] - pn[1], d2 = gn[2] - pn[2];
+                a_nd += w * (d0 * d0 + d1 * d1 + d2 * d2);
+            }
+        }
+    }
+    a_op = wave_sum(a_op);
+    a_d = wave_sum(a_d);
+    a_m = wave_sum(a_m);
+    a_nd = wave_sum(a_nd);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a_c[k] = wave_sum(a_c[k]); a_n[k] = wave_sum(a_n[k]); a_g[k] = wave_sum(a_g[k]); }
+    if (lane == 0) {
+        if (A.opacity) A.opacity[ray] = a_op;
+        if (A.rgb_map) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A.rgb_map[ray * 3 + k] = A.white_back ? a_c[k] + (1.f - a_op) : a_c[k];
+        }
+        if (A.depth) A.depth[ray] = a_d;
+        if (A.mirror_mask) A.mirror_mask[ray] = a_m;
+        if (A.surf_normal) { for (int k = 0; k < 3; ++k) A.surf_normal[ray * 3 + k] = a_n[k]; }
+        if (A.surf_normal_grad) { for (int k = 0; k < 3; ++k) A.surf_normal_grad[ray * 3 + k] = a_g[k]; }
+        if (A.normal_dif) A.normal_dif[ray] = a_nd;
+        if (A.x_surface) {
+            const float* r = A.rays + ray * 8;
+            for (int k = 0; k < 3; ++k) A.x_surface[ray * 3 + k] = r[k] + r[3 + k] * a_d;   // 362-367
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hierarchical resampling
+// models/rendering.py:7-51 (sample_pdf) + 312-326 (merge and sort).  One wavefront per ray.
+// cdf is accumulated in double and rounded per entry, as ATen's CPU cumsum does.
+constexpr int SF_MAX = 512;   // S + n_importance <= 512, S <= 256
+
+__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
+                                                          long long n_rays, int S, const float* __restrict__ u, int u_per_ray,
+                                                          int n_imp, float* __restrict__ z_fine) {
+    __shared__ float s_cdf[4][256];
+    __shared__ float s_bin[4][256];
+    __shared__ float s_sort[4][SF_MAX];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    long long ray = (long long)blockIdx.x * 4 + wv;
+    const bool live = ray < n_rays;
+    if (!live) ray = n_rays - 1;
+    const float* zc = z_coarse + ray * S;
+    const float* wc = weights + ray * S;
+    const int nw = S - 2;          // weights[:, 1:-1]
+    const int nbins = S - 1;       // mid-points
+    float* cdf = s_cdf[wv];
+    float* bin = s_bin[wv];
+    float* srt = s_sort[wv];
+    const float eps = 1e-5f;
+    // mid-points and the weight sum
+    float part = 0.f;
+    for (int i = lane; i < nbins; i += 64) bin[i] = 0.5f * (zc[i] + zc[i + 1]);
+    for (int i = lane; i < nw; i += 64) part += wc[1 + i] + eps;
+    const float total = wave_sum(part);
+    // cdf[0] = 0, cdf[i+1] = cumsum(pdf)[i]
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int base = 0; base < nw; base += 64) {
+        const int i = base + lane;
+        double v = i < nw ? (double)((wc[1 + i] + eps) / total) : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(v, o);
+            if (lane >= o) v += up;
+        }
+        if (i < nw) cdf[i + 1] = (float)(carry + v);
+        carry += __shfl(v, 63);
+    }
+    // coarse depths go straight into the sort buffer
+    const int T = S + n_imp;
+    int P2 = 1;
+    while (P2 < T) P2 <<= 1;
+    for (int i = lane; i < S; i += 64) srt[i] = zc[i];
+    for (int i = T + lane; i < P2; i += 64) srt[i] = __builtin_inff();
+    __syncthreads();
+    // inverse CDF
+    for (int j = lane; j < n_imp; j += 64) {
+        const float uj = u_per_ray ? u[ray * n_imp + j] : u[j];
+        // searchsorted(cdf, u, right=True): number of entries <= u
+        int lo = 0, hi = nbins;    // cdf has nbins entries
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nw ? lo : nw;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = bin[below], b1 = bin[above];
+        float denom = c1 - c0;
+        if (denom < eps) denom = 1.f;
+        srt[S + j] = b0 + (uj - c0) / denom * (b1 - b0);
+    }
+    __syncthreads();
+    // bitonic sort of P2 values
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = lane; i < P2; i += 64) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const float a = srt[i], b = srt[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (live)
+        for (int i = lane; i < T; i += 64) z_fine[ray * T + i] = srt[i];
+}
+
+// ------------------------------------------------------------------ mask threshold
+// train.py:165-166 / eval.py:305-306: m[m>0.5]=1; m[m<0.5]=0 (exactly 0.5 stays), any(m != 0)
+__global__ void threshold_kernel(float* __restrict__ m, long long n, int* __restrict__ any) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool nz = false;
+    if (i < n) {
+        float v = m[i];
+        if (v > 0.5f) v = 1.f;
+        else if (v < 0.5f) v = 0.f;
+        m[i] = v;
+        nz = v != 0.f;
+    }
+    if (__ballot(nz) != 0ull && (threadIdx.x & 63) == 0 && any) atomicOr(any, 1);
+}
+
+// ------------------------------------------------------------------ reflected rays + compaction
+// train.py:192-252, eval.py:336-360, 506-548.  One workgroup walks the chunk in order so
+// that the compacted rows keep the order of `secondary_rays[mask]`.
+struct ReflArgs {
+    const float* rays; const float* x_surface; const float* normal; const float* normal_noise; float noise_std;
+    const float* mask; long long n; int compact; float near2;
+    float* sec; int* index; int* count; float* reflect_dir;
+};
+
+__global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (long long start = 0; start < A.n; start += 1024) {
+        const long long i = start + tid;
+        const bool in = i < A.n;
+        float r[3] = {0.f, 0.f, 0.f};
+        bool sel = false;
+        if (in) {
+            float nv[3], wvv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                nv[k] = A.normal[i * 3 + k];
+                if (A.normal_noise) nv[k] = nv[k] + A.normal_noise[i * 3 + k] * A.noise_std;   // eval.py:506-511
+                wvv[k] = -A.rays[i * 8 + 3 + k];
+            }
+            // l2_normalize (utils/func.py:5-7) of both, then r = 2 (w.n) n - w
+            const float ninv = 1.f / sqrtf(fmaxf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2], EPS32));
+            const float winv = 1.f / sqrtf(fmaxf(wvv[0] * wvv[0] + wvv[1] * wvv[1] + wvv[2] * wvv[2], EPS32));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { nv[k] = nv[k] * ninv; wvv[k] = wvv[k] * winv; }
+            const float c = wvv[0] * nv[0] + wvv[1] * nv[1] + wvv[2] * nv[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r[k] = 2.f * c * nv[k] - wvv[k];
+            if (A.reflect_dir) { for (int k = 0; k < 3; ++k) A.reflect_dir[i * 3 + k] = r[k]; }
+            sel = A.compact ? (A.mask[i] != 0.f) : true;
+        }
+        const unsigned long long bal = __ballot(sel);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const int c = s_wave[k]; if (k < wv) woff += c; tot += c; }
+        const int base = s_base;
+        if (sel) {
+            const long long p = base + woff + before;
+            float* o = A.sec + p * 8;
+            o[0] = A.x_surface[i * 3]; o[1] = A.x_surface[i * 3 + 1]; o[2] = A.x_surface[i * 3 + 2];
+            o[3] = r[0]; o[4] = r[1]; o[5] = r[2];
+            o[6] = A.near2;                    // ray_forward_offset, absolute (train.py:232, eval.py:529)
+            o[7] = A.rays[i * 8 + 7];
+            A.index[p] = (int)i;
+        }
+        __syncthreads();
+        if (tid == 0) s_base = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) *A.count = s_base;
+}
+
+// ------------------------------------------------------------------ blend / scatter
+// train.py:261-296, eval.py:676-697
+__global__ void blend_all_kernel(const float* __restrict__ base, const float* __restrict__ sec, const float* __restrict__ mask,
+                                 long long n, int c, int direct, float* __restrict__ out, float* __restrict__ refl) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const float m = mask[i / c];
+    const float b = base[i];
+    const float part = direct ? sec[i] : b;   // compacted case: rows without a source keep base
+    out[i] = m * part + (1.f - m) * b;
+    if (refl) refl[i] = direct ? sec[i] : 0.f;
+}
+
+__global__ void blend_scatter_kernel(const float* __restrict__ base, const float* __restrict__ sec, const int* __restrict__ index,
+                                     long long n_sec, const float* __restrict__ mask, int c, float* __restrict__ out,
+                                     float* __restrict__ refl) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sec * c) return;
+    const long long row = index[j / c];
+    const int ch = (int)(j % c);
+    const float m = mask[row];
+    const float v = sec[j];
+    out[row * c + ch] = m * v + (1.f - m) * base[row * c + ch];
+    if (refl) refl[row * c + ch] = v;
+}
+
+// ------------------------------------------------------------------ pin-hole rays
+// datasets/ray_utils.py:6-53
+struct Pose { float m[12]; };
+
+__global__ void generate_rays_kernel(int H, int W, float focal, Pose c2w, float near, float far, float* __restrict__ rays) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)H * W) return;
+    const int i = (int)(p % W), j = (int)(p / W);
+    const float dx = ((float)i - (float)W / 2.f) / focal;   // no +0.5 (ray_utils.py:19-24)
+    const float dy = -((float)j - (float)H / 2.f) / focal;
+    const float dz = -1.f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = dx * c2w.m[r * 4] + dy * c2w.m[r * 4 + 1] + dz * c2w.m[r * 4 + 2];
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float* o = rays + p * 8;
+    o[0] = c2w.m[3]; o[1] = c2w.m[7]; o[2] = c2w.m[11];
+    o[3] = d[0] / nrm; o[4] = d[1] / nrm; o[5] = d[2] / nrm;
+    o[6] = near; o[7] = far;
+}
+
+inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* stream) {
+    if (n < 0 || c < 1 || n_freqs < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!x || !out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed: null pointer");
+    hipLaunchKernelGGL(embed_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, c,
+                       n_freqs, out);
+    return mnrf_check_launch("mnrf_embed");
+}
+
+extern "C" int mnrf_sample_coarse(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp,
+                                  float perturb, const float* perturb_rand, float* z_vals, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: bad size");
+    if (n_rays == 0) return MNRF_OK;
+    if (!rays || !z_steps || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: null pointer");
+    if (perturb > 0.f && !perturb_rand) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: perturb > 0 needs perturb_rand");
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3(blocks_for(n_rays * n_samples, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, (long long)n_rays, z_steps, n_samples, use_disp, perturb, perturb_rand, z_vals);
+    return mnrf_check_launch("mnrf_sample_coarse");
+}
+
+extern "C" int mnrf_composite(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                              const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
+                              const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
+                              float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
+                              float* normal_dif, float* x_surface, void* stream) {
+    if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: bad size");
+    if (n_rays == 0) return MNRF_OK;
+    if (!sigma || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: sigma and z_vals are required");
+    if (rgb_map && !rgb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: rgb_map needs rgb");
+    if (mirror_mask && !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: mirror_mask needs is_mirror");
+    if (surf_normal && !pred_normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: surf_normal needs pred_normal");
+    if (surf_normal_grad && !normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: surf_normal_grad needs normal");
+    if (normal_dif && !(normal && pred_normal)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: normal_dif needs both normals");
+    if (x_surface && !rays) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: x_surface needs rays");
+    CompArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
+               weights, opacity, rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface};
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_composite");
+}
+
+extern "C" int mnrf_sample_fine(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,
+                                int u_per_ray, int n_importance, float* z_fine, void* stream) {
+    if (n_rays < 0 || S < 3 || n_importance < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_fine: bad size");
+    if (S > 256 || S + n_importance > SF_MAX)
+        return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_sample_fine: needs S <= 256 and S + n_importance <= 512");
+    if (n_rays == 0) return MNRF_OK;
+    if (!z_coarse || !weights || !u || !z_fine) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_fine: null pointer");
+    hipLaunchKernelGGL(sample_fine_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, z_coarse, weights,
+                       (long long)n_rays, S, u, u_per_ray, n_importance, z_fine);
+    return mnrf_check_launch("mnrf_sample_fine");
+}
+
+extern "C" int mnrf_threshold_mask(float* mask, int64_t n, int32_t* any, void* stream) {
+    if (n < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_threshold_mask: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_threshold_mask: null pointer");
+    hipLaunchKernelGGL(threshold_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long long)n, any);
+    return mnrf_check_launch("mnrf_threshold_mask");
+}
+
+extern "C" int mnrf_reflect_compact(const float* rays, const float* x_surface, const float* normal,
+                                    const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
+                                    int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
+                                    float* reflect_dir, void* stream) {
+    if (n_rays < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: bad size");
+    if (!count) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: count is null");
+    if (n_rays > 0 && (!rays || !x_surface || !normal || !sec_rays || !index))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: null pointer");
+    if (compact && n_rays > 0 && !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: compaction needs the mask");
+    ReflArgs A{rays, x_surface, normal, normal_noise, noise_std, mask, (long long)n_rays, compact, near2,
+               sec_rays, index, count, reflect_dir};
+    hipLaunchKernelGGL(reflect_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_reflect_compact");
+}
+
+extern "C" int mnrf_blend_scatter(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                                  const float* mask, int64_t n, int c, float* out, float* reflect_out, void* stream) {
+    if (n < 0 || n_sec < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!base || !mask || !out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: null pointer");
+    if (n_sec > 0 && !sec) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: sec is null");
+    if (!index && n_sec != n) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: without an index n_sec must equal n");
+    hipStream_t s = (hipStream_t)stream;
+    const int direct = index == nullptr;
+    hipLaunchKernelGGL(blend_all_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, s, base, sec, mask, (long long)n, c,
+                       direct, out, reflect_out);
+    if (!direct && n_sec > 0)
+        hipLaunchKernelGGL(blend_scatter_kernel, dim3(blocks_for(n_sec * c, 256)), dim3(256), 0, s, base, sec, index,
+                           (long long)n_sec, mask, c, out, reflect_out);
+    return mnrf_check_launch("mnrf_blend_scatter");
+}
+
+extern "C" int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far, float* rays,
+                                  void* stream) {
+    if (H < 1 || W < 1 || !c2w_host12 || !rays) return mnrf_fail(MNRF_ERR_ARG, "mnrf_generate_rays: bad argument");
+    Pose p;
+    memcpy(p.m, c2w_host12, sizeof(p.m));
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for((long long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, H, W,
+                       focal, p, near, far, rays);
+    return mnrf_check_launch("mnrf_generate_rays");
+}

@@ -1,0 +1,278 @@
+"""Whitted-style reflected-ray recursion around render_rays, in both rule sets of the reference:
+
+  * `NeRFSystem.forward` / `render_rays_chunk_recursively`  -- TRAIN semantics, train.py:102-348
+  * `batched_inference`                                      -- EVAL semantics, eval.py:114-172,
+    293-360, 506-548, 614-740 (core path + roughness; the scene-editing demo branches
+    place-mirror / substitution / new-object are out of scope)
+
+Python here is the recursion driver only: mask thresholding, reflected-ray construction,
+order-preserving compaction and blending are the HIP kernels mnrf_threshold_mask,
+mnrf_reflect_compact and mnrf_blend_scatter.  One 4-byte device->host read per level decides
+whether (and how many) reflected rays are traced -- the reference syncs at the same place
+through `mirror_mask.bool().any()` (train.py:175, eval.py:315).
+"""
+from collections import defaultdict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import _lib
+from .mirror_nerf import Embedding, MirrorNeRF
+from .rendering import render_rays
+
+RAY_FORWARD_OFFSET = 0.1   # train.py:232, eval.py:529 (absolute near of a reflected ray)
+
+
+def _f(dev, *s):
+    return torch.empty(*s, dtype=torch.float32, device=dev)
+
+
+def _threshold_(mask):
+    """In place m[m>0.5]=1, m[m<0.5]=0 (exactly 0.5 untouched); returns any(m != 0) as a bool."""
+    n = mask.shape[0]
+    flag = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    if n:
+        _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), n, _lib.ptr(flag), _lib.stream()),
+                   "mnrf_threshold_mask")
+    return bool(flag.item())
+
+
+def _reflect(rays, x_surface, normal, mask, compact, normal_noise=None, noise_std=0.0, want_dir=True):
+    """-> (secondary rays (M,8), index (M,) int32 or None when not compacted, reflect_dir (N,3))."""
+    N = rays.shape[0]
+    dev = rays.device
+    sec = _f(dev, N, 8)
+    index = torch.empty(N, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    rdir = _f(dev, N, 3) if want_dir else None
+    p = _lib.ptr
+    _lib.check(_lib.lib().mnrf_reflect_compact(
+        p(rays), p(x_surface.contiguous()), p(normal.contiguous()), p(normal_noise), float(noise_std),
+        p(mask.contiguous()) if mask is not None else None, N, int(bool(compact)), RAY_FORWARD_OFFSET,
+        p(sec), p(index), p(count), p(rdir), _lib.stream()), "mnrf_reflect_compact")
+    M = int(count.item()) if compact else N
+    return sec[:M], (index[:M] if compact else None), rdir
+
+
+def _blend(base, sec, index, mask, want_reflect):
+    """m*part + (1-m)*base with part = sec scattered through index (or sec itself)."""
+    N, c = base.shape[0], (base.shape[1] if base.dim() == 2 else 1)
+    dev = base.device
+    out = torch.empty_like(base)
+    refl = torch.empty_like(base) if want_reflect else None
+    p = _lib.ptr
+    _lib.check(_lib.lib().mnrf_blend_scatter(
+        p(base.contiguous()), p(sec.contiguous()), p(index), sec.shape[0], p(mask), N, c, p(out), p(refl),
+        _lib.stream()), "mnrf_blend_scatter")
+    return out, refl
+
+
+def _pick_normal(r, sel):
+    """train.py:194-215 / eval.py:338-360 -- composited predicted normal, else composited grad normal."""
+    if f"pred_normal_{sel}" in r:
+        return r[f"surface_normal_{sel}"]
+    return r[f"surface_normal_grad_{sel}"]
+
+
+# ----------------------------------------------------------------------------- train semantics
+def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_level,
+                                  extra_chunk, white_back=False, train_geometry_stage=False):
+    """train.py:129-348."""
+    r = render_rays(models, embeddings, rays_chunk, hp.N_samples, hp.use_disp, hp.perturb, hp.noise_std,
+                    hp.N_importance, hp.chunk, white_back, compute_normal=hp.trace_secondary_rays,
+                    **extra_chunk)
+    N = rays_chunk.shape[0]
+    dev = rays_chunk.device
+    sel = "fine" if (hp.N_importance > 0 and not hp.only_one_field) else "coarse"
+
+    # -- mirror mask (train.py:153-168)
+    gt = extra_chunk["mirror_mask"].float()
+    any_mirror = None
+    if recur_level > 0 or bool((gt < 0).any().item()):
+        # the reference thresholds `results[...].detach()` in place: the returned predicted
+        # mask is the hard one
+        if "mirror_mask_fine" in r:
+            mask = r["mirror_mask_fine"]
+        elif "mirror_mask_coarse" in r:
+            mask = r["mirror_mask_coarse"]
+        else:
+            mask = torch.zeros(N, device=dev)
+        any_mirror = _threshold_(mask)
+    else:
+        mask = gt.clone().contiguous()
+    only_in = hp.only_trace_rays_in_mirrors
+    if (not only_in) and recur_level > 0:
+        mask = mask * mirror_mask_prev.float()
+        any_mirror = None
+    if any_mirror is None:
+        any_mirror = bool((mask != 0).any().item()) if N else False
+
+    # -- trace decision (train.py:170-178)
+    trace = bool(hp.trace_secondary_rays and (not train_geometry_stage) and (any_mirror or hp.for_vis))
+    if recur_level >= hp.max_recursive_level:
+        trace = False
+    is_eval = extra_chunk.get("is_eval", False)
+
+    traced = False
+    if trace and N:
+        sec, index, rdir = _reflect(rays_chunk, r[f"x_surface_{sel}"], _pick_normal(r, sel), mask, only_in)
+        if sec.shape[0] > 0:
+            traced = True
+            r2 = render_rays_chunk_recursively(models, embeddings, hp, sec.contiguous(), mask, recur_level + 1,
+                                               extra_chunk, white_back, train_geometry_stage)
+            for typ in ("coarse", "fine"):                               # train.py:263-311
+                if f"rgb_{typ}" in r and f"rgb_{typ}" in r2:
+                    r[f"rgb_{typ}_direct"] = r[f"rgb_{typ}"]
+                    r[f"rgb_{typ}"], refl = _blend(r[f"rgb_{typ}"], r2[f"rgb_{typ}"], index, mask, is_eval)
+                    if is_eval:
+                        r[f"rgb_{typ}_reflect"] = refl
+            if is_eval:                                                  # train.py:312-324
+                if only_in:
+                    d = torch.zeros_like(r[f"depth_{sel}"])
+                    d[index.long()] = r2[f"depth_{sel}"]
+                    r[f"depth_{sel}_reflect"] = d
+                else:
+                    r[f"depth_{sel}_reflect"] = r2[f"depth_{sel}"]
+                r["secondary_rays_o"] = r[f"x_surface_{sel}"]
+                r["reflect_direction"] = rdir
+    if not trace and is_eval:                                            # train.py:325-346
+        for typ in ("coarse", "fine"):
+            if f"rgb_{typ}" in r:
+                r[f"rgb_{typ}_reflect"] = torch.zeros_like(r[f"rgb_{typ}"])
+                r[f"rgb_{typ}_direct"] = torch.zeros_like(r[f"rgb_{typ}"])
+        r[f"depth_{sel}_reflect"] = torch.zeros_like(r[f"depth_{sel}"])
+        r["secondary_rays_o"] = torch.zeros_like(r[f"rgb_{sel}"])
+        r["reflect_direction"] = torch.zeros_like(r[f"rgb_{sel}"])
+    del traced
+    return r
+
+
+class NeRFSystem(nn.Module):
+    """The model-holding part of train.NeRFSystem (train.py:33-127): same attribute names
+    (`nerf_coarse`, `nerf_fine`, `embedding_xyz`, `embedding_dir`, `models`, `embeddings`) and the
+    same `forward(rays, extra)`.  The Lightning training loop around it is out of scope."""
+
+    def __init__(self, hparams, white_back=False):
+        super().__init__()
+        self.hparams = hparams if not isinstance(hparams, dict) else SimpleNamespace(**hparams)
+        hp = self.hparams
+        if getattr(hp, "model_type", "nerf") != "nerf":
+            raise NotImplementedError("model_type nerf_tcnn (hash grid) is not built yet")
+        self.train_geometry_stage = getattr(hp, "train_geometry_stage", False)
+        self.white_back = white_back
+        self.embedding_xyz = Embedding(hp.N_emb_xyz)
+        self.embedding_dir = Embedding(hp.N_emb_dir)
+        self.embeddings = {"xyz": self.embedding_xyz, "dir": self.embedding_dir}
+        kw = dict(in_channels_xyz=6 * hp.N_emb_xyz + 3, in_channels_dir=6 * hp.N_emb_dir + 3,
+                  predict_normal=hp.predict_normal, predict_mirror_mask=hp.predict_mirror_mask)
+        self.nerf_coarse = MirrorNeRF(**kw)
+        self.models = {"coarse": self.nerf_coarse}
+        if hp.N_importance > 0 and not hp.only_one_field:
+            self.nerf_fine = MirrorNeRF(**kw)
+            self.models["fine"] = self.nerf_fine
+
+    def forward(self, rays, extra=dict()):
+        hp = self.hparams
+        results = defaultdict(list)
+        for i in range(0, rays.shape[0], hp.chunk):
+            ex = {k: (v[i:i + hp.chunk] if isinstance(v, torch.Tensor) else v) for k, v in extra.items()}
+            rc = rays[i:i + hp.chunk].contiguous()
+            first = torch.ones(rc.shape[0], dtype=torch.bool, device=rc.device)
+            out = render_rays_chunk_recursively(self.models, self.embeddings, hp, rc, first, 0, ex,
+                                                self.white_back, self.train_geometry_stage)
+            for k, v in out.items():
+                results[k] += [v]
+        return {k: torch.cat(v, 0) for k, v in results.items()}
+
+
+# ----------------------------------------------------------------------------- eval semantics
+@torch.no_grad()
+def batched_inference(models, embeddings, rays, N_samples, N_importance, use_disp, chunk, **kwargs):
+    """eval.batched_inference.  kwargs: args (namespace/dict with predict_normal, only_one_field,
+    only_one_field_fine_epoch, max_recursive_level, app_control_mirror_roughness, trace_ray_times),
+    trace_secondary_rays, normal_noise_std, test_time, white_back (the reference reads the module
+    global `dataset.white_back`), to_cpu (default True: eval.py:735-736 moves every value to the CPU),
+    _normal_noise (iterator of pre-drawn (n,3) standard-normal tensors, for tests)."""
+    args = kwargs.get("args")
+    if isinstance(args, dict):
+        args = SimpleNamespace(**args)
+    for flag in ("app_place_new_mirror", "app_reflection_substitution", "app_reflect_newly_placed_objects"):
+        if getattr(args, flag, False):
+            raise NotImplementedError(f"{flag}: scene-editing demo branches are out of scope")
+    trace_flag = kwargs.get("trace_secondary_rays", False)
+    test_time = kwargs.get("test_time", True)
+    white_back = kwargs.get("white_back", False)
+    noise_std = kwargs.get("normal_noise_std", 0)
+    noise_iter = kwargs.get("_normal_noise")
+    to_cpu = kwargs.get("to_cpu", True)
+    rough = getattr(args, "app_control_mirror_roughness", False)
+    one_field = getattr(args, "only_one_field", False)
+    fine_epoch = getattr(args, "only_one_field_fine_epoch", 2)
+    sel = "fine" if (N_importance > 0 and not one_field) else "coarse"
+
+    def draw(n, dev):
+        if noise_iter is not None:
+            return next(noise_iter).to(dev).float().contiguous()
+        return torch.randn(n, 3, device=dev)
+
+    def recurse(rays_chunk, level):
+        r = render_rays(models, embeddings, rays_chunk, N_samples, use_disp, 0, 0, N_importance, chunk,
+                        white_back, test_time=test_time,
+                        compute_normal=trace_flag and (not args.predict_normal),
+                        only_one_field=one_field, only_one_field_fine_epoch=fine_epoch,
+                        current_epoch=fine_epoch + 1)
+        N = rays_chunk.shape[0]
+        dev = rays_chunk.device
+        only_in = not (level < 1)                                         # eval.py:159
+        r[f"rgb_{sel}_reflect"] = torch.zeros_like(r[f"rgb_{sel}"])
+        r[f"depth_{sel}_reflect"] = torch.zeros_like(r[f"depth_{sel}"])
+        mask = None
+        for key in (f"mirror_mask_{sel}", "mirror_mask_fine", "mirror_mask_coarse"):
+            if key in r:
+                mask = r[key]
+                break
+        any_mirror = _threshold_(mask) if mask is not None else False     # in place (eval.py:303-307)
+        trace = bool(mask is not None and any_mirror and trace_flag)
+        if level >= args.max_recursive_level:
+            trace = False
+        if not trace or N == 0:
+            return r
+        # `mirror_mask = mirror_mask.bool()` then `.float()` (eval.py:307, 689): an exact 0.5 blends as 1
+        mask = (mask != 0).float()
+        normal = _pick_normal(r, sel)
+        nn0 = draw(N, dev) if rough else None                             # eval.py:506-511
+        sec, index, rdir = _reflect(rays_chunk, r[f"x_surface_{sel}"], normal, mask, only_in, nn0, noise_std)
+        r["reflect_direction"] = rdir
+        if sec.shape[0] > 0:
+            r2 = recurse(sec.contiguous(), level + 1)
+            if rough:                                                     # eval.py:622-674
+                times = args.trace_ray_times
+                for _ in range(times):
+                    s2, _, _ = _reflect(rays_chunk, r[f"x_surface_{sel}"], normal, mask, True, draw(N, dev),
+                                        noise_std, want_dir=False)
+                    r3 = recurse(s2.contiguous(), level + 1)
+                    for typ in ("coarse", "fine"):
+                        if f"rgb_{typ}" in r2:
+                            # the reference adds tensors of M = sum(mask) rows to the first secondary
+                            # render; at level 0 that only works when every ray is a mirror
+                            r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] + r3[f"rgb_{typ}"]
+                for typ in ("coarse", "fine"):
+                    if f"rgb_{typ}" in r2:
+                        r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] / (times + 1)
+            r[f"rgb_{sel}"], refl = _blend(r[f"rgb_{sel}"], r2[f"rgb_{sel}"], index, mask, True)
+            r[f"rgb_{sel}_reflect"] = refl
+            if only_in:
+                d = torch.zeros_like(r[f"depth_{sel}"])
+                d[index.long()] = r2[f"depth_{sel}"]
+                r[f"depth_{sel}_reflect"] = d
+            else:
+                r[f"depth_{sel}_reflect"] = r2[f"depth_{sel}"]
+        return r
+
+    results = defaultdict(list)
+    for i in range(0, rays.shape[0], chunk):
+        out = recurse(rays[i:i + chunk].contiguous(), 0)
+        for k, v in out.items():
+            results[k] += [v.cpu() if to_cpu else v]
+    return {k: torch.cat(v, 0) for k, v in results.items()}

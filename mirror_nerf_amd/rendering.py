@@ -1,0 +1,173 @@
+"""render_rays with the reference's signature and result-dict contract
+(models/rendering.py:54-369), executed by the HIP kernels behind include/mnrf.h.
+
+Per call:  mnrf_embed (view encoding, once per ray) -> mnrf_sample_coarse -> mnrf_field_forward
+(positions generated in-kernel from rays and depths) -> mnrf_composite -> mnrf_sample_fine ->
+mnrf_field_forward -> mnrf_composite.  Python only allocates outputs and assembles the dict.
+
+Differences from the reference that do not change values:
+  * `chunk` does not split the MLP evaluation (the kernel is already tiled; results are
+    independent of the split, SURVEY 8a noise-floor table);
+  * the three detach_* kwargs and `mirror_mask` only steer gradients in the reference;
+  * random draws can be injected (`_perturb_rand`, `_noise_coarse`, `_noise_fine`, `_u`) so that
+    tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator;
+  * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
+Outputs live on rays.device and carry no autograd history.
+"""
+import torch
+
+from . import _lib
+from .mirror_nerf import field_forward
+
+__all__ = ["render_rays", "sample_pdf"]
+
+_LINSPACE = {}
+
+
+def _linspace01(n, device):
+    key = (n, str(device))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = torch.linspace(0, 1, n).to(device)   # CPU kernel, then copy (SURVEY 8a hazard 2)
+        _LINSPACE[key] = t
+    return t
+
+
+def _n_freqs(emb):
+    n = getattr(emb, "N_freqs", None)
+    if n is None:
+        raise RuntimeError("embeddings must expose N_freqs (Embedding modules)")
+    return n
+
+
+def _embed(x, n_freqs):
+    x = x.float().contiguous()
+    n, c = x.shape
+    out = torch.empty(n, c * (2 * n_freqs + 1), dtype=torch.float32, device=x.device)
+    if n:
+        _lib.check(_lib.lib().mnrf_embed(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.stream()), "mnrf_embed")
+    return out
+
+
+def sample_pdf(bins_z, weights, N_importance, det=False, u=None):
+    """Fine depths for rays whose coarse depths are `bins_z` (N,S) and weights (N,S):
+    sample_pdf(mid-points, weights[:,1:-1]) merged with the coarse depths and sorted
+    (models/rendering.py:7-51 and 312-326 in one kernel)."""
+    N, S = bins_z.shape
+    dev = bins_z.device
+    if u is None:
+        u = _linspace01(N_importance, dev) if det else torch.rand(N, N_importance, device=dev)
+    u = u.float().contiguous()
+    per_ray = 1 if u.dim() == 2 else 0
+    z_fine = torch.empty(N, S + N_importance, dtype=torch.float32, device=dev)
+    if N:
+        _lib.check(_lib.lib().mnrf_sample_fine(_lib.ptr(bins_z), _lib.ptr(weights), N, S, _lib.ptr(u), per_ray,
+                                               N_importance, _lib.ptr(z_fine), _lib.stream()), "mnrf_sample_fine")
+    return z_fine
+
+
+def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1,
+                N_importance=0, chunk=1024 * 32, white_back=False, test_time=False, **kwargs):
+    L = _lib.lib()
+    p = _lib.ptr
+    rays = rays.float().contiguous()
+    if not rays.is_cuda:
+        raise RuntimeError("mirror_nerf_amd.render_rays needs CUDA (ROCm) tensors; there is no CPU path")
+    dev = rays.device
+    N = rays.shape[0]
+    compute_normal = kwargs.get("compute_normal", True)
+    n_fx, n_fd = _n_freqs(embeddings["xyz"]), _n_freqs(embeddings["dir"])
+    if n_fx != 10 or n_fd != 4:
+        raise NotImplementedError("the HIP field kernel is built for Embedding(10)/Embedding(4)")
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+
+    # rendering.py:275-277 -- view encoding once per ray
+    dir_emb = _embed(kwargs.get("view_dir", rays[:, 3:6]), n_fd)
+
+    # rendering.py:283-300 -- coarse depths
+    z_steps = kwargs.get("_z_steps")
+    z_steps = _linspace01(N_samples, dev) if z_steps is None else z_steps.float().contiguous()
+    prand = None
+    if perturb > 0:
+        prand = kwargs.get("_perturb_rand")
+        prand = torch.rand(N, N_samples, device=dev) if prand is None else prand.float().contiguous()
+    z_vals = f(N, N_samples)
+    if N:
+        _lib.check(L.mnrf_sample_coarse(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
+                                        p(prand), p(z_vals), _lib.stream()), "mnrf_sample_coarse")
+
+    has_fine = "fine" in models
+    results = {}
+
+    def inference(model, typ, z, noise_key):
+        """rendering.py:108-264 for one pass.  In the sigma-only coarse pass the reference also
+        evaluates (and discards) the normals; they are not computed here."""
+        S = z.shape[1]
+        sigma_only = typ == "coarse" and test_time and has_fine          # rendering.py:139
+        B = N * S
+        if N:
+            o = field_forward(model, B, rays=rays, z_vals=z, spr=S, dir_emb=dir_emb, dir_stride=dir_emb.shape[1],
+                              sigma_only=sigma_only, grad_normal=compute_normal and not sigma_only)
+        else:
+            o = {"sigma": f(0)}
+            if not sigma_only:
+                o.update(rgb=f(0, 3), pred_normal=f(0, 3), is_mirror=f(0))
+                if compute_normal:
+                    o["normal"] = f(0, 3)
+        noise = kwargs.get(noise_key)
+        if noise is not None:
+            noise = (noise.float() * noise_std).contiguous()
+        elif noise_std != 0:
+            noise = torch.randn(N, S, device=dev) * noise_std            # rendering.py:189
+        weights, opacity = f(N, S), f(N)
+        full = not sigma_only
+        rgb_map = f(N, 3) if full else None
+        depth = f(N) if full else None
+        mask = f(N) if full else None
+        sn = f(N, 3) if full else None
+        sng = f(N, 3) if (full and compute_normal) else None
+        nd = f(N) if (full and compute_normal) else None
+        xs = f(N, 3) if full else None
+        if N:
+            _lib.check(L.mnrf_composite(
+                p(rays), N, S, p(o["sigma"]), p(z), p(noise), p(o.get("rgb")), p(o.get("is_mirror")),
+                p(o.get("pred_normal")), p(o.get("normal")) if full else None, int(bool(white_back)),
+                p(weights), p(opacity), p(rgb_map), p(depth), p(mask), p(sn), p(sng), p(nd), p(xs),
+                _lib.stream()), "mnrf_composite")
+        results[f"weights_{typ}"] = weights
+        results[f"opacity_{typ}"] = opacity
+        results[f"z_vals_{typ}"] = z
+        if sigma_only:
+            return                                                        # rendering.py:208-209
+        results[f"rgb_{typ}"] = rgb_map
+        results[f"depth_{typ}"] = depth
+        results[f"mirror_mask_{typ}"] = mask
+        if compute_normal:
+            results[f"normal_{typ}"] = o["normal"].view(N, S, 3)
+            results[f"surface_normal_grad_{typ}"] = sng
+        results[f"pred_normal_{typ}"] = o["pred_normal"].view(N, S, 3)
+        results[f"surface_normal_{typ}"] = sn
+        if compute_normal:
+            results[f"normal_dif_{typ}"] = nd
+        results[f"_x_surface_{typ}"] = xs
+
+    inference(models["coarse"], "coarse", z_vals, "_noise_coarse")
+
+    if N_importance > 0:
+        def fine_depths():
+            u = kwargs.get("_u")
+            if u is None and perturb == 0:
+                u = kwargs.get("_u_det")
+            return sample_pdf(z_vals, results["weights_coarse"], N_importance, det=(perturb == 0), u=u)
+
+        if kwargs.get("only_one_field", False):                           # rendering.py:328-348
+            if kwargs.get("current_epoch", 0) > kwargs.get("only_one_field_fine_epoch", 2):
+                inference(models["coarse"], "coarse", fine_depths(), "_noise_fine")
+        else:                                                             # rendering.py:349-360
+            inference(models["fine"], "fine", fine_depths(), "_noise_fine")
+
+    for typ in ("coarse", "fine"):                                        # rendering.py:362-367
+        xs = results.pop(f"_x_surface_{typ}", None)
+        if f"depth_{typ}" in results:
+            results[f"x_surface_{typ}"] = xs
+    return results

@@ -1,0 +1,88 @@
+"""Packing of a MirrorNeRF state dict into the MFMA-fragment image the field kernel streams.
+
+The interchange format is the reference's parameter naming (`xyz_encoding_{1..8}.0.weight`,
+`xyz_encoding_final`, `dir_encoding.0`, `sigma`, `rgb.0`, `normal_net.{0,1}`,
+`is_mirror_net.{0,2}`; utils/__init__.py:109-136, train.py:56,66), so checkpoints of the
+reference load unchanged.  Weights are read at call time: the packed image is rebuilt
+whenever a parameter changed (optimizer steps bump `_version`).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+PARAM_NAMES = []
+for _i in range(8):
+    PARAM_NAMES += [f"xyz_encoding_{_i+1}.0.weight", f"xyz_encoding_{_i+1}.0.bias"]
+PARAM_NAMES += ["xyz_encoding_final.weight", "xyz_encoding_final.bias",
+                "dir_encoding.0.weight", "dir_encoding.0.bias",
+                "sigma.weight", "sigma.bias", "rgb.0.weight", "rgb.0.bias",
+                "normal_net.0.weight", "normal_net.0.bias", "normal_net.1.weight", "normal_net.1.bias",
+                "is_mirror_net.0.weight", "is_mirror_net.0.bias", "is_mirror_net.2.weight", "is_mirror_net.2.bias"]
+
+PARAM_SHAPES = {}
+for _i in range(8):
+    _in = 63 if _i == 0 else (319 if _i == 4 else 256)
+    PARAM_SHAPES[f"xyz_encoding_{_i+1}.0.weight"] = (256, _in)
+    PARAM_SHAPES[f"xyz_encoding_{_i+1}.0.bias"] = (256,)
+PARAM_SHAPES.update({
+    "xyz_encoding_final.weight": (256, 256), "xyz_encoding_final.bias": (256,),
+    "dir_encoding.0.weight": (128, 283), "dir_encoding.0.bias": (128,),
+    "sigma.weight": (1, 256), "sigma.bias": (1,), "rgb.0.weight": (3, 128), "rgb.0.bias": (3,),
+    "normal_net.0.weight": (128, 256), "normal_net.0.bias": (128,),
+    "normal_net.1.weight": (3, 128), "normal_net.1.bias": (3,),
+    "is_mirror_net.0.weight": (128, 256), "is_mirror_net.0.bias": (128,),
+    "is_mirror_net.2.weight": (1, 128), "is_mirror_net.2.bias": (1,),
+})
+
+
+def pack_state(tensors, out=None):
+    """tensors: dict name -> fp32 CUDA tensor.  Returns the packed image (1-D fp32 CUDA tensor)."""
+    L = _lib.lib()
+    missing = [n for n in PARAM_NAMES if n not in tensors]
+    if missing:
+        raise RuntimeError(
+            "the HIP field kernel implements the reference default architecture with normal and "
+            f"mirror heads (train.py:44-66); missing parameters: {missing}")
+    keep = []
+    arr = (ctypes.c_void_p * _lib.N_PARAMS)()
+    dev = None
+    for i, n in enumerate(PARAM_NAMES):
+        t = tensors[n].detach()
+        if tuple(t.shape) != PARAM_SHAPES[n]:
+            raise RuntimeError(f"{n}: shape {tuple(t.shape)} != {PARAM_SHAPES[n]} (D=8, W=256, N_emb 10/4 only)")
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise RuntimeError(f"{n}: need a float32 CUDA tensor")
+        t = t.contiguous()
+        keep.append(t)
+        arr[i] = t.data_ptr()
+        dev = t.device
+    if out is None:
+        out = torch.empty(L.mnrf_packed_floats(), dtype=torch.float32, device=dev)
+    _lib.check(L.mnrf_pack_weights(arr, _lib.ptr(out), _lib.stream()), "mnrf_pack_weights")
+    return out
+
+
+class PackedCache:
+    """Packed image of one nn.Module (ours or the reference's), refreshed when parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+
+    def get(self, module):
+        sd = dict(module.named_parameters())
+        key = tuple((sd[n].data_ptr(), sd[n]._version) for n in PARAM_NAMES if n in sd)
+        if key != self.key or self.packed is None:
+            self.packed = pack_state(sd, self.packed)
+            self.key = key
+        return self.packed
+
+
+def packed_of(module):
+    cache = module.__dict__.get("_mnrf_packed")
+    if cache is None:
+        cache = PackedCache()
+        module.__dict__["_mnrf_packed"] = cache
+    return cache.get(module)

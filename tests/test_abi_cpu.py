@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mnrf.h declares,
+and validates arguments before touching the GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mnrf.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from mirror_nerf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(L):
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(mnrf_[a-z_]+)\s*\(", text))
+    from mirror_nerf_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(L, name), f"libmnrf_hip.so lacks {name}"
+
+
+def test_packed_size_matches_layout(L):
+    # forward tiles 2616 + bias block 3072 floats + backward tiles 1920 (mnrf_layout.h)
+    assert L.mnrf_packed_floats() == 2616 * 256 + 3072 + 1920 * 256
+    assert L.mnrf_version() >= 1
+
+
+def test_argument_validation_without_gpu(L):
+    null = None
+    assert L.mnrf_field_forward(null, 0, 128, null, 3, null, null, 1, null, 27, null, null, null, null, null,
+                                null, null) < 0
+    assert b"packed" in L.mnrf_last_error()
+    assert L.mnrf_sample_fine(null, null, 4, 2, null, 0, 16, null, null) < 0      # S < 3
+    assert L.mnrf_sample_fine(null, null, 4, 300, null, 0, 16, null, null) < 0    # S > 256
+    assert L.mnrf_composite(null, 4, 64, null, null, null, null, null, null, null, 0, null, null, null, null,
+                            null, null, null, null, null, null) < 0
+    assert L.mnrf_embed(null, -1, 3, 4, null, null) < 0
+    # zero-sized work is a no-op, not an error
+    assert L.mnrf_embed(null, 0, 3, 4, null, null) == 0
+    assert L.mnrf_threshold_mask(null, 0, null, null) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mirror_nerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    import mirror_nerf_amd as M
+    with pytest.raises(RuntimeError):
+        M.render_rays({}, {"xyz": M.Embedding(10), "dir": M.Embedding(4)}, torch.zeros(4, 8))
+
+
+def test_module_mirrors_reference_names():
+    import torch
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd.weights import PARAM_NAMES, PARAM_SHAPES
+    from tests.golden import weights as GW
+    torch.manual_seed(0)
+    m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+    sd = m.state_dict()
+    assert list(sd) == PARAM_NAMES
+    ref = GW.make_state_dict(0, 1)[0]
+    for k, v in sd.items():
+        assert tuple(v.shape) == PARAM_SHAPES[k]
+        assert (v.numpy() == ref[k]).all(), k     # same construction order => same init under a seed
+    with pytest.raises(NotImplementedError):
+        M.MirrorNeRF(W=128, predict_normal=True, predict_mirror_mask=True)

@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the committed golden vectors
+captured from the reference, and against the oracle on seeded inputs.
+
+Tolerances (stated once, used everywhere below):
+  * composited per-ray outputs rgb / opacity / mirror mask / predicted surface normal: 1e-4 abs
+    (BASELINE.json north_star); depth, x_surface: 1e-4 relative to far = 8;
+  * keys derived from the normalised autograd density gradient: floor-aware, see
+    tests/golden/fixtures.py (the reference's own fp32-vs-fp64 difference on them is up to 1e-2);
+  * per-sample tensors at the fine sample positions are compared only through
+    order-insensitive reductions (positions are not stable at 1e-4).
+In practice the HIP path agrees with the reference to ~1e-6 on the well-conditioned keys.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mirror_nerf_oracle as O
+from tests.golden import fixtures as FX
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EMB_O = {"xyz": 10, "dir": 4}
+
+
+def _M():
+    import mirror_nerf_amd as M
+    return M
+
+
+def _module(sd):
+    M = _M()
+    m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(DEV)
+
+
+def _emb():
+    M = _M()
+    return {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
+
+
+def _np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def _cmp(name, got, want_dict, meta, skip=(), base=1e-4):
+    for k, want in want_dict.items():
+        if k in skip:
+            continue
+        assert k in got, f"{name}: missing key {k}"
+        g = got[k]
+        assert g.shape == want.shape, (name, k, g.shape, want.shape)
+        tol = FX.tolerance(k, meta, base)
+        err = float(np.max(np.abs(g.astype(np.float64) - want))) if want.size else 0.0
+        assert err <= tol, f"{name}:{k} max-abs {err:.3e} > {tol:.1e}"
+    extra = set(got) - set(want_dict) - set(skip)
+    assert not extra or all(k.startswith(("pred_normal_", "normal_")) for k in extra), extra
+
+
+# --------------------------------------------------------------------------- a1
+def test_embedding_golden():
+    fx = FX.Fixture("g1_embedding")
+    M = _M()
+    x = torch.from_numpy(fx.inputs["x"]).to(DEV)
+    d = torch.from_numpy(fx.inputs["d"]).to(DEV)
+    assert np.max(np.abs(M.Embedding(10)(x).cpu().numpy() - fx.outputs["e10"])) <= 2e-6
+    assert np.max(np.abs(M.Embedding(4)(d).cpu().numpy() - fx.outputs["e4"])) <= 2e-6
+    assert np.array_equal(M.Embedding(0)(x).cpu().numpy(), fx.outputs["e0"])
+    assert M.Embedding(4)(x[:0]).shape == (0, 27)
+
+
+# --------------------------------------------------------------------------- a2-a5
+def test_field_golden():
+    fx = FX.Fixture("g2_field")
+    m = _module(fx.state_dicts()[0])
+    e = _emb()
+    x30 = torch.from_numpy(fx.inputs["x30"]).to(DEV)
+    full = _np(m(x30, compute_normal=True, sigma_only=False, embedding_xyz=e["xyz"], embedding_dir=e["dir"]))
+    sonly = _np(m(x30[:, :3].contiguous(), compute_normal=False, sigma_only=True, embedding_xyz=e["xyz"],
+                  embedding_dir=e["dir"]))
+    assert full["sigma"].shape == (512, 1) and full["is_mirror"].shape == (512, 1)
+    for k, want in fx.outputs.items():
+        mode, key = k.split("__")
+        got = (full if mode == "full" else sonly)[key]
+        if key == "geo_feat":
+            got = got[:, :8]
+        err = float(np.max(np.abs(got - want)))
+        assert err <= 2e-5, f"{k}: {err:.3e}"
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 127, 128, 129, 1000])
+def test_field_ragged_sizes_vs_oracle(B):
+    """Tile edges: the kernel works on 128-sample tiles of 4 waves x 2 x 16."""
+    from tests.golden import weights as GW
+    sd = GW.apply_tweaks(GW.make_state_dict(3, 1)[0], GW.OPAQUE)
+    m = _module(sd)
+    e = _emb()
+    rs = np.random.RandomState(B)
+    xyz = rs.uniform(-4, 4, (B, 3)).astype(np.float32)
+    d = rs.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x30 = np.concatenate([xyz, O.embedding(d, 4)], 1)
+    want = O.field_forward(sd, x30, False, True)
+    got = _np(m(torch.from_numpy(x30).to(DEV), compute_normal=True, embedding_xyz=e["xyz"], embedding_dir=e["dir"]))
+    for k in ("sigma", "rgb", "pred_normal", "is_mirror", "geo_feat"):
+        err = float(np.max(np.abs(got[k] - want[k])))
+        assert err <= 3e-5, (k, err)
+    # normal: compare where the gradient is well conditioned
+    dn = np.abs(got["normal"] - want["normal"]).max(-1)
+    assert np.median(dn) <= 1e-4
+
+
+def test_field_empty():
+    from tests.golden import weights as GW
+    m = _module(GW.make_state_dict(3, 1)[0])
+    e = _emb()
+    out = m(torch.zeros(0, 30, device=DEV), compute_normal=False, embedding_xyz=e["xyz"], embedding_dir=e["dir"])
+    assert out["sigma"].shape == (0, 1) and out["rgb"].shape == (0, 3)
+
+
+# --------------------------------------------------------------------------- a6-a11
+def _render_fixture(name):
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0])}
+    if m["N_importance"] > 0 and not m["kwargs"].get("only_one_field", False):
+        models["fine"] = _module(sds[1])
+    kw = dict(m["kwargs"])
+    for k in ("perturb_rand", "noise_coarse", "noise_fine", "u"):
+        if k in fx.inputs:
+            kw["_" + k] = torch.from_numpy(fx.inputs[k]).to(DEV)
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    got = _np(_M().render_rays(models, _emb(), rays, m["N_samples"], m["use_disp"], m["perturb"], m["noise_std"],
+                               m["N_importance"], m["chunk"], m["white_back"], m["test_time"], **kw))
+    return fx, got
+
+
+@pytest.mark.parametrize("name", FX.names("g3_") + FX.names("g4_") + FX.names("g5_"))
+def test_render_rays_golden(name):
+    fx, got = _render_fixture(name)
+    skip = list(FX.PER_SAMPLE_FINE)
+    if fx.meta["kwargs"].get("only_one_field") and fx.meta["kwargs"].get("current_epoch", 0) > 2:
+        skip += ["z_vals_coarse", "weights_coarse", "pred_normal_coarse", "normal_coarse"]
+    skip += ["normal_coarse", "normal_fine"]          # per-sample normalised gradients (noise-dominated)
+    _cmp(name, got, fx.outputs, fx.meta, skip=skip)
+    for typ in ("coarse", "fine"):
+        if f"weights_{typ}" in got and f"opacity_{typ}" in got:
+            assert np.max(np.abs(got[f"weights_{typ}"].sum(1) - got[f"opacity_{typ}"])) <= 1e-5
+            assert np.all(np.diff(got[f"z_vals_{typ}"], axis=1) >= 0)
+    if "weights_fine" in fx.outputs and name != "g4_fine_rawinit":
+        assert np.max(np.abs(got["weights_fine"].sum(1) - fx.outputs["weights_fine"].sum(1))) <= 1e-4
+        # the multiset of fine depths moves by at most a few 1e-4 (bin flips), never wholesale
+        assert np.max(np.abs(got["z_vals_fine"] - fx.outputs["z_vals_fine"])) <= 5e-3
+
+
+def test_render_rays_empty_and_single():
+    from tests.golden import weights as GW
+    sds = GW.make_state_dict(0, 2)
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    M = _M()
+    r0 = M.render_rays(models, _emb(), torch.zeros(0, 8, device=DEV), 64, False, 0, 0, 128, test_time=True,
+                       compute_normal=False)
+    assert r0["rgb_fine"].shape == (0, 3) and r0["weights_coarse"].shape == (0, 64)
+    rays = torch.from_numpy(O.synthetic_rays(4, 4)[5:6]).to(DEV)
+    r1 = _np(M.render_rays(models, _emb(), rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False))
+    want = O.render_rays({"coarse": sds[0], "fine": sds[1]}, EMB_O, rays.cpu().numpy(), 64, False, 0, 0, 128,
+                         test_time=True, compute_normal=False)
+    assert np.max(np.abs(r1["rgb_fine"] - want["rgb_fine"])) <= 1e-4
+
+
+# --------------------------------------------------------------------------- kernels one by one
+def test_sample_fine_matches_oracle_exactly_given_same_weights():
+    """With identical coarse weights the inverse-CDF + sort kernel reproduces the oracle's depths
+    (double-accumulated cdf as ATen does) to 1 ulp-level differences."""
+    rs = np.random.RandomState(11)
+    N, S, NI = 300, 64, 128
+    z = np.sort(rs.uniform(0.05, 8, (N, S)).astype(np.float32), 1)
+    w = (rs.uniform(0, 1, (N, S)) ** 8).astype(np.float32)
+    w[5] = 0          # empty ray: cdf from eps only
+    w[6, 10] = 1.0    # one dominant bin
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    want = np.sort(np.concatenate([z, O.sample_pdf(mid, w[:, 1:-1], NI, det=True)], -1), -1)
+    got = _M().sample_pdf(torch.from_numpy(z).to(DEV), torch.from_numpy(w).to(DEV), NI, det=True).cpu().numpy()
+    assert got.shape == (N, S + NI)
+    assert np.max(np.abs(got - want)) <= 2e-5
+    u = rs.uniform(0, 1, (N, NI)).astype(np.float32)
+    want = np.sort(np.concatenate([z, O.sample_pdf(mid, w[:, 1:-1], NI, det=False, u=u)], -1), -1)
+    got = _M().sample_pdf(torch.from_numpy(z).to(DEV), torch.from_numpy(w).to(DEV), NI, det=False,
+                          u=torch.from_numpy(u).to(DEV)).cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 2e-5
+
+
+def test_reflect_compact_and_blend():
+    from mirror_nerf_amd import recursion as R
+    rs = np.random.RandomState(5)
+    N = 2500   # > 2 passes of the 1024-thread compaction loop, ragged tail
+    rays = rs.normal(size=(N, 8)).astype(np.float32)
+    xs = rs.normal(size=(N, 3)).astype(np.float32)
+    nrm = rs.normal(size=(N, 3)).astype(np.float32)
+    nrm[7] = 0  # degenerate normal: eps clamp
+    mask = (rs.uniform(size=N) < 0.3).astype(np.float32)
+    mask[11] = 0.5
+    t = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+    sec, index, rdir = R._reflect(t(rays), t(xs), t(nrm), t(mask), True)
+    want_dir, _, _ = O.reflect(rays[:, 3:6], nrm)
+    sel = mask != 0
+    assert index.cpu().numpy().tolist() == np.nonzero(sel)[0].tolist()
+    assert np.max(np.abs(rdir.cpu().numpy() - want_dir)) <= 1e-5
+    s = sec.cpu().numpy()
+    assert np.array_equal(s[:, 0:3], xs[sel]) and np.all(s[:, 6] == np.float32(0.1))
+    assert np.array_equal(s[:, 7], rays[sel, 7])
+    assert np.max(np.abs(s[:, 3:6] - want_dir[sel])) <= 1e-5
+    sec_all, idx_none, _ = R._reflect(t(rays), t(xs), t(nrm), t(mask), False)
+    assert idx_none is None and sec_all.shape == (N, 8)
+    # blend / scatter
+    base = rs.uniform(size=(N, 3)).astype(np.float32)
+    secrgb = rs.uniform(size=(int(sel.sum()), 3)).astype(np.float32)
+    out, refl = R._blend(t(base), t(secrgb), index, t(mask), True)
+    part = base.copy()
+    part[sel] = secrgb
+    want = mask[:, None] * part + (1 - mask[:, None]) * base
+    assert np.max(np.abs(out.cpu().numpy() - want)) <= 1e-6
+    rr = np.zeros_like(base)
+    rr[sel] = secrgb
+    assert np.array_equal(refl.cpu().numpy(), rr)
+    # nothing selected
+    sec0, idx0, _ = R._reflect(t(rays), t(xs), t(nrm), t(np.zeros(N, np.float32)), True)
+    assert sec0.shape[0] == 0 and idx0.shape[0] == 0
+
+
+def test_threshold_mask_leaves_half_untouched():
+    from mirror_nerf_amd import recursion as R
+    m = torch.tensor([0.2, 0.5, 0.7, 0.4999, 0.5001], device=DEV)
+    assert R._threshold_(m) is True
+    assert m.cpu().tolist() == [0.0, 0.5, 1.0, 0.0, 1.0]
+    z = torch.tensor([0.1, 0.3], device=DEV)
+    assert R._threshold_(z) is False
+
+
+# --------------------------------------------------------------------------- a12
+@pytest.mark.parametrize("name", FX.names("g6_"))
+def test_recursion_train_golden(name):
+    from types import SimpleNamespace
+    fx = FX.Fixture(name)
+    sds = fx.state_dicts()
+    hp = dict(fx.meta["hp"])
+    hp.update(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf")
+    system = _M().NeRFSystem(SimpleNamespace(**hp))
+    system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
+    system.nerf_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
+    system.to(DEV)
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    extra = {"mirror_mask": torch.from_numpy(fx.inputs["gt_mask"].copy()).to(DEV), "is_eval": fx.meta["is_eval"],
+             "train_geometry_stage": False}
+    got = _np(system(rays, extra))
+    _cmp(name, got, fx.outputs, fx.meta, skip=FX.PER_SAMPLE_FINE)
+
+
+# --------------------------------------------------------------------------- a13 / a14
+@pytest.mark.parametrize("name", FX.names("g7_") + FX.names("g8_"))
+def test_recursion_eval_golden(name):
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    n_noise = len([k for k in fx.inputs if k.startswith("normal_noise_")])
+    noise = iter([torch.from_numpy(fx.inputs[f"normal_noise_{i}"]) for i in range(n_noise)])
+    got = _np(_M().batched_inference(models, _emb(), torch.from_numpy(fx.inputs["rays"]).to(DEV), m["N_samples"],
+                                     m["N_importance"], False, m["chunk"], args=m["args"],
+                                     trace_secondary_rays=True, normal_noise_std=m["args"]["normal_noise_std"],
+                                     _normal_noise=noise))
+    _cmp(name, got, fx.outputs, m, skip=FX.PER_SAMPLE_FINE)
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_size_chunk_properties():
+    """One 32768-ray chunk of the 800x800 configuration (64 coarse + 128 fine): size-independent
+    invariants, plus agreement with the oracle on a strided subset of the same rays."""
+    from tests.golden import weights as GW
+    sds = [GW.apply_tweaks(sd, GW.OPAQUE) for sd in GW.make_state_dict(0, 2)]
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays_np = O.synthetic_rays(800, 800)[300 * 800: 300 * 800 + 32768]
+    rays = torch.from_numpy(rays_np).to(DEV)
+    r = _M().render_rays(models, _emb(), rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+    w, op, z = r["weights_fine"], r["opacity_fine"], r["z_vals_fine"]
+    assert w.shape == (32768, 192)
+    assert torch.isfinite(r["rgb_fine"]).all() and torch.isfinite(r["depth_fine"]).all()
+    assert float((w.sum(1) - op).abs().max()) <= 1e-5
+    assert float(op.max()) <= 1 + 1e-5 and float(w.min()) >= 0
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    assert float(r["rgb_fine"].min()) >= 0 and float(r["rgb_fine"].max()) <= 1 + 1e-5
+    # rendering is per-ray: a strided subset rendered alone gives the same numbers (chunk independence)
+    sub = rays[::997].contiguous()
+    r2 = _M().render_rays(models, _emb(), sub, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+    assert float((r2["rgb_fine"] - r["rgb_fine"][::997]).abs().max()) <= 1e-6
+    want = O.render_rays({"coarse": sds[0], "fine": sds[1]}, EMB_O, rays_np[::997], 64, False, 0, 0, 128,
+                         test_time=True, compute_normal=False)
+    got = _np(r2)
+    for k in ("rgb_fine", "opacity_fine", "mirror_mask_fine", "surface_normal_fine"):
+        assert np.max(np.abs(got[k] - want[k])) <= 1e-4, k
+    assert np.max(np.abs(got["depth_fine"] - want["depth_fine"])) <= 8e-4
