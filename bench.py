@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the rendering hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): novel-view rendering of the synthetic 800x800 Blender-style
+camera with the reference's eval procedure -- eval.batched_inference (eval.py:114-740): 64 coarse
+(sigma-only) + 192 fine samples per ray, chunk 32768, one reflection bounce.  Weights are the
+random-init 8x256 MirrorNeRF pair (torch.manual_seed(0)) with the density made opaque and the
+mirror head biased to 1, so that -- as eval.py does whenever a chunk contains mirror pixels --
+every primary ray spawns one reflected ray: 640 000 primary + 640 000 reflected rays per frame.
+A "step" is one frame.  Inputs (rays, packed weights) are resident in HBM when timing starts; the
+result maps stay on the GPU (`to_cpu=False`; the reference's per-chunk D2H of every dict entry
+is caller-side data movement).
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): frames are independent units; every
+rank renders its own frame (weak scaling), no collective on the data path, barrier + max-over-ranks
+timing.  value = rays of all ranks / slowest rank's time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+N_SAMPLES, N_IMPORTANCE, CHUNK = 64, 128, 32768
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def build_models(dev):
+    import torch
+    import mirror_nerf_amd as M
+    from tests.golden import weights as GW
+    sds = [GW.apply_tweaks(sd, GW.ALL_MIRROR) for sd in GW.make_state_dict(0, 2)]
+    models = {}
+    for name, sd in zip(("coarse", "fine"), sds):
+        m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        models[name] = m.to(dev)
+    return models, sds, {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
+
+
+ARGS = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
+
+
+def cpu_baseline(sds, n_rays=1024):
+    """The oracle (numpy port of the reference path, OpenBLAS threads = host cores) on a bounded
+    sample of the same workload: `n_rays` primary rays of the frame + their reflected rays."""
+    from oracle import mirror_nerf_oracle as O
+    rays = O.synthetic_rays(H, W)
+    idx = np.linspace(0, rays.shape[0] - 1, n_rays).astype(np.int64)
+    sub = rays[idx]
+    O.render_eval({"coarse": sds[0], "fine": sds[1]}, {"xyz": 10, "dir": 4}, sub[:64], N_SAMPLES, N_IMPORTANCE,
+                  False, CHUNK, ARGS)  # warm-up
+    t0 = time.perf_counter()
+    r = O.render_eval({"coarse": sds[0], "fine": sds[1]}, {"xyz": 10, "dir": 4}, sub, N_SAMPLES, N_IMPORTANCE,
+                      False, CHUNK, ARGS)
+    dt = time.perf_counter() - t0
+    traced = int((r["mirror_mask_fine"] != 0).any()) * n_rays
+    return {"value": (n_rays + traced) / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_rays} primary + {traced} reflected rays of the same frame, numpy/OpenBLAS oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from oracle import mirror_nerf_oracle as O
+
+    models, sds, emb = build_models(dev)
+    # every rank renders its own view: same camera model, pose rotated about z by the rank index
+    pose = O.look_at_pose(eye=(4.0 * np.sin(0.3 * rank), -4.0 * np.cos(0.3 * rank), 1.5))
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
+    rays = torch.empty(H * W, 8, device=dev)
+    import ctypes
+    c2w = (ctypes.c_float * 12)(*pose.reshape(-1).tolist())
+    M._lib.check(M._lib.lib().mnrf_generate_rays(H, W, float(focal), c2w, 0.05, 8.0, M._lib.ptr(rays),
+                                                 M._lib.stream()), "mnrf_generate_rays")
+
+    def frame():
+        return M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,
+                                   trace_secondary_rays=True, to_cpu=False)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = frame()
+    sync()
+    MN.LAUNCH_LOG = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = frame()
+    sync()
+    dt = time.perf_counter() - t0
+    log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_mirror = int((out["mirror_mask_fine"] != 0).sum().item())
+    rays_per_frame = H * W + (H * W if n_mirror > 0 else 0)      # eval.py:159: level 0 traces every ray
+    evals_per_ray = N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)
+    total_rays = rays_per_frame * a.steps * world
+    value = total_rays / dt
+
+    # dominant kernel: the full (4-head) field kernel of the fine pass
+    full = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in log if not (flags & 1)]
+    sig = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in log if (flags & 1)]
+    ms_full = sum(t for _, t in full)
+    flop_full = sum(B for B, _ in full) * MN.FLOP_FULL
+    achieved = flop_full / (ms_full * 1e-3) / 1e12 if ms_full > 0 else 0.0
+    ms_sig = sum(t for _, t in sig)
+    sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
+
+    if rank == 0:
+        res = {
+            "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
+                                   "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
+                                   "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
+                       "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames"},
+            "samples_per_s": value * evals_per_ray,
+            "field_evals_per_ray": evals_per_ray,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "mnrf::field_kernel<false,false> (full 4-head evaluation, fine pass)",
+                         "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
+                         "flop_per_sample": MN.FLOP_FULL,
+                         "sigma_only_kernel_tflops": sig_tf,
+                         "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sds, a.cpu_rays)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,16 @@ class Embedding(nn.Module):
         return out
 
 
+# When a list is installed here, every field-kernel launch is bracketed by two events on the
+# launching stream and (flags, B, start, end) is appended -- bench.py reads kernel time from it.
+LAUNCH_LOG = None
+
+# algorithmic work per sample (SURVEY 8d / BASELINE.md section 3), FLOP = 2*MAC
+FLOP_FULL = 1318912
+FLOP_SIGMA = 982528
+FLOP_GRAD = 982528      # density-gradient pass: the trunk GEMMs once more, transposed
+
+
 def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, spr=1, dir_emb=None,
                   dir_stride=27, sigma_only=False, grad_normal=False, want_geo=False, device=None):
     """Run the fused field kernel; returns flat per-sample tensors (sigma (B,), rgb (B,3), ...)."""
@@ -53,10 +63,16 @@ def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, 
         out["geo_feat"] = f(B, 256)
     flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
     p = _lib.ptr
+    if LAUNCH_LOG is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().mnrf_field_forward(
         p(packed), flags, B, p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dir_emb), dir_stride,
         p(out["sigma"]), p(out.get("rgb")), p(out.get("pred_normal")), p(out.get("is_mirror")),
         p(out.get("normal")), p(out.get("geo_feat")), _lib.stream()), "mnrf_field_forward")
+    if LAUNCH_LOG is not None:
+        e1.record()
+        LAUNCH_LOG.append((flags, B, e0, e1))
     return out
 
 
