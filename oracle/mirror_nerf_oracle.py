@@ -70,8 +70,21 @@ def _sigmoid(x):
     return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
 
 
+_SGEMM = None  # optional replacement for the fp32 GEMM  (x, w) -> x @ w.T, see set_sgemm
+
+
+def set_sgemm(fn):
+    """Swap the fp32 matrix product used by every Linear (default: numpy/OpenBLAS).
+    bench.py's cpu_baseline leg installs torch's CPU sgemm here -- the library the reference's
+    CPU path itself runs on -- so that the baseline is not limited by numpy's BLAS build."""
+    global _SGEMM
+    _SGEMM = fn
+
+
 def _linear(x, w, b):
     """nn.Linear: y = x W^T + b with W stored (out, in)."""
+    if _SGEMM is not None:
+        return (_SGEMM(x, w) + b).astype(F32, copy=False)
     return (x @ w.T + b).astype(F32)
 
 

@@ -179,7 +179,8 @@ def test_sample_fine_vs_oracle_given_same_weights():
     rs = np.random.RandomState(11)
     N, S, NI = 300, 64, 128
     z = np.sort(rs.uniform(0.05, 8, (N, S)).astype(np.float32), 1)
-    w = (rs.uniform(0.05, 1, (N, S)) ** 2).astype(np.float32)     # well-conditioned bins
+    # well-conditioned bins: pdf >= 0.01, so a 1-ulp change of the cdf moves a sample by < 2e-6
+    w = rs.uniform(0.5, 1, (N, S)).astype(np.float32)
     w[5] = 0          # empty ray: cdf from eps only
     mid = 0.5 * (z[:, :-1] + z[:, 1:])
     t = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
@@ -188,7 +189,7 @@ def test_sample_fine_vs_oracle_given_same_weights():
     want = np.sort(np.concatenate([z, O.sample_pdf(mid, w[:, 1:-1], NI, det=False, u=u)], -1), -1)
     got = _M().sample_pdf(t(z), t(w), NI, det=False, u=t(u)).cpu().numpy()
     assert got.shape == (N, S + NI)
-    assert np.max(np.abs(got - want)) <= 2e-5
+    assert np.max(np.abs(got - want)) <= 1e-5
     # deterministic u = linspace(0,1): every sample but (possibly) the u = 1.0 one agrees
     want = np.sort(np.concatenate([z, O.sample_pdf(mid, w[:, 1:-1], NI, det=True)], -1), -1)
     got = _M().sample_pdf(t(z), t(w), NI, det=True).cpu().numpy()
