@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 H = W = 800
 N_SAMPLES, N_IMPORTANCE, CHUNK = 64, 128, 32768
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+# HBM bytes per full-kernel sample from the PMC passes in profiles/r01_pmc (FETCH_SIZE doubled per the
+# guide's gfx950 correction + WRITE_SIZE): (2 x 33758 + 196608) KiB / 6291456 samples
+PMC_HBM_BYTES_PER_FULL_SAMPLE = (2 * 33758 + 196608) * 1024 / 6291456
 
 
 def build_models(dev):
@@ -172,7 +175,10 @@ def main():
             "samples_per_s": value * evals_per_ray,
             "field_evals_per_ray": evals_per_ray,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": PMC_HBM_BYTES_PER_FULL_SAMPLE * (sum(B for B, _ in full) / max(1, len(full))),
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/r01_pmc), "
+                                         "not re-measured in this run; algorithmic bytes are 36 B/sample",
                          "kernel": "mnrf::field_kernel<false,false> (full 4-head evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
                          "flop_per_sample": MN.FLOP_FULL,

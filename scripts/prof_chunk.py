@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One 32768-ray chunk of the bench workload (64 sigma-only coarse + 192 full fine samples per ray),
+rendered `--reps` times: the unit that rocprofv3 --pmc passes and tuning experiments are run on.
+Prints the HIP-event time of each field launch."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import mirror_nerf_amd as M  # noqa: E402
+from mirror_nerf_amd import mirror_nerf as MN  # noqa: E402
+from oracle import mirror_nerf_oracle as O  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--rays", type=int, default=32768)
+ap.add_argument("--train", action="store_true", help="train-mode forward: full coarse pass + density-gradient normals")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+models, sds, emb = bench.build_models(dev)
+rays = torch.from_numpy(O.synthetic_rays(800, 800)[300 * 800: 300 * 800 + a.rays]).to(dev)
+MN.LAUNCH_LOG = []
+for _ in range(a.reps + 1):
+    if a.train:
+        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=False, compute_normal=True)
+    else:
+        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+torch.cuda.synchronize()
+for flags, B, e0, e1 in MN.LAUNCH_LOG[2:]:
+    ms = e0.elapsed_time(e1)
+    flop = B * (MN.FLOP_SIGMA if flags & 1 else MN.FLOP_FULL) + (B * MN.FLOP_GRAD if flags & 2 else 0)
+    print(f"flags={flags} B={B} {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s (algorithmic)")
