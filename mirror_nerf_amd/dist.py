@@ -1,0 +1,93 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in CPU tests).
+
+Rendering shards naturally -- rays are independent units -- so the data path has NO collective:
+each rank renders an interleaved set of ray tiles (mirror pixels cluster spatially; interleaving
+balances the reflected-ray load) and owns the matching slice of every output map.  Collectives
+appear only (a) optionally, to assemble a frame on rank 0, and (b) in training, as ONE all-reduce
+of the flat gradient buffer (1 324 304 fp32 = 5.3 MB for the coarse+fine pair; the reference
+gets the same from Lightning DDP, train.py:577-584).
+"""
+import torch
+import torch.distributed as dist
+
+TILE = 4096
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n_rays, rank, world_size, tile=TILE, device="cpu"):
+    """Ray indices of `rank`: tiles of `tile` consecutive rays dealt round-robin to the ranks."""
+    idx = torch.arange(n_rays, device=device)
+    return idx[(idx // tile) % world_size == rank]
+
+
+def render_sharded(render_fn, rays, tile=TILE):
+    """Render this rank's tiles.  render_fn(rays_subset) -> dict of per-ray tensors.
+    Returns (indices, results) -- results cover rays[indices] only; no communication."""
+    rank, ws = world()
+    idx = shard_indices(rays.shape[0], rank, ws, tile, rays.device)
+    return idx, render_fn(rays[idx].contiguous())
+
+
+def gather_frame(idx, results, n_rays, keys=None, dst=0):
+    """Optional assembly of full per-ray maps on rank `dst` (20 B/ray for rgb+depth+mask at most)."""
+    rank, ws = world()
+    keys = list(results) if keys is None else keys
+    if ws == 1:
+        return {k: results[k] for k in keys}
+    out = {}
+    counts = [int(shard_indices(n_rays, r, ws, TILE).numel()) for r in range(ws)]
+    idx_parts = [torch.empty(c, dtype=idx.dtype, device=idx.device) for c in counts]
+    dist.all_gather(idx_parts, idx) if len(set(counts)) == 1 else _all_gather_ragged(idx_parts, idx, counts)
+    for k in keys:
+        v = results[k]
+        parts = [torch.empty((c,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for c in counts]
+        dist.all_gather(parts, v.contiguous()) if len(set(counts)) == 1 else _all_gather_ragged(parts, v.contiguous(), counts)
+        if rank == dst:
+            full = torch.empty((n_rays,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            for ip, p in zip(idx_parts, parts):
+                full[ip] = p
+            out[k] = full
+    return out
+
+
+def _all_gather_ragged(parts, mine, counts):
+    """all_gather for unequal shard sizes: broadcast each rank's piece in turn."""
+    rank, ws = world()
+    for r in range(ws):
+        if r == rank:
+            parts[r].copy_(mine)
+        dist.broadcast(parts[r], src=r)
+
+
+def max_over_ranks(seconds, device):
+    """The slowest rank's time (bench.py contract)."""
+    rank, ws = world()
+    if ws == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_gradients(params, average=True):
+    """One all-reduce of all gradients as a single flat buffer (direct reduce-scatter+all-gather
+    inside RCCL uses all 7 xGMI links; a 5.3 MB message is latency-, not bandwidth-bound)."""
+    rank, ws = world()
+    grads = [p.grad for p in params if p.grad is not None]
+    if ws == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= ws
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
