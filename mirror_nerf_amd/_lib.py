@@ -12,7 +12,7 @@ import subprocess
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmnrf_hip.so")
+LIB_PATH = os.environ.get("MNRF_LIB", os.path.join(_HERE, "libmnrf_hip.so"))   # MNRF_LIB: tuning experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 _c_f = ctypes.c_void_p      # device float*

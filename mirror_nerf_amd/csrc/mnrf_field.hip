@@ -75,7 +75,7 @@ __host__ __device__ inline void build_parts(PartTable& T) {
     int n = 0, tile = 0;
     auto add = [&](Part* arr, int& cnt, int param, int n_true, int ld, int ntq, int nb, int col_off, int kind) {
         arr[cnt] = Part{param, n_true, ld, ntq, nb, col_off, kind, tile};
-        tile += ntq * nb;
+        tile += padded_tiles(ntq * nb);
         cnt++;
     };
     add(T.fwd, n, 0, 256, 63, 4, 16, 0, KIND_ENC);                             // L1
@@ -115,7 +115,7 @@ __global__ void pack_kernel(PackArgs P, PartTable T) {
         while (k + 1 < N_FWD_PARTS && T.fwd[k + 1].tile0 <= tile) ++k;
         const Part pt = T.fwd[k];
         const int lt = tile - pt.tile0;
-        const int tq = lt / pt.nb, nb = lt % pt.nb;
+        const int tq = lt / pt.nb, nb = lt % pt.nb;   // tq >= ntq: chunk padding behind a short part
         const int n = 16 * nb + i;
         const int t = 4 * tq + j;
         int col;
@@ -124,7 +124,7 @@ __global__ void pack_kernel(PackArgs P, PartTable T) {
             col = 16 * (t >> 2) + 4 * g + (t & 3);
             if (pt.kind == KIND_DIR && col >= ENC_DIR) col = -1;
         }
-        if (n < pt.n_true && col >= 0) v = P.params[pt.param][(long long)n * pt.ld + pt.col_off + col];
+        if (tq < pt.ntq && n < pt.n_true && col >= 0) v = P.params[pt.param][(long long)n * pt.ld + pt.col_off + col];
     } else if (p < OFF_BWD) {
         // ---- bias block
         const int b = (int)(p - OFF_BIAS);
@@ -208,10 +208,14 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
     if (grad && !normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward: GRAD_NORMAL needs the normal output");
     FieldArgs A{packed, flags, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, geo_feat};
-    static const int variant = [] {
-        const char* e = getenv("MNRF_FIELD_VARIANT");   // "s1" (default) | "s2"  (tuning experiments)
-        return (e && e[0] == 's' && e[1] == '2') ? 2 : 1;
+    // Tuning: s2 (32 samples/wave, one wave per SIMD) is fastest for the forward-only kernels, s1
+    // (16 samples/wave, two workgroups per CU) for the ones with the density-gradient pass.
+    // MNRF_FIELD_VARIANT=s1|s2 forces one (experiments).
+    static const int forced = [] {
+        const char* e = getenv("MNRF_FIELD_VARIANT");
+        return (e && e[0] == 's' && (e[1] == '1' || e[1] == '2')) ? e[1] - '0' : 0;
     }();
+    const int variant = forced ? forced : (grad ? 1 : 2);
     const int rc = variant == 1 ? s1::launch(A, sigma_only, grad, (hipStream_t)stream)
                                 : s2::launch(A, sigma_only, grad, (hipStream_t)stream);
     if (rc != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward: too many samples for one launch");

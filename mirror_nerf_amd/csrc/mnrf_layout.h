@@ -29,7 +29,7 @@ constexpr int NFREQ_DIR = 4;
 
 constexpr int TILE_FLOATS = 256;
 constexpr int TILE_BYTES = 1024;
-constexpr int CHUNK_TILES = 8;   // LDS staging granule: 8 KiB
+constexpr int CHUNK_TILES = 16;  // LDS staging granule: 16 KiB (every part is padded to whole chunks)
 constexpr int CHUNK_BYTES = CHUNK_TILES * TILE_BYTES;
 
 // how the 4*ntq k-steps of a part map to columns of the nn.Linear weight
@@ -61,13 +61,15 @@ struct Part {
     int tile0;      // first tile of the part inside its stream
 };
 
+__host__ __device__ constexpr int padded_tiles(int n) { return (n + CHUNK_TILES - 1) / CHUNK_TILES * CHUNK_TILES; }
+
 // ---- forward stream -------------------------------------------------------------------
 // stage:       L1   L2..L4  L5(enc,h)  L6..L8  SIG | NRM1 NRM2 MIR1 MIR2 FIN  DIR(h,dir)  RGB
 // (the heads that only read geo_feat come first so that geo_feat dies before the colour branch)
 constexpr int N_FWD_PARTS = 18;
 constexpr int N_BWD_PARTS = 9;
 constexpr int FWD_TILES_SIGMA = 64 + 3 * 256 + 320 + 3 * 256 + 16;               // 1936
-constexpr int FWD_TILES = FWD_TILES_SIGMA + 128 + 8 + 128 + 8 + 256 + 144 + 8;   // 2616
+constexpr int FWD_TILES = FWD_TILES_SIGMA + 128 + 16 + 128 + 16 + 256 + 144 + 16;   // 2640 (3-row heads: 8 tiles + 8 pad)
 // ---- backward (density-gradient) stream: A = W_i^T for i = 8..1 ------------------------
 constexpr int BWD_TILES = 3 * 256 + 320 + 3 * 256 + 64;                           // 1920
 
