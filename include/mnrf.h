@@ -124,6 +124,24 @@ int mnrf_blend_scatter(const float* base, const float* sec, const int32_t* index
                        const float* mask, int64_t n, int c, float* out, float* reflect_out,
                        void* stream);
 
+/* Backward of mnrf_composite (training).  Inputs: the forward inputs (rays, sigma, z_vals, noise,
+ * rgb, is_mirror, pred_normal, normal), the forward outputs weights (n_rays,S) and depth (n_rays),
+ * and the upstream gradients of every per-ray output (null = zero): g_weights (n_rays,S), g_opacity,
+ * g_rgb_map (.,3), g_depth, g_mirror_mask, g_surf_normal (.,3), g_surf_normal_grad (.,3),
+ * g_normal_dif, g_x_surface (.,3).
+ * Outputs (null = skip): d_sigma (n_rays,S), d_rgb (.,S,3), d_is_mirror (.,S), d_pred_normal (.,S,3),
+ * d_normal (.,S,3), d_rays (n_rays,8) [origin and direction gradients through x_surface = o + d*depth].
+ * Reference: autograd through models/rendering.py:181-264, 362-367. */
+int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                            const float* noise, const float* rgb, const float* is_mirror,
+                            const float* pred_normal, const float* normal, int white_back,
+                            const float* weights, const float* depth,
+                            const float* g_weights, const float* g_opacity, const float* g_rgb_map,
+                            const float* g_depth, const float* g_mirror_mask, const float* g_surf_normal,
+                            const float* g_surf_normal_grad, const float* g_normal_dif, const float* g_x_surface,
+                            float* d_sigma, float* d_rgb, float* d_is_mirror, float* d_pred_normal,
+                            float* d_normal, float* d_rays, void* stream);
+
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
                        float* rays, void* stream);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mnrf_sample_coarse": (_int, [_c_f, _i64, _c_f, _int, _int, _flt, _c_f, _c_f, _str]),
     "mnrf_composite": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
                               _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
+    "mnrf_composite_backward": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_str]),
     "mnrf_sample_fine": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _str]),
     "mnrf_threshold_mask": (_int, [_c_f, _i64, _c_i, _str]),
     "mnrf_reflect_compact": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i,

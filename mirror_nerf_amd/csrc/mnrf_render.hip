@@ -176,6 +176,117 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs A) {
     }
 }
 
+
+// ------------------------------------------------------------------ compositing backward
+// w_i = alpha_i T_i, T_i = prod_{j<i} t_j, t_j = 1 - alpha_j + 1e-10.  With G_i = dL/dw_i (direct +
+// through every composited output):  dL/dalpha_i = G_i T_i - (sum_{k>i} G_k w_k) / t_i, and
+// dalpha/dsigma = delta (1 - alpha) [sigma + noise > 0].  One wavefront per ray: T by the forward
+// prefix product of the forward kernel, the suffix sum by a reverse scan over the lanes; both are
+// carried across 64-sample blocks (S <= 256).
+struct CompBwdArgs {
+    const float* rays; long long n_rays; int S;
+    const float* sigma; const float* z; const float* noise; const float* rgb; const float* is_mirror;
+    const float* pred_normal; const float* normal; int white_back;
+    const float* depth;
+    const float* g_w; const float* g_op; const float* g_rgb; const float* g_depth; const float* g_mask;
+    const float* g_sn; const float* g_sng; const float* g_nd; const float* g_xs;
+    float* d_sigma; float* d_rgb; float* d_mirror; float* d_pn; float* d_n; float* d_rays;
+};
+constexpr int CB_MAXB = 4;
+
+__global__ __launch_bounds__(256) void composite_backward_kernel(CompBwdArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= A.n_rays) return;
+    const int S = A.S;
+    const float* r8 = A.rays ? A.rays + ray * 8 : nullptr;
+    float gop = A.g_op ? A.g_op[ray] : 0.f;
+    float gc[3] = {0.f, 0.f, 0.f}, gsn[3] = {0.f, 0.f, 0.f}, gsg[3] = {0.f, 0.f, 0.f}, gxs[3] = {0.f, 0.f, 0.f};
+    if (A.g_rgb) { for (int k = 0; k < 3; ++k) gc[k] = A.g_rgb[ray * 3 + k]; }
+    if (A.g_sn) { for (int k = 0; k < 3; ++k) gsn[k] = A.g_sn[ray * 3 + k]; }
+    if (A.g_sng) { for (int k = 0; k < 3; ++k) gsg[k] = A.g_sng[ray * 3 + k]; }
+    if (A.g_xs) { for (int k = 0; k < 3; ++k) gxs[k] = A.g_xs[ray * 3 + k]; }
+    float gd = A.g_depth ? A.g_depth[ray] : 0.f;
+    const float gm = A.g_mask ? A.g_mask[ray] : 0.f;
+    const float gnd = A.g_nd ? A.g_nd[ray] : 0.f;
+    if (A.g_xs && r8) gd += gxs[0] * r8[3] + gxs[1] * r8[4] + gxs[2] * r8[5];   // x_surface = o + d * depth
+    if (A.white_back) gop -= gc[0] + gc[1] + gc[2];                            // rgb_map += 1 - opacity
+    if (A.d_rays && lane == 0) {
+        float* o = A.d_rays + ray * 8;
+        const float dep = A.depth ? A.depth[ray] : 0.f;
+        for (int k = 0; k < 3; ++k) { o[k] = gxs[k]; o[3 + k] = gxs[k] * dep; }
+        o[6] = 0.f; o[7] = 0.f;
+    }
+    // forward sweep: alpha, T, w, G per sample (kept in registers: <= 4 blocks per lane)
+    float Tn[CB_MAXB], Gw[CB_MAXB], Gv[CB_MAXB], tv[CB_MAXB], dads[CB_MAXB];
+    float carry = 1.f;
+#pragma unroll
+    for (int blk = 0; blk < CB_MAXB; ++blk) {
+        Tn[blk] = 0.f; Gw[blk] = 0.f; Gv[blk] = 0.f; tv[blk] = 1.f; dads[blk] = 0.f;
+        if (blk * 64 >= S) continue;
+        const int s = blk * 64 + lane;
+        const bool in = s < S;
+        const long long i1 = ray * S + s, i3 = i1 * 3;
+        float alpha = 0.f, G = 0.f, delta = 0.f, sv = 0.f;
+        float pn[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+        if (in) {
+            const float zv = A.z[i1];
+            delta = s + 1 < S ? A.z[i1 + 1] - zv : 1e10f;
+            sv = A.sigma[i1];
+            if (A.noise) sv = sv + A.noise[i1];
+            alpha = 1.f - expf(-delta * fmaxf(sv, 0.f));
+            G = (A.g_w ? A.g_w[i1] : 0.f) + gop + gd * zv;
+            if (A.rgb) G += gc[0] * A.rgb[i3] + gc[1] * A.rgb[i3 + 1] + gc[2] * A.rgb[i3 + 2];
+            if (A.is_mirror) G += gm * A.is_mirror[i1];
+            if (A.pred_normal) { for (int k = 0; k < 3; ++k) { pn[k] = A.pred_normal[i3 + k]; G += gsn[k] * pn[k]; } }
+            if (A.normal) { for (int k = 0; k < 3; ++k) { gn[k] = A.normal[i3 + k]; G += gsg[k] * gn[k]; } }
+            if (A.pred_normal && A.normal) {
+                const float d0 = gn[0] - pn[0], d1 = gn[1] - pn[1], d2 = gn[2] - pn[2];
+                G += gnd * (d0 * d0 + d1 * d1 + d2 * d2);
+            }
+        }
+        const float t = in ? (1.f - alpha) + 1e-10f : 1.f;
+        float incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o);
+            if (lane >= o) incl *= up;
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63);
+        const float w = alpha * T;
+        Tn[blk] = T; Gv[blk] = G; Gw[blk] = in ? G * w : 0.f; tv[blk] = t;
+        dads[blk] = (in && sv > 0.f) ? delta * (1.f - alpha) : 0.f;   // relu'(0) = 0 as in torch
+        if (in) {   // gradients of the per-sample inputs that enter linearly
+            if (A.d_rgb) { for (int k = 0; k < 3; ++k) A.d_rgb[i3 + k] = w * gc[k]; }
+            if (A.d_mirror) A.d_mirror[i1] = w * gm;
+            if (A.d_pn) { for (int k = 0; k < 3; ++k) A.d_pn[i3 + k] = w * (gsn[k] - 2.f * gnd * (gn[k] - pn[k])); }
+            if (A.d_n) { for (int k = 0; k < 3; ++k) A.d_n[i3 + k] = w * (gsg[k] + 2.f * gnd * (gn[k] - pn[k])); }
+        }
+    }
+    // backward sweep: suffix sums of G*w
+    float tail = 0.f;
+#pragma unroll
+    for (int blk = CB_MAXB - 1; blk >= 0; --blk) {
+        if (blk * 64 >= S) continue;
+        float suf = Gw[blk];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float dn = __shfl_down(suf, o);
+            if (lane + o < 64) suf += dn;
+        }
+        const float total = __shfl(suf, 0);
+        float after = __shfl_down(suf, 1);
+        if (lane == 63) after = 0.f;
+        after += tail;
+        tail += total;
+        const int s = blk * 64 + lane;
+        if (s < S && A.d_sigma) A.d_sigma[ray * S + s] = (Gv[blk] * Tn[blk] - after / tv[blk]) * dads[blk];
+    }
+}
+
 // ------------------------------------------------------------------ hierarchical resampling
 // models/rendering.py:7-51 (sample_pdf) + 312-326 (merge and sort).  One wavefront per ray.
 // cdf is accumulated in double and rounded per entry, as ATen's CPU cumsum does.
@@ -429,6 +540,34 @@ extern "C" int mnrf_composite(const float* rays, int64_t n_rays, int S, const fl
                weights, opacity, rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface};
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_composite");
+}
+
+extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                       const float* noise, const float* rgb, const float* is_mirror,
+                                       const float* pred_normal, const float* normal, int white_back,
+                                       const float* weights, const float* depth, const float* g_weights,
+                                       const float* g_opacity, const float* g_rgb_map, const float* g_depth,
+                                       const float* g_mirror_mask, const float* g_surf_normal,
+                                       const float* g_surf_normal_grad, const float* g_normal_dif,
+                                       const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
+                                       float* d_pred_normal, float* d_normal, float* d_rays, void* stream) {
+    (void)weights;   // recomputed in-kernel from sigma and z (cheaper than reading them back)
+    if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: bad size");
+    if (S > 64 * CB_MAXB) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_composite_backward: needs S <= 256");
+    if (n_rays == 0) return MNRF_OK;
+    if (!sigma || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: sigma and z_vals are required");
+    if ((g_rgb_map || d_rgb) && !rgb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: rgb missing");
+    if ((g_mirror_mask || d_is_mirror) && !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: is_mirror missing");
+    if ((g_surf_normal || d_pred_normal) && !pred_normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: pred_normal missing");
+    if ((g_surf_normal_grad || d_normal) && !normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: normal missing");
+    if (g_normal_dif && !(normal && pred_normal)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: normal_dif needs both normals");
+    if ((g_x_surface || d_rays) && !rays) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: rays missing");
+    if (d_rays && !depth) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: d_rays needs the forward depth");
+    CompBwdArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
+                  depth, g_weights, g_opacity, g_rgb_map, g_depth, g_mirror_mask, g_surf_normal, g_surf_normal_grad,
+                  g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays};
+    hipLaunchKernelGGL(composite_backward_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_composite_backward");
 }
 
 extern "C" int mnrf_sample_fine(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,

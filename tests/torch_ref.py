@@ -1,0 +1,56 @@
+"""Plain-torch fp32 restatements of the two floating-point kernels that have a backward pass
+(field MLP, compositing).  TEST INFRASTRUCTURE ONLY: the GPU tests differentiate these with
+torch.autograd to check the hand-written HIP backward kernels; the product never imports this."""
+import torch
+
+
+def l2n(x):
+    eps = torch.tensor(torch.finfo(torch.float32).eps, device=x.device, dtype=x.dtype)
+    return x / torch.sqrt(torch.maximum((x * x).sum(-1, keepdim=True), eps))
+
+
+def embed(x, n):
+    out = [x]
+    for k in range(n):
+        out += [torch.sin((2.0 ** k) * x), torch.cos((2.0 ** k) * x)]
+    return torch.cat(out, -1)
+
+
+def field(w, xyz, dir_emb):
+    """w: dict name -> tensor (reference parameter names); returns sigma (B), rgb, pred_normal, is_mirror (B)."""
+    enc = embed(xyz, 10)
+    h = enc
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([enc, h], -1)
+        h = torch.relu(h @ w[f"xyz_encoding_{i+1}.0.weight"].T + w[f"xyz_encoding_{i+1}.0.bias"])
+    sigma = (h @ w["sigma.weight"].T + w["sigma.bias"])[:, 0]
+    fin = h @ w["xyz_encoding_final.weight"].T + w["xyz_encoding_final.bias"]
+    hd = torch.relu(torch.cat([fin, dir_emb], -1) @ w["dir_encoding.0.weight"].T + w["dir_encoding.0.bias"])
+    rgb = torch.sigmoid(hd @ w["rgb.0.weight"].T + w["rgb.0.bias"])
+    hn = h @ w["normal_net.0.weight"].T + w["normal_net.0.bias"]
+    pn = l2n(hn @ w["normal_net.1.weight"].T + w["normal_net.1.bias"])
+    hm = torch.nn.functional.leaky_relu(h @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
+    m = torch.sigmoid(hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"])[:, 0]
+    return sigma, rgb, pn, m
+
+
+def composite(rays, sigma, z, noise, rgb, is_mirror, pn, nrm, white_back=False):
+    """models/rendering.py:181-264, 362-367 on (N,S) tensors."""
+    deltas = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
+    sv = sigma if noise is None else sigma + noise
+    alphas = 1 - torch.exp(-deltas * torch.relu(sv))
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    w = alphas * torch.cumprod(shifted[:, :-1], -1)
+    op = w.sum(1)
+    out = {"weights": w, "opacity": op}
+    rgb_map = (w[..., None] * rgb).sum(1)
+    if white_back:
+        rgb_map = rgb_map + 1 - op[:, None]
+    depth = (w * z).sum(1)
+    out.update(rgb=rgb_map, depth=depth, mask=(w * is_mirror).sum(1), sn=(w[..., None] * pn).sum(1))
+    if nrm is not None:
+        out["sng"] = (w[..., None] * nrm).sum(1)
+        out["nd"] = (w * ((nrm - pn) ** 2).sum(-1)).sum(1)
+    out["xs"] = rays[:, :3] + rays[:, 3:6] * depth[:, None]
+    return out
