@@ -142,6 +142,35 @@ int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const floa
                             float* d_sigma, float* d_rgb, float* d_is_mirror, float* d_pred_normal,
                             float* d_normal, float* d_rays, void* stream);
 
+/* ---- training (forward with saved activations, backward) -----------------------------------
+ * Buffer sizes for B samples: activations (floats), ReLU bit masks (uint64 words), workspace of
+ * the backward (floats: pre-activation gradients + split-K partials of the weight gradients). */
+int64_t mnrf_train_save_floats(int64_t B);
+int64_t mnrf_train_mask_words(int64_t B);
+int64_t mnrf_train_workspace_floats(int64_t B);
+
+/* mnrf_field_forward for training: all four heads (+ `normal` when non-null), and keeps in
+ * save_x / save_mask / save_inv what mnrf_field_backward needs (no recomputation). */
+int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                             const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                             int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                             float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                             float* save_inv, void* stream);
+
+/* Backward of the field MLP: given dL/d{sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B)},
+ * writes the gradient of every parameter (d_params: HOST array of MNRF_N_PARAMS device pointers,
+ * state_dict order, overwritten), dL/dxyz (B,3) and dL/d(view encoding) (B,32 padded) when non-null.
+ * The gradient flowing into `normal` (the normalised density gradient: a second-order term) is
+ * not propagated by this entry point.
+ * Autograd equivalent: loss.backward() through models/mirror_nerf.py:101-212. */
+int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                        const float* rays, const float* z_vals, int spr,
+                        const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                        const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                        const float* is_mirror, const float* save_x, const uint64_t* save_mask,
+                        const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
+                        float* d_dir, void* stream);
+
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
                        float* rays, void* stream);

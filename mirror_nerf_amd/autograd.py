@@ -71,3 +71,117 @@ class CompositeFn(torch.autograd.Function):
                 like(d_m, is_mirror) if is_mirror is not None else None,
                 like(d_pn, pred_normal) if pred_normal is not None else None,
                 like(d_n, normal) if normal is not None else None, None)
+
+
+class FieldFn(torch.autograd.Function):
+    """mnrf_field_forward_train / mnrf_field_backward: the fused MirrorNeRF evaluation with a
+    hand-written backward (activation gradients by transposed MFMA chains, weight gradients by
+    split-K MFMA GEMMs over the saved activations).
+
+    apply(module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params) ->
+        sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty)
+    Positions come from `xyz` (B,>=3 columns, row stride = its row length) or from rays (N,8) and
+    z_vals (N,spr).  `dir_emb`: (B/spr, 27) view encoding.  `params`: the module's 32 parameters in
+    state_dict order (so that autograd routes their gradients).
+    `normal` (the normalised density gradient) is returned non-differentiable: its backward is a
+    second-order term that this round does not build."""
+
+    @staticmethod
+    def forward(ctx, module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params):
+        from .weights import packed_of
+        L = _lib.lib()
+        packed = packed_of(module)
+        dev = packed.device
+        B = xyz.shape[0] if xyz is not None else rays.shape[0] * spr
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        xyz, rays, z_vals, dir_emb = _c(xyz), _c(rays), _c(z_vals), _c(dir_emb)
+        sigma, rgb, pn, mir = f(B), f(B, 3), f(B, 3), f(B)
+        normal = f(B, 3) if want_normal else None
+        save_x = f(max(1, L.mnrf_train_save_floats(B)))
+        save_mask = torch.empty(max(1, L.mnrf_train_mask_words(B)), dtype=torch.int64, device=dev)
+        save_inv = f(max(1, B))
+        p = _lib.ptr
+        xs = xyz.shape[1] if xyz is not None else 3
+        if B:
+            _lib.check(L.mnrf_field_forward_train(
+                p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
+                p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), _lib.stream()), "mnrf_field_forward_train")
+        ctx.module, ctx.spr, ctx.B = module, spr, B
+        ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv)
+        ctx.param_shapes = [tuple(t.shape) for t in params]
+        if normal is None:
+            normal = f(0, 3)
+        ctx.mark_non_differentiable(normal)
+        return sigma, rgb, pn, mir, normal
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal):
+        import ctypes
+        from .weights import packed_of
+        L = _lib.lib()
+        xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv = ctx.saved_tensors
+        B, spr = ctx.B, ctx.spr
+        packed = packed_of(ctx.module)
+        dev = packed.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        z = lambda t, *s: torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()  # noqa: E731
+        g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
+        d_params = [f(*s) for s in ctx.param_shapes]
+        arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in d_params])
+        need = ctx.needs_input_grad
+        want_xyz = (xyz is not None and need[2]) or (rays is not None and need[3])
+        d_xyz = f(B, 3) if want_xyz else None
+        d_dir = f(B, 32) if need[5] else None
+        ws = f(max(1, L.mnrf_train_workspace_floats(B)))
+        p = _lib.ptr
+        xs = xyz.shape[1] if xyz is not None else 3
+        if B:
+            _lib.check(L.mnrf_field_backward(
+                p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
+                p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), _lib.stream()),
+                "mnrf_field_backward")
+        else:
+            for t in d_params:
+                t.zero_()
+        g_xyz = g_rays = g_de = None
+        if d_xyz is not None:
+            if xyz is not None:
+                g_xyz = torch.zeros_like(xyz)
+                g_xyz[:, :3] = d_xyz
+            else:   # x = o + d*z  (rendering.py:302): dL/do = sum_s dL/dx, dL/dd = sum_s z dL/dx
+                N = rays.shape[0]
+                dx = d_xyz.view(N, spr, 3)
+                g_rays = torch.zeros_like(rays)
+                g_rays[:, 0:3] = dx.sum(1)
+                g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
+        if d_dir is not None:
+            g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
+        return (None, None, g_xyz, g_rays, None, g_de, None, *d_params)
+
+
+class EmbedFn(torch.autograd.Function):
+    """Embedding.forward with its analytic backward (per-ray tensors only: the view encoding of
+    reflected rays carries gradient back to the surface normal, train.py:205 "not detach()")."""
+
+    @staticmethod
+    def forward(ctx, x, n_freqs):
+        x = x.float().contiguous()
+        n, c = x.shape
+        out = torch.empty(n, c * (2 * n_freqs + 1), dtype=torch.float32, device=x.device)
+        if n:
+            _lib.check(_lib.lib().mnrf_embed(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.stream()), "mnrf_embed")
+        ctx.save_for_backward(x)
+        ctx.n_freqs = n_freqs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        c = x.shape[1]
+        gx = g[:, :c].clone()
+        for k in range(ctx.n_freqs):
+            fr = 2.0 ** k
+            gs = g[:, c * (1 + 2 * k): c * (2 + 2 * k)]
+            gc = g[:, c * (2 + 2 * k): c * (3 + 2 * k)]
+            gx += fr * (gs * torch.cos(fr * x) - gc * torch.sin(fr * x))
+        return gx, None

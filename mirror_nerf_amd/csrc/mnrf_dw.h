@@ -1,0 +1,11 @@
+// mnrf_dw.h -- weight-gradient driver (mnrf_dw.hip), called from the backward C-ABI entry point.
+#pragma once
+#include <hip/hip_runtime.h>
+namespace mnrf {
+int dw_splits(long long B);
+long long dw_workspace_floats(long long B);
+// save_x: activations of the training forward; dY: pre-activation gradients of the backward kernel;
+// ws: dw_workspace_floats(B) floats; d_params: 32 device pointers in state_dict order (overwritten).
+int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
+              hipStream_t s);
+}  // namespace mnrf

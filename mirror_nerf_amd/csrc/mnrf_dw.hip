@@ -1,0 +1,286 @@
+// mnrf_dw.hip -- weight gradients of the field MLP (training) for gfx950.
+//
+// The backward kernel (mnrf_field_bwd.inc) leaves, per Linear, the pre-activation gradient dY
+// [samples][N] and the training forward leaves its input X [samples][K], both row-major in HBM
+// (288 GB of HBM3E make keeping ~22 KB per sample affordable; recomputing them would cost another
+// forward).  dW[n][k] = sum_s dY[s][n] X[s][k] is a GEMM whose contraction runs over samples:
+//   * dw_gemm_kernel: 128 x TK output tile per workgroup, v_mfma_f32_16x16x4_f32 with the sample
+//     axis as the MFMA k axis (A operand = 4 rows x 16 columns of dY, B operand = 4 rows x 16
+//     columns of X, straight out of padded LDS tiles, bank-conflict free), split over the sample
+//     range; bias gradients (column sums of dY) fall out of the A operands already in registers;
+//   * dw_small_kernel: the 1- and 3-row Linears (sigma, rgb, normal_net.1, is_mirror_net.2);
+//   * dw_finish_kernel: sums the split partials and writes gradients in nn.Linear (out,in) layout.
+// Autograd equivalent: the .grad accumulation of loss.backward() for models/mirror_nerf.py:59-99.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mnrf.h"
+#include "mnrf_error.h"
+#include "mnrf_layout.h"
+#include "mnrf_dw.h"
+
+namespace mnrf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DW_TN = 128;
+constexpr int DW_CH = 32;          // samples per LDS stage
+constexpr int DW_PAD = 16;         // row stride = width + 16 floats: lanes of rows r and r+1 hit different bank halves
+
+template <int TK>
+__global__ __launch_bounds__(256) void dw_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
+                                                      long long B, int splits, int N, int K, float* __restrict__ Cpart,
+                                                      float* __restrict__ bpart) {
+    constexpr int LDA = DW_TN + DW_PAD;
+    constexpr int LDX = TK + DW_PAD;
+    __shared__ float As[DW_CH * LDA];
+    __shared__ float Xs[DW_CH * LDX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int wn = wave >> 1, wk = wave & 1;
+    constexpr int MB = 4;              // 64 rows of dW per wave
+    constexpr int KB = TK / 32;        // TK/2 columns per wave
+    const int n0 = blockIdx.x * DW_TN, k0 = blockIdx.y * TK, split = blockIdx.z;
+    const long long per = (B + splits - 1) / splits;
+    const long long s_begin = split * per;
+    const long long s_end = s_begin + per < B ? s_begin + per : B;
+
+    f32x4 acc[MB][KB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[MB] = {0.f, 0.f, 0.f, 0.f};
+
+    for (long long s0 = s_begin; s0 < s_end; s0 += DW_CH) {
+        __syncthreads();
+        // stage DW_CH rows of dY (128 columns) and X (TK columns); rows past the range are zero
+        for (int v = tid; v < DW_CH * (DW_TN / 4); v += 256) {
+            const int r = v / (DW_TN / 4), c4 = v % (DW_TN / 4);
+            f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s0 + r < s_end) val = *(const f32x4*)(A + (s0 + r) * lda + n0 + c4 * 4);
+            *(f32x4*)(As + r * LDA + c4 * 4) = val;
+        }
+        for (int v = tid; v < DW_CH * (TK / 4); v += 256) {
+            const int r = v / (TK / 4), c4 = v % (TK / 4);
+            f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s0 + r < s_end) val = *(const f32x4*)(X + (s0 + r) * ldx + k0 + c4 * 4);
+            *(f32x4*)(Xs + r * LDX + c4 * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < DW_CH / 4; ++ks) {
+            float a[MB], b[KB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = As[(ks * 4 + g) * LDA + wn * 64 + mb * 16 + i];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) b[kb] = Xs[(ks * 4 + g) * LDX + wk * (TK / 2) + kb * 16 + i];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bsum[mb] += a[mb];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    acc[mb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[kb], acc[mb][kb], 0, 0, 0);
+            }
+        }
+    }
+    // partial tile: C[n = 4g + r][k = i] of every 16x16 block
+    float* C = Cpart + (long long)split * N * K;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + mb * 16 + 4 * g + r;
+                const int k = k0 + wk * (TK / 2) + kb * 16 + i;
+                C[(long long)n * K + k] = acc[mb][kb][r];
+            }
+    if (bpart && blockIdx.y == 0 && wk == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float v = bsum[mb];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) bpart[(long long)split * N + n0 + wn * 64 + mb * 16 + i] = v;
+        }
+    }
+}
+
+// dW for Linears with <= 3 output rows: Cpart[split][3][K], bpart[split][3]
+__global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__ A, int lda, int n_true,
+                                                       const float* __restrict__ X, int ldx, int K, long long B,
+                                                       int splits, float* __restrict__ Cpart, float* __restrict__ bpart) {
+    const int k = threadIdx.x;
+    const int split = blockIdx.x;
+    const long long per = (B + splits - 1) / splits;
+    const long long s_begin = split * per;
+    const long long s_end = s_begin + per < B ? s_begin + per : B;
+    float acc[3] = {0.f, 0.f, 0.f}, bs[3] = {0.f, 0.f, 0.f};
+    for (long long s = s_begin; s < s_end; ++s) {
+        const float x = k < K ? X[s * ldx + k] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const float a = n < n_true ? A[s * lda + n] : 0.f;
+            acc[n] += a * x;
+            bs[n] += a;
+        }
+    }
+    if (k < K) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) Cpart[((long long)split * 3 + n) * K + k] = acc[n];
+    }
+    if (k < 3) bpart[(long long)split * 3 + k] = bs[k];
+}
+
+// ---- assemble parameter gradients
+struct DwSource {
+    const float* part;   // [splits][N][K]
+    int K;               // row length of the partial
+    int N;               // rows of the partial (128/256, or 3 for the small kernel)
+};
+struct DwLayer {
+    DwSource src[2];     // columns [0, split_col) from src[0], the rest from src[1]
+    int split_col;       // = in_features when there is a single source
+    int kind0;           // column map of src[0]: 0 identity, 1 xyz-encoding pair order
+    const float* bpart;  // [splits][N]
+    int out_f, in_f;
+    float* d_w;
+    float* d_b;
+};
+struct DwFinishArgs {
+    DwLayer layer[16];
+    int splits;
+    int encpos[64];      // logical encoding column -> position in the saved pair-ordered encoding
+};
+
+__global__ void dw_finish_kernel(DwFinishArgs F) {
+    const int L = blockIdx.y;
+    const DwLayer& ly = F.layer[L];
+    const int nw = ly.out_f * ly.in_f;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nw) {
+        const int n = e / ly.in_f, c = e % ly.in_f;
+        const bool first = c < ly.split_col;
+        const DwSource& s = first ? ly.src[0] : ly.src[1];
+        int col = first ? c : c - ly.split_col;
+        if (first && ly.kind0 == 1) col = F.encpos[c];
+        float v = 0.f;
+        for (int sp = 0; sp < F.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];
+        ly.d_w[e] = v;
+    } else if (e < nw + ly.out_f) {
+        const int n = e - nw;
+        const int NB = ly.src[0].N;
+        float v = 0.f;
+        for (int sp = 0; sp < F.splits; ++sp) v += ly.bpart[(long long)sp * NB + n];
+        ly.d_b[n] = v;
+    }
+}
+
+}  // namespace mnrf
+
+// ====================================================================== driver
+
+namespace mnrf {
+
+int dw_splits(long long B) {
+    long long s = (B + 4095) / 4096;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+// floats of partial results per split (see the job list in launch_dw)
+constexpr long long DW_PER_SPLIT = 256LL * 64 * 2 + 256LL * 256 * 8 + 128LL * 256 * 3 + 128LL * 32 + 3LL * 256 + 3LL * 128 * 3 +
+                                   /* bias partials */ 256LL * 9 + 128LL * 3 + 3LL * 4;
+
+long long dw_workspace_floats(long long B) { return (long long)dw_splits(B) * DW_PER_SPLIT; }
+
+template <int TK>
+static void gemm(const float* A, int lda, int N, const float* X, int ldx, int K, long long B, int splits, float* C, float* bp,
+                 hipStream_t s) {
+    dim3 grid(N / DW_TN, K / TK, splits);
+    hipLaunchKernelGGL((dw_gemm_kernel<TK>), grid, dim3(256), 0, s, A, lda, X, ldx, B, splits, N, K, C, bp);
+}
+
+int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
+              hipStream_t s) {
+    const int splits = dw_splits(B);
+    float* p = ws;
+    auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
+    auto X = [&](int sec) { return save_x + (long long)sec * B; };
+    auto Y = [&](int sec) { return dY + (long long)sec * B; };
+    DwFinishArgs F;
+    F.splits = splits;
+    for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
+    for (int gq = 0; gq < 4; ++gq)
+        for (int t = 0; t < 16; ++t) {
+            const int c = enc_col(t, gq);
+            if (c >= 0) F.encpos[c] = 16 * (t >> 2) + 4 * gq + (t & 3);
+        }
+    auto layer = [&](int L, int out_f, int in_f, DwSource s0, DwSource s1, int split_col, int kind0, const float* bp) {
+        DwLayer& ly = F.layer[L];
+        ly.src[0] = s0; ly.src[1] = s1; ly.split_col = split_col; ly.kind0 = kind0; ly.bpart = bp;
+        ly.out_f = out_f; ly.in_f = in_f; ly.d_w = d_params[2 * L]; ly.d_b = d_params[2 * L + 1];
+    };
+    // ---- trunk
+    for (int i = 0; i < 8; ++i) {
+        float* bp = take(256);
+        if (i == 0) {
+            float* c = take(256 * 64);
+            gemm<64>(Y(DY_L), 256, 256, X(SEC_ENC), 64, 64, B, splits, c, bp, s);
+            layer(0, 256, 63, DwSource{c, 64, 256}, DwSource{c, 64, 256}, 63, 1, bp);
+        } else if (i == 4) {
+            float* ce = take(256 * 64);
+            float* ch = take(256 * 256);
+            gemm<64>(Y(DY_L + 256 * 4), 256, 256, X(SEC_ENC), 64, 64, B, splits, ce, bp, s);
+            gemm<128>(Y(DY_L + 256 * 4), 256, 256, X(SEC_H + 256 * 3), 256, 256, B, splits, ch, nullptr, s);
+            layer(4, 256, 319, DwSource{ce, 64, 256}, DwSource{ch, 256, 256}, 63, 1, bp);
+        } else {
+            float* c = take(256 * 256);
+            gemm<128>(Y(DY_L + 256 * i), 256, 256, X(SEC_H + 256 * (i - 1)), 256, 256, B, splits, c, bp, s);
+            layer(i, 256, 256, DwSource{c, 256, 256}, DwSource{c, 256, 256}, 256, 0, bp);
+        }
+    }
+    const float* h8 = X(SEC_H + 256 * 7);
+    {   // xyz_encoding_final (L = 8)
+        float* bp = take(256);
+        float* c = take(256 * 256);
+        gemm<128>(Y(DY_FIN), 256, 256, h8, 256, 256, B, splits, c, bp, s);
+        layer(8, 256, 256, DwSource{c, 256, 256}, DwSource{c, 256, 256}, 256, 0, bp);
+    }
+    {   // dir_encoding.0 (L = 9): columns [0,256) from final, [256,283) from the view encoding
+        float* bp = take(128);
+        float* cf = take(128 * 256);
+        float* cd = take(128 * 32);
+        gemm<128>(Y(DY_DIR), 128, 128, X(SEC_FIN), 256, 256, B, splits, cf, bp, s);
+        gemm<32>(Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, B, splits, cd, nullptr, s);
+        layer(9, 128, 283, DwSource{cf, 256, 128}, DwSource{cd, 32, 128}, 256, 0, bp);
+    }
+    auto small = [&](int L, const float* A, int lda, int n_true, const float* Xp, int K) {
+        float* bp = take(3);
+        float* c = take(3 * K);
+        hipLaunchKernelGGL(dw_small_kernel, dim3(splits), dim3(256), 0, s, A, lda, n_true, Xp, K, K, B, splits, c, bp);
+        layer(L, n_true, K, DwSource{c, K, 3}, DwSource{c, K, 3}, K, 0, bp);
+    };
+    small(10, g_sigma, 1, 1, h8, 256);                          // sigma
+    small(11, Y(DY_RGB), 16, 3, X(SEC_HD), 128);                // rgb.0
+    {   // normal_net.0 (L = 12)
+        float* bp = take(128);
+        float* c = take(128 * 256);
+        gemm<128>(Y(DY_NRM1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
+        layer(12, 128, 256, DwSource{c, 256, 128}, DwSource{c, 256, 128}, 256, 0, bp);
+    }
+    small(13, Y(DY_NRM2), 16, 3, X(SEC_HN), 128);               // normal_net.1
+    {   // is_mirror_net.0 (L = 14)
+        float* bp = take(128);
+        float* c = take(128 * 256);
+        gemm<128>(Y(DY_MIR1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
+        layer(14, 128, 256, DwSource{c, 256, 128}, DwSource{c, 256, 128}, 256, 0, bp);
+    }
+    small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
+    if (p - ws > dw_workspace_floats(B)) return -1;
+    // largest layer: 256 x 319 + 256 elements
+    hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
+    return 0;
+}
+
+}  // namespace mnrf

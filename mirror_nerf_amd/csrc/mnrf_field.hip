@@ -41,6 +41,10 @@ struct FieldArgs {
     float* is_mirror;
     float* normal;
     float* geo_feat;
+    // training forward: activations / relu masks / normal-head norm kept for the backward pass
+    float* save_x;                 // [SAVE_FLOATS sections][B][width]   (null = inference)
+    unsigned long long* save_mask; // [tiles][N_MASKS][S][256]
+    float* save_inv;               // [B] 1/|v| of normal_net (negative when the eps clamp was active)
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,6 +57,7 @@ namespace s2 {
 constexpr int S = 2;
 constexpr int MIN_WAVES_PER_SIMD = 1;
 #include "mnrf_field_impl.inc"
+#include "mnrf_field_bwd.inc"
 }  // namespace s2
 namespace s1 {
 constexpr int S = 1;
@@ -69,6 +74,7 @@ struct PackArgs {
 struct PartTable {
     Part fwd[N_FWD_PARTS];
     Part bwd[N_BWD_PARTS];
+    Part hbwd[N_HBWD_PARTS];
 };
 
 __host__ __device__ inline void build_parts(PartTable& T) {
@@ -100,6 +106,17 @@ __host__ __device__ inline void build_parts(PartTable& T) {
     add(T.bwd, n, 8, 256, 319, 16, 16, ENC_XYZ, KIND_H);                        // layer 5: 16 hidden row blocks
     for (int i = 3; i >= 1; --i) add(T.bwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // layers 4,3,2
     add(T.bwd, n, 0, 256, 63, 16, 4, 0, KIND_ENC);                              // layer 1: 4 encoding row blocks
+    // head backward (training): n_true = rows of W = contraction length, nb = 16-blocks of W's columns
+    n = 0;
+    tile = 0;
+    add(T.hbwd, n, 22, 3, 128, 1, 8, 0, KIND_H);        // rgb^T
+    add(T.hbwd, n, 18, 128, 283, 8, 16, 0, KIND_H);     // dir_encoding^T, xyz_encoding_final columns
+    add(T.hbwd, n, 18, 128, 283, 8, 2, 256, KIND_DIR);  // dir_encoding^T, view-encoding columns
+    add(T.hbwd, n, 16, 256, 256, 16, 16, 0, KIND_H);    // xyz_encoding_final^T
+    add(T.hbwd, n, 26, 3, 128, 1, 8, 0, KIND_H);        // normal_net.1^T
+    add(T.hbwd, n, 24, 128, 256, 8, 16, 0, KIND_H);     // normal_net.0^T
+    add(T.hbwd, n, 30, 1, 128, 1, 8, 0, KIND_H);        // is_mirror_net.2^T
+    add(T.hbwd, n, 28, 128, 256, 8, 16, 0, KIND_H);     // is_mirror_net.0^T
 }
 
 __global__ void pack_kernel(PackArgs P, PartTable T) {
@@ -139,27 +156,33 @@ __global__ void pack_kernel(PackArgs P, PartTable T) {
         else if (b < BIAS_WSIG) { if (b - BIAS_MIR2 < 1) v = P.params[31][0]; }
         else if (b < BIAS_WSIG + 256) v = P.params[20][b - BIAS_WSIG];
     } else {
-        // ---- backward tiles: A[row rho][contraction c] = W_i[c][column(rho)]
-        const long long q = p - OFF_BWD;
+        // ---- transposed tiles (density-gradient trunk stream, then the head-backward stream):
+        //      A[row rho][contraction c] = W[c][column(rho)]
+        const bool heads = p >= OFF_HBWD;
+        const long long q = p - (heads ? OFF_HBWD : OFF_BWD);
         const int tile = (int)(q / TILE_FLOATS);
         const int within = (int)(q % TILE_FLOATS);
         const int lane = within >> 2, j = within & 3, g = lane >> 4, i = lane & 15;
+        const Part* parts = heads ? T.hbwd : T.bwd;
+        const int nparts = heads ? N_HBWD_PARTS - 1 : N_BWD_PARTS;
         int k = 0;
-        while (k + 1 < N_BWD_PARTS && T.bwd[k + 1].tile0 <= tile) ++k;
-        const Part pt = T.bwd[k];
+        while (k + 1 < nparts && parts[k + 1].tile0 <= tile) ++k;
+        const Part pt = parts[k];
         const int lt = tile - pt.tile0;
-        const int tq = lt / pt.nb, nb = lt % pt.nb;
+        const int tq = lt / pt.nb, nb = lt % pt.nb;   // tq >= ntq: chunk padding
         const int rho = 16 * nb + i;                 // output row of the transposed product
-        const int c = 16 * tq + 4 * g + j;           // contraction index = output unit of layer i
+        const int c = 16 * tq + 4 * g + j;           // contraction index = row of W
         int col;
         if (pt.kind == KIND_ENC) {
             // C-form row rho = 16*nbe + 4*g' + r  <->  k-step t' = 4*nbe + r of lane group g'
             const int nbe = rho >> 4, gq = (rho >> 2) & 3, r = rho & 3;
             col = enc_col(4 * nbe + r, gq);
+        } else if (pt.kind == KIND_DIR) {
+            col = rho < ENC_DIR ? pt.col_off + rho : -1;
         } else {
             col = pt.col_off + rho;
         }
-        if (col >= 0) v = P.params[pt.param][(long long)c * pt.ld + col];
+        if (tq < pt.ntq && c < pt.n_true && col >= 0) v = P.params[pt.param][(long long)c * pt.ld + col];
     }
     P.packed[p] = v;
 }
@@ -168,6 +191,7 @@ __global__ void pack_kernel(PackArgs P, PartTable T) {
 
 // ====================================================================== C ABI
 #include "../../include/mnrf.h"
+#include "mnrf_dw.h"
 #include "mnrf_error.h"
 
 using namespace mnrf;
@@ -220,4 +244,60 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
                                 : s2::launch(A, sigma_only, grad, (hipStream_t)stream);
     if (rc != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_forward");
+}
+
+// ---------------------------------------------------------------------- training entry points
+static inline int64_t train_tiles(int64_t B) { return (B + s2::WG_SAMPLES - 1) / s2::WG_SAMPLES; }
+
+extern "C" int64_t mnrf_train_save_floats(int64_t B) { return (int64_t)SAVE_FLOATS * B; }
+extern "C" int64_t mnrf_train_mask_words(int64_t B) { return train_tiles(B) * N_MASKS * s2::S * s2::WG_THREADS; }
+extern "C" int64_t mnrf_train_workspace_floats(int64_t B) { return (int64_t)DY_FLOATS * B + dw_workspace_floats(B); }
+
+extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                        const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                                        int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                        float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                                        float* save_inv, void* stream) {
+    if (!packed || !save_x || !save_mask || !save_inv) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: negative sample count");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: need xyz or rays+z_vals");
+    if (spr < 1 || !dir_emb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: bad spr / dir_emb");
+    if (!sigma || !rgb || !pred_normal || !is_mirror)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: the four head outputs are required (the backward reads them)");
+    FieldArgs A{packed, MNRF_GRAD_NORMAL, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
+                (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
+                save_x, (unsigned long long*)save_mask, save_inv};
+    // always the s2 tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map
+    if (s2::launch(A, false, true, (hipStream_t)stream) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: too many samples for one launch");
+    return mnrf_check_launch("mnrf_field_forward_train");
+}
+
+extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                   const float* rays, const float* z_vals, int spr,
+                                   const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                   const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                                   const float* is_mirror, const float* save_x, const uint64_t* save_mask,
+                                   const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
+                                   float* d_dir, void* stream) {
+    if (!packed || !save_x || !save_mask || !save_inv || !workspace || !d_params)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: negative sample count");
+    if (!g_sigma || !g_rgb || !g_pred_normal || !g_is_mirror)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: all four upstream gradients are required (pass zeros)");
+    if (!rgb || !pred_normal || !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: forward outputs missing");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: need xyz or rays+z_vals");
+    for (int i = 0; i < MNRF_N_PARAMS; ++i)
+        if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: null gradient pointer");
+    float* dY = workspace;
+    float* ws = workspace + (int64_t)DY_FLOATS * B;
+    s2::FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
+                       g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, dY, d_xyz, d_dir};
+    hipStream_t s = (hipStream_t)stream;
+    if (s2::launch_bwd(A, s) != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");
+    int rc = mnrf_check_launch("mnrf_field_backward (activation gradients)");
+    if (rc != MNRF_OK) return rc;
+    if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, s) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: workspace accounting error");
+    return mnrf_check_launch("mnrf_field_backward (weight gradients)");
 }

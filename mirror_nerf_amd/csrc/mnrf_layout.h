@@ -86,12 +86,39 @@ constexpr int BIAS_MIR2 = 2736;       // 16
 constexpr int BIAS_WSIG = 2752;       // 256: sigma.weight, seed of the density gradient
 constexpr int BIAS_FLOATS = 3072;     // padded to 12 KiB
 
+// ---- head-backward stream (training): A = W^T of rgb, dir_encoding (final | view columns),
+//      xyz_encoding_final, normal_net.1, normal_net.0, is_mirror_net.2, is_mirror_net.0
+constexpr int N_HBWD_PARTS = 9;   // 8 used (+1 spare slot)
+constexpr int HBWD_TILES = 16 + 128 + 16 + 256 + 16 + 128 + 16 + 128;                 // 704
+
 constexpr int64_t OFF_FWD = 0;
 constexpr int64_t OFF_BIAS = (int64_t)FWD_TILES * TILE_FLOATS;
 constexpr int64_t OFF_BWD = OFF_BIAS + BIAS_FLOATS;
-constexpr int64_t PACKED_FLOATS = OFF_BWD + (int64_t)BWD_TILES * TILE_FLOATS;
+constexpr int64_t OFF_HBWD = OFF_BWD + (int64_t)BWD_TILES * TILE_FLOATS;
+constexpr int64_t PACKED_FLOATS = OFF_HBWD + (int64_t)HBWD_TILES * TILE_FLOATS;
+
+// ---- activations saved by the training forward, [section][sample][width], B-form column order
+constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)
+constexpr int SEC_H = 64;             // 8 x 256  h1..h8 (post-ReLU)
+constexpr int SEC_FIN = 2112;         // 256  xyz_encoding_final output
+constexpr int SEC_DIRE = 2368;        // 32   view encoding padded
+constexpr int SEC_HD = 2400;          // 128  dir_encoding output (post-ReLU)
+constexpr int SEC_HN = 2528;          // 128  normal_net.0 output
+constexpr int SEC_HM = 2656;          // 128  is_mirror_net.0 output (post-LeakyReLU)
+constexpr int SAVE_FLOATS = 2784;     // per sample
+constexpr int N_MASKS = 10;           // relu masks of L1..L8, dir_encoding, sign mask of is_mirror_net.0
+// ---- pre-activation gradients written by the backward kernel, same convention
+constexpr int DY_L = 0;               // 8 x 256
+constexpr int DY_FIN = 2048;          // 256
+constexpr int DY_DIR = 2304;          // 128
+constexpr int DY_NRM1 = 2432;         // 128
+constexpr int DY_MIR1 = 2560;         // 128
+constexpr int DY_RGB = 2688;          // 16 (3 used)
+constexpr int DY_NRM2 = 2704;         // 16 (3 used)
+constexpr int DY_MIR2 = 2720;         // 16 (1 used)
+constexpr int DY_FLOATS = 2736;       // per sample
 
 static_assert(FWD_TILES % CHUNK_TILES == 0 && FWD_TILES_SIGMA % CHUNK_TILES == 0, "chunking");
-static_assert(BWD_TILES % CHUNK_TILES == 0, "chunking");
+static_assert(BWD_TILES % CHUNK_TILES == 0 && HBWD_TILES % CHUNK_TILES == 0, "chunking");
 
 }  // namespace mnrf

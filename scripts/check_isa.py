@@ -26,7 +26,7 @@ def main():
                         "--cuda-device-only", SRC, "-o", out], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     ok = True
-    for m in re.finditer(r"^(_ZN4mnrf2s[12]12field_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4mnrf2s[12]1[26]field_(?:bwd_)?kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         mf = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x4" in l]
         inner = body[mf[0]:mf[-1] + 1]
@@ -34,7 +34,7 @@ def main():
         scratch = [l for l in inner if "scratch_" in l]
         reads = sum("ds_read_b128" in l for l in inner)
         counted = sum(bool(re.search(r"s_waitcnt lgkmcnt\([1-4]\)", l)) for l in inner)
-        grad = "Lb1EEEv" in name
+        grad = "Lb1EEEv" in name or "bwd" in name
         print(f"{name}: {len(mf)} MFMA, {reads} ds_read_b128, {counted} counted waits, "
               f"{len(smem)} scalar loads inside, {len(scratch)} scratch ops inside")
         if smem or (scratch and not grad) or counted < 100:

@@ -47,3 +47,76 @@ def test_composite_backward_matches_autograd(S, white):
     assert _rel(r2.grad, r1.grad) <= 1e-5
     for k in base:
         assert _rel(d2[k].grad, d1[k].grad) <= 2e-4, (k, _rel(d2[k].grad, d1[k].grad))
+
+
+def _field_setup(seed=5):
+    import mirror_nerf_amd as M
+    from tests.golden import weights as GW
+    sd = GW.apply_tweaks(GW.make_state_dict(seed, 1)[0], GW.OPAQUE)
+    m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(DEV), sd
+
+
+@pytest.mark.parametrize("B", [200, 1000])
+def test_field_backward_matches_autograd_xyz_mode(B):
+    """All 32 parameter gradients, dL/dxyz and dL/d(view encoding) of the fused field kernel."""
+    from mirror_nerf_amd.autograd import FieldFn
+    m, sd = _field_setup()
+    torch.manual_seed(B)
+    xyz = (torch.rand(B, 3, device=DEV) * 6 - 3)
+    d = TR.l2n(torch.randn(B, 3, device=DEV))
+    de = TR.embed(d, 4)
+    cot = [torch.randn(B, device=DEV), torch.randn(B, 3, device=DEV), torch.randn(B, 3, device=DEV), torch.randn(B, device=DEV)]
+    # reference
+    w = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in sd.items()}
+    x1 = xyz.clone().requires_grad_(True)
+    de1 = de.clone().requires_grad_(True)
+    outs = TR.field(w, x1, de1)
+    sum((o * c).sum() for o, c in zip(outs, cot)).backward()
+    # HIP
+    x2 = xyz.clone().requires_grad_(True)
+    de2 = de.clone().requires_grad_(True)
+    params = list(m.parameters())
+    got = FieldFn.apply(m, 1, x2, None, None, de2, False, *params)
+    for o, r in zip(got[:4], outs):
+        assert _rel(o, r) <= 2e-5
+    sum((o * c).sum() for o, c in zip(got[:4], cot)).backward()
+    names = [n for n, _ in m.named_parameters()]
+    worst = 0.0
+    for n, p in zip(names, params):
+        e = _rel(p.grad, w[n].grad)
+        worst = max(worst, e)
+        assert e <= 2e-3, (n, e)
+    assert _rel(x2.grad, x1.grad) <= 2e-3
+    assert _rel(de2.grad, de1.grad) <= 2e-3
+    print("worst relative parameter-gradient error", worst)
+
+
+def test_field_backward_ray_mode_accumulates_over_samples():
+    from mirror_nerf_amd.autograd import FieldFn
+    m, sd = _field_setup(7)
+    torch.manual_seed(0)
+    N, S = 24, 16      # 384 samples: 3 tiles of 128
+    rays = torch.randn(N, 8, device=DEV)
+    rays[:, 3:6] = TR.l2n(rays[:, 3:6])
+    z = torch.sort(torch.rand(N, S, device=DEV) * 4 + 0.2, 1)[0]
+    de = TR.embed(rays[:, 3:6], 4)
+    cot = [torch.randn(N * S, device=DEV), torch.randn(N * S, 3, device=DEV), torch.randn(N * S, 3, device=DEV),
+           torch.randn(N * S, device=DEV)]
+    w = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in sd.items()}
+    r1 = rays.clone().requires_grad_(True)
+    de1 = de.clone().requires_grad_(True)
+    xyz = (r1[:, None, 0:3] + r1[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+    outs = TR.field(w, xyz, de1.repeat_interleave(S, 0))
+    sum((o * c).sum() for o, c in zip(outs, cot)).backward()
+    r2 = rays.clone().requires_grad_(True)
+    de2 = de.clone().requires_grad_(True)
+    params = list(m.parameters())
+    got = FieldFn.apply(m, S, None, r2, z, de2, True, *params)
+    assert got[4].shape == (N * S, 3) and not got[4].requires_grad
+    sum((o * c).sum() for o, c in zip(got[:4], cot)).backward()
+    assert _rel(r2.grad[:, :6], r1.grad[:, :6]) <= 2e-3
+    assert _rel(de2.grad, de1.grad) <= 2e-3
+    for (n, p) in zip([n for n, _ in m.named_parameters()], params):
+        assert _rel(p.grad, w[n].grad) <= 2e-3, n
