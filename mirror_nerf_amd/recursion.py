@@ -68,6 +68,46 @@ def _blend(base, sec, index, mask, want_reflect):
     return out, refl
 
 
+def _reflect_autograd(rays, x_surface, normal, mask, compact):
+    """The same reflected-ray construction with torch ops, used only when gradients must flow from
+    the reflected render back into the surface point and normal (train.py:205 "not detach() to
+    jointly optimize").  Per-ray tensors; the heavy lifting stays in the HIP kernels."""
+    eps = torch.tensor(torch.finfo(torch.float32).eps, device=rays.device)
+
+    def l2n(v):
+        return v / torch.sqrt(torch.maximum((v * v).sum(-1, keepdim=True), eps))
+    n = l2n(normal)
+    w = l2n(-rays[:, 3:6])
+    cos = (w * n).sum(-1)
+    rdir = 2 * cos[:, None] * n - w
+    far = rays[:, 7:8]
+    sec = torch.cat([x_surface, rdir, torch.ones_like(far) * RAY_FORWARD_OFFSET, far], -1)
+    index = None
+    if compact:
+        index = torch.nonzero(mask != 0)[:, 0].to(torch.int32)
+        sec = sec[index.long()]
+    return sec, index, rdir
+
+
+def _blend_autograd(base, sec, index, mask, want_reflect):
+    """train.py:263-296 with torch ops (autograd path)."""
+    if index is not None:
+        part = base.clone().detach()
+        part[index.long()] = sec
+    else:
+        part = sec
+    m = mask.float()[:, None]
+    out = m * part + (1 - m) * base
+    refl = None
+    if want_reflect:
+        refl = torch.zeros_like(base)
+        if index is not None:
+            refl[index.long()] = sec.detach()
+        else:
+            refl = sec.detach()
+    return out, refl
+
+
 def _pick_normal(r, sel):
     """train.py:194-215 / eval.py:338-360 -- composited predicted normal, else composited grad normal."""
     if f"pred_normal_{sel}" in r:
@@ -98,7 +138,8 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
             mask = r["mirror_mask_coarse"]
         else:
             mask = torch.zeros(N, device=dev)
-        any_mirror = _threshold_(mask)
+        any_mirror = _threshold_(mask.detach())   # in place on the shared storage, like the reference
+        mask = mask.detach()
     else:
         mask = gt.clone().contiguous()
     only_in = hp.only_trace_rays_in_mirrors
@@ -115,8 +156,13 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     is_eval = extra_chunk.get("is_eval", False)
 
     traced = False
+    grad_path = torch.is_grad_enabled() and r[f"rgb_{sel}"].requires_grad
+    reflect_fn, blend_fn = (_reflect_autograd, _blend_autograd) if grad_path else (_reflect, _blend)
     if trace and N:
-        sec, index, rdir = _reflect(rays_chunk, r[f"x_surface_{sel}"], _pick_normal(r, sel), mask, only_in)
+        nrm = _pick_normal(r, sel)
+        if getattr(hp, "detach_normal_in_reflection", False):
+            nrm = nrm.detach()
+        sec, index, rdir = reflect_fn(rays_chunk, r[f"x_surface_{sel}"], nrm, mask, only_in)
         if sec.shape[0] > 0:
             traced = True
             r2 = render_rays_chunk_recursively(models, embeddings, hp, sec.contiguous(), mask, recur_level + 1,
@@ -124,7 +170,7 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
             for typ in ("coarse", "fine"):                               # train.py:263-311
                 if f"rgb_{typ}" in r and f"rgb_{typ}" in r2:
                     r[f"rgb_{typ}_direct"] = r[f"rgb_{typ}"]
-                    r[f"rgb_{typ}"], refl = _blend(r[f"rgb_{typ}"], r2[f"rgb_{typ}"], index, mask, is_eval)
+                    r[f"rgb_{typ}"], refl = blend_fn(r[f"rgb_{typ}"], r2[f"rgb_{typ}"], index, mask, is_eval)
                     if is_eval:
                         r[f"rgb_{typ}_reflect"] = refl
             if is_eval:                                                  # train.py:312-324

@@ -12,11 +12,15 @@ Differences from the reference that do not change values:
   * random draws can be injected (`_perturb_rand`, `_noise_coarse`, `_noise_fine`, `_u`) so that
     tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator;
   * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
-Outputs live on rays.device and carry no autograd history.
+Outputs live on rays.device.  When autograd is enabled and a model parameter (or `rays`) requires
+grad, the field evaluation and the compositing run through `autograd.FieldFn` / `CompositeFn`,
+whose backward passes are HIP kernels too; everything else is unchanged.  The gradient through
+the normalised density gradient (`normal_*` keys, a second-order term) is not propagated.
 """
 import torch
 
 from . import _lib
+from .autograd import CompositeFn, EmbedFn, FieldFn
 from .mirror_nerf import field_forward
 
 __all__ = ["render_rays", "sample_pdf"]
@@ -81,8 +85,12 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         raise NotImplementedError("the HIP field kernel is built for Embedding(10)/Embedding(4)")
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
 
+    train = torch.is_grad_enabled() and (rays.requires_grad or any(
+        q.requires_grad for mdl in models.values() for q in mdl.parameters()))
+
     # rendering.py:275-277 -- view encoding once per ray
-    dir_emb = _embed(kwargs.get("view_dir", rays[:, 3:6]), n_fd)
+    view = kwargs.get("view_dir", rays[:, 3:6])
+    dir_emb = EmbedFn.apply(view, n_fd) if (train and view.requires_grad) else _embed(view.detach(), n_fd)
 
     # rendering.py:283-300 -- coarse depths
     z_steps = kwargs.get("_z_steps")
@@ -105,6 +113,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         S = z.shape[1]
         sigma_only = typ == "coarse" and test_time and has_fine          # rendering.py:139
         B = N * S
+        if train and not sigma_only and N:
+            return inference_train(model, typ, z, noise_key)
         if N:
             o = field_forward(model, B, rays=rays, z_vals=z, spr=S, dir_emb=dir_emb, dir_stride=dir_emb.shape[1],
                               sigma_only=sigma_only, grad_normal=compute_normal and not sigma_only)
@@ -151,6 +161,34 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             results[f"normal_dif_{typ}"] = nd
         results[f"_x_surface_{typ}"] = xs
 
+    def inference_train(model, typ, z, noise_key):
+        """The same pass with autograd-aware kernels (training)."""
+        S = z.shape[1]
+        sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
+                                                    *list(model.parameters()))
+        noise = kwargs.get(noise_key)
+        if noise is not None:
+            noise = (noise.float() * noise_std).contiguous()
+        elif noise_std != 0:
+            noise = torch.randn(N, S, device=dev) * noise_std
+        nrm = normal if compute_normal else None
+        weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
+            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back))
+        results[f"weights_{typ}"] = weights
+        results[f"opacity_{typ}"] = opacity
+        results[f"z_vals_{typ}"] = z
+        results[f"rgb_{typ}"] = rgb_map
+        results[f"depth_{typ}"] = depth
+        results[f"mirror_mask_{typ}"] = mask
+        if compute_normal:
+            results[f"normal_{typ}"] = normal.view(N, S, 3)
+            results[f"surface_normal_grad_{typ}"] = sng
+        results[f"pred_normal_{typ}"] = pn.view(N, S, 3)
+        results[f"surface_normal_{typ}"] = sn
+        if compute_normal:
+            results[f"normal_dif_{typ}"] = nd
+        results[f"_x_surface_{typ}"] = xs
+
     inference(models["coarse"], "coarse", z_vals, "_noise_coarse")
 
     if N_importance > 0:
@@ -158,7 +196,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             u = kwargs.get("_u")
             if u is None and perturb == 0:
                 u = kwargs.get("_u_det")
-            return sample_pdf(z_vals, results["weights_coarse"], N_importance, det=(perturb == 0), u=u)
+            # weights are detached here, as in the reference (rendering.py:335, 353)
+            return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=u)
 
         if kwargs.get("only_one_field", False):                           # rendering.py:328-348
             if kwargs.get("current_epoch", 0) > kwargs.get("only_one_field_fine_epoch", 2):

@@ -305,6 +305,58 @@ def eval_case(name, n_rays, tweaks, max_level, chunk=32768, rough=False, n_imp=6
     save(name, meta, inputs, ref, keep_per_sample=False)
 
 
+# ---------------------------------------------------------------- G9
+from make_golden_loss import first_order_loss, grad_summary  # noqa: E402
+
+
+def grad_case(name, n_rays):
+    import train as ref_train
+
+    hp = R.get_hparams(predict_normal=True, predict_mirror_mask=True, trace_secondary_rays=True,
+                       N_samples=64, N_importance=64, perturb=0, noise_std=0, only_trace_rays_in_mirrors=True,
+                       max_recursive_level=1)
+    torch.manual_seed(0)
+    system = ref_train.NeRFSystem(hp)
+    _, sds = ref_models(0, 2, W.OPAQUE)
+    system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
+    system.nerf_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
+    system.train_dataset = types.SimpleNamespace(white_back=False)
+    rays = pick_rays(n_rays, 9)
+    rs = np.random.RandomState(99)
+    gt = (rs.uniform(size=n_rays) < 0.3).astype(np.float32)
+    target = rs.uniform(size=(n_rays, 3)).astype(np.float32)
+    extra = {"mirror_mask": torch.from_numpy(gt.copy()), "is_eval": False, "train_geometry_stage": False}
+    res = system(torch.from_numpy(rays), extra)
+    loss = first_order_loss(res, torch.from_numpy(target), torch.from_numpy(gt))
+    loss.backward()
+    outs = {"loss": np.array(loss.item())}
+    for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        for pn_, p_ in mod.named_parameters():
+            outs[f"grad__{mname}__{pn_}"] = grad_summary(p_.grad, p_)
+    # the reference's own noise floor: the same step in float64
+    g32 = {f"{mn}.{pn_}": (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
+           for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)) for pn_, p_ in mod.named_parameters()}
+    system.double()
+    system.zero_grad()
+    extra64 = {"mirror_mask": torch.from_numpy(gt.copy()).double(), "is_eval": False, "train_geometry_stage": False}
+    res64 = system(torch.from_numpy(rays).double(), extra64)
+    first_order_loss(res64, torch.from_numpy(target).double(), torch.from_numpy(gt).double()).backward()
+    floor = 0.0
+    for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        for pn_, p_ in mod.named_parameters():
+            g64 = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            a = g32[f"{mn}.{pn_}"].double()
+            if g64.abs().max() > 0:
+                floor = max(floor, float((a - g64).abs().max() / g64.abs().max()))
+    print(f"  reference fp32-vs-fp64 gradient floor (relative to each tensor's max): {floor:.2e}")
+    hp_o = dict(N_samples=64, use_disp=False, perturb=0, noise_std=0, N_importance=64, chunk=hp.chunk,
+                trace_secondary_rays=True, only_one_field=False, max_recursive_level=1,
+                only_trace_rays_in_mirrors=True, for_vis=False)
+    print(f"  {name}: loss {loss.item():.6f}, |grad| coarse L1 weight {outs['grad__coarse__xyz_encoding_1.0.weight'][1]:.3e}")
+    meta = dict(seed=0, n_models=2, tweaks=W.OPAQUE, checksum=[W.checksum(s) for s in sds], hp=hp_o, grad_floor=floor)
+    save(name, meta, {"rays": rays, "gt_mask": gt, "target": target}, outs)
+
+
 def main():
     only = sys.argv[1:]
 
@@ -348,6 +400,8 @@ def main():
         eval_case("g7_eval_l2_chunk32", 96, W.STRADDLE, 2, chunk=32)
     if want("g8"):
         eval_case("g8_rough_allmirror", 48, W.ALL_MIRROR, 1, rough=True)
+    if want("g9"):
+        grad_case("g9_train_grads", 64)
 
 
 if __name__ == "__main__":

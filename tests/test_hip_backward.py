@@ -120,3 +120,45 @@ def test_field_backward_ray_mode_accumulates_over_samples():
     assert _rel(de2.grad, de1.grad) <= 2e-3
     for (n, p) in zip([n for n, _ in m.named_parameters()], params):
         assert _rel(p.grad, w[n].grad) <= 2e-3, n
+
+
+def test_train_step_gradients_golden():
+    """G9: gradients of a first-order loss through the whole train-semantics render (coarse + fine
+    pass, GT mirror mask, compacted reflected rays, blend) against the reference's autograd,
+    captured by tests/golden/make_golden.py.  Tolerance: 1e-3 of each tensor's largest gradient."""
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from tests.golden import fixtures as FX
+    from tests.golden.make_golden_loss import first_order_loss, grad_summary
+    fx = FX.Fixture("g9_train_grads")
+    sds = fx.state_dicts()
+    hp = dict(fx.meta["hp"])
+    hp.update(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf")
+    system = M.NeRFSystem(SimpleNamespace(**hp))
+    system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
+    system.nerf_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
+    system.to(DEV)
+    t = lambda k: torch.from_numpy(fx.inputs[k]).to(DEV)  # noqa: E731
+    res = system(t("rays"), {"mirror_mask": t("gt_mask"), "is_eval": False, "train_geometry_stage": False})
+    loss = first_order_loss(res, t("target"), t("gt_mask"))
+    assert abs(loss.item() - float(fx.outputs["loss"])) <= 1e-5
+    loss.backward()
+    worst = 0.0
+    report = []
+    for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        for pn_, p_ in mod.named_parameters():
+            want = fx.outputs[f"grad__{mname}__{pn_}"]
+            got = grad_summary(p_.grad.cpu() if p_.grad is not None else None, p_.detach().cpu())
+            scale = max(want[2], 1e-12)
+            err = np.max(np.abs(got[3:] - want[3:])) / scale
+            worst = max(worst, err)
+            nerr = abs(got[1] - want[1]) / max(want[1], 1e-12)
+            report.append((err, nerr, mname, pn_))
+    report.sort(reverse=True)
+    print("G9 relative gradient errors (entry-wise / norm), worst first:")
+    for err, nerr, mname, pn_ in report[:8]:
+        print(f"  {err:.2e} {nerr:.2e} {mname} {pn_}")
+    floor = fx.meta.get("grad_floor", 0.0)
+    tol = max(1e-3, 4 * floor)
+    bad = [r for r in report if r[0] > tol or r[1] > tol]
+    assert not bad, bad[:4]
