@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement")
     a = ap.parse_args()
 
     import torch
@@ -148,6 +149,7 @@ def main():
         dt = float(t.item())
 
     n_mirror = int((out["mirror_mask_fine"] != 0).sum().item())
+    out = None
     rays_per_frame = H * W + (H * W if n_mirror > 0 else 0)      # eval.py:159: level 0 traces every ray
     evals_per_ray = N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)
     total_rays = rays_per_frame * a.steps * world
@@ -161,6 +163,11 @@ def main():
     achieved = flop_full / (ms_full * 1e-3) / 1e12 if ms_full > 0 else 0.0
     ms_sig = sum(t for _, t in sig)
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
+
+    train = None
+    if not a.no_train:
+        from mirror_nerf_amd import training
+        train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
 
     if rank == 0:
         res = {
@@ -185,6 +192,8 @@ def main():
                          "sigma_only_kernel_tflops": sig_tf,
                          "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
         }
+        if train is not None:
+            res["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, a.cpu_rays)
         print(json.dumps(res))

@@ -138,6 +138,7 @@ struct DwSource {
     const float* part;   // [splits][N][K]
     int K;               // row length of the partial
     int N;               // rows of the partial (128/256, or 3 for the small kernel)
+    int splits;          // sample-range splits this partial (and the layer's bias partial) was computed with
 };
 struct DwLayer {
     DwSource src[2];     // columns [0, split_col) from src[0], the rest from src[1]
@@ -150,7 +151,6 @@ struct DwLayer {
 };
 struct DwFinishArgs {
     DwLayer layer[16];
-    int splits;
     int encpos[64];      // logical encoding column -> position in the saved pair-ordered encoding
 };
 
@@ -166,13 +166,13 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
         int col = first ? c : c - ly.split_col;
         if (first && ly.kind0 == 1) col = F.encpos[c];
         float v = 0.f;
-        for (int sp = 0; sp < F.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];
+        for (int sp = 0; sp < s.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];
         ly.d_w[e] = v;
     } else if (e < nw + ly.out_f) {
         const int n = e - nw;
         const int NB = ly.src[0].N;
         float v = 0.f;
-        for (int sp = 0; sp < F.splits; ++sp) v += ly.bpart[(long long)sp * NB + n];
+        for (int sp = 0; sp < ly.src[0].splits; ++sp) v += ly.bpart[(long long)sp * NB + n];
         ly.d_b[n] = v;
     }
 }
@@ -183,16 +183,24 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
 
 namespace mnrf {
 
-int dw_splits(long long B) {
-    long long s = (B + 4095) / 4096;
-    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+// Split counts: enough workgroups to fill 256 CUs even for a 1024-ray training batch.
+int dw_splits(long long B) {          // MFMA GEMMs: >= 512 samples per workgroup, <= 128 splits
+    long long s = (B + 511) / 512;
+    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+}
+int dw_small_splits(long long B) {    // 1-/3-row Linears: HBM-bound streaming, 128 samples per workgroup
+    long long s = (B + 127) / 128;
+    return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
 }
 
 // floats of partial results per split (see the job list in launch_dw)
-constexpr long long DW_PER_SPLIT = 256LL * 64 * 2 + 256LL * 256 * 8 + 128LL * 256 * 3 + 128LL * 32 + 3LL * 256 + 3LL * 128 * 3 +
-                                   /* bias partials */ 256LL * 9 + 128LL * 3 + 3LL * 4;
+constexpr long long DW_PER_SPLIT = 256LL * 64 * 2 + 256LL * 256 * 8 + 128LL * 256 * 3 + 128LL * 32 +
+                                   /* bias partials */ 256LL * 9 + 128LL * 3;
+constexpr long long DW_PER_SMALL_SPLIT = 3LL * 256 + 3LL * 128 * 3 + 3LL * 4;
 
-long long dw_workspace_floats(long long B) { return (long long)dw_splits(B) * DW_PER_SPLIT; }
+long long dw_workspace_floats(long long B) {
+    return (long long)dw_splits(B) * DW_PER_SPLIT + (long long)dw_small_splits(B) * DW_PER_SMALL_SPLIT;
+}
 
 template <int TK>
 static void gemm(const float* A, int lda, int N, const float* X, int ldx, int K, long long B, int splits, float* C, float* bp,
@@ -204,12 +212,13 @@ static void gemm(const float* A, int lda, int N, const float* X, int ldx, int K,
 int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
               hipStream_t s) {
     const int splits = dw_splits(B);
+    const int ssplits = dw_small_splits(B);
     float* p = ws;
     auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
+    auto take_small = [&](long long n) { float* r = p; p += n * ssplits; return r; };
     auto X = [&](int sec) { return save_x + (long long)sec * B; };
     auto Y = [&](int sec) { return dY + (long long)sec * B; };
     DwFinishArgs F;
-    F.splits = splits;
     for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
     for (int gq = 0; gq < 4; ++gq)
         for (int t = 0; t < 16; ++t) {
@@ -227,17 +236,17 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         if (i == 0) {
             float* c = take(256 * 64);
             gemm<64>(Y(DY_L), 256, 256, X(SEC_ENC), 64, 64, B, splits, c, bp, s);
-            layer(0, 256, 63, DwSource{c, 64, 256}, DwSource{c, 64, 256}, 63, 1, bp);
+            layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1, bp);
         } else if (i == 4) {
             float* ce = take(256 * 64);
             float* ch = take(256 * 256);
             gemm<64>(Y(DY_L + 256 * 4), 256, 256, X(SEC_ENC), 64, 64, B, splits, ce, bp, s);
             gemm<128>(Y(DY_L + 256 * 4), 256, 256, X(SEC_H + 256 * 3), 256, 256, B, splits, ch, nullptr, s);
-            layer(4, 256, 319, DwSource{ce, 64, 256}, DwSource{ch, 256, 256}, 63, 1, bp);
+            layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1, bp);
         } else {
             float* c = take(256 * 256);
             gemm<128>(Y(DY_L + 256 * i), 256, 256, X(SEC_H + 256 * (i - 1)), 256, 256, B, splits, c, bp, s);
-            layer(i, 256, 256, DwSource{c, 256, 256}, DwSource{c, 256, 256}, 256, 0, bp);
+            layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
         }
     }
     const float* h8 = X(SEC_H + 256 * 7);
@@ -245,7 +254,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* bp = take(256);
         float* c = take(256 * 256);
         gemm<128>(Y(DY_FIN), 256, 256, h8, 256, 256, B, splits, c, bp, s);
-        layer(8, 256, 256, DwSource{c, 256, 256}, DwSource{c, 256, 256}, 256, 0, bp);
+        layer(8, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
     }
     {   // dir_encoding.0 (L = 9): columns [0,256) from final, [256,283) from the view encoding
         float* bp = take(128);
@@ -253,13 +262,13 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* cd = take(128 * 32);
         gemm<128>(Y(DY_DIR), 128, 128, X(SEC_FIN), 256, 256, B, splits, cf, bp, s);
         gemm<32>(Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, B, splits, cd, nullptr, s);
-        layer(9, 128, 283, DwSource{cf, 256, 128}, DwSource{cd, 32, 128}, 256, 0, bp);
+        layer(9, 128, 283, DwSource{cf, 256, 128, splits}, DwSource{cd, 32, 128, splits}, 256, 0, bp);
     }
     auto small = [&](int L, const float* A, int lda, int n_true, const float* Xp, int K) {
-        float* bp = take(3);
-        float* c = take(3 * K);
-        hipLaunchKernelGGL(dw_small_kernel, dim3(splits), dim3(256), 0, s, A, lda, n_true, Xp, K, K, B, splits, c, bp);
-        layer(L, n_true, K, DwSource{c, K, 3}, DwSource{c, K, 3}, K, 0, bp);
+        float* bp = take_small(3);
+        float* c = take_small(3 * K);
+        hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits), dim3(256), 0, s, A, lda, n_true, Xp, K, K, B, ssplits, c, bp);
+        layer(L, n_true, K, DwSource{c, K, 3, ssplits}, DwSource{c, K, 3, ssplits}, K, 0, bp);
     };
     small(10, g_sigma, 1, 1, h8, 256);                          // sigma
     small(11, Y(DY_RGB), 16, 3, X(SEC_HD), 128);                // rgb.0
@@ -267,14 +276,14 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* bp = take(128);
         float* c = take(128 * 256);
         gemm<128>(Y(DY_NRM1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
-        layer(12, 128, 256, DwSource{c, 256, 128}, DwSource{c, 256, 128}, 256, 0, bp);
+        layer(12, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
     }
     small(13, Y(DY_NRM2), 16, 3, X(SEC_HN), 128);               // normal_net.1
     {   // is_mirror_net.0 (L = 14)
         float* bp = take(128);
         float* c = take(128 * 256);
         gemm<128>(Y(DY_MIR1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
-        layer(14, 128, 256, DwSource{c, 256, 128}, DwSource{c, 256, 128}, 256, 0, bp);
+        layer(14, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
     }
     small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
     if (p - ws > dw_workspace_floats(B)) return -1;

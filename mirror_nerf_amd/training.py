@@ -1,0 +1,81 @@
+"""A minimal training step around NeRFSystem: forward (train semantics), loss, backward through the
+HIP kernels, one flat gradient all-reduce, Adam.  The Lightning loop of the reference
+(train.py:386-458) is out of scope; this is the arithmetic a `training_step` performs, used by
+bench.py and scripts/bench_train.py with synthetic batches (1024 rays, perturb = noise_std = 1,
+train.py defaults)."""
+import time
+from types import SimpleNamespace
+
+import torch
+
+from . import dist as D
+from .recursion import NeRFSystem
+
+
+def default_hparams(**over):
+    hp = dict(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf",
+              N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=1.0, chunk=32768,
+              trace_secondary_rays=True, only_one_field=False, max_recursive_level=1,
+              only_trace_rays_in_mirrors=True, for_vis=False)
+    hp.update(over)
+    return SimpleNamespace(**hp)
+
+
+def color_mask_loss(res, target, gt_mask):
+    """ColorLoss + MirrorMaskLoss of losses.py (7-51, 175-198) in their default form."""
+    loss = ((res["rgb_coarse"] - target) ** 2).mean()
+    if "rgb_fine" in res:
+        loss = loss + ((res["rgb_fine"] - target) ** 2).mean()
+    key = "mirror_mask_fine" if "mirror_mask_fine" in res else "mirror_mask_coarse"
+    m = res[key].clamp(1e-5, 1 - 1e-5)
+    return loss + 0.1 * torch.nn.functional.binary_cross_entropy(m, gt_mask)
+
+
+def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss):
+    res = system(rays, {"mirror_mask": gt_mask, "is_eval": False, "train_geometry_stage": False})
+    loss = loss_fn(res, target, gt_mask)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    D.allreduce_gradients([p for p in system.parameters()])   # RCCL over xGMI when world_size > 1
+    optimizer.step()
+    return loss
+
+
+def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0):
+    """Returns dict(rays_per_s, ms_per_step, reflected_per_step, loss) for this process group."""
+    rank, world = D.world()
+    torch.manual_seed(seed)
+    system = NeRFSystem(default_hparams()).to(dev)
+    with torch.no_grad():   # opaque density so that surfaces and reflections exist
+        for m in (system.nerf_coarse, system.nerf_fine):
+            m.sigma.weight.mul_(20.0)
+            m.sigma.bias.fill_(1.0)
+    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+
+    def one():
+        idx = torch.randint(0, all_rays.shape[0], (batch,), device=dev, generator=g)
+        rays = all_rays[idx].contiguous()
+        target = torch.rand(batch, 3, device=dev, generator=g)
+        gt = (torch.rand(batch, device=dev, generator=g) < 0.25).float()
+        return train_step(system, opt, rays, target, gt), float(gt.sum().item())
+
+    for _ in range(warmup):
+        one()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    refl = 0.0
+    for _ in range(steps):
+        loss, n = one()
+        refl += n
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)",
+            "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
+            "samples_per_ray": 64 + 128, "steps": steps, "loss": float(loss.item()),
+            "note": "gradient through the normalised density gradient (second-order normal loss) not propagated"}

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Training-step throughput (BASELINE config 3 shape), one JSON line on rank 0.
+Single GPU: python scripts/bench_train.py;  N GPUs: python -m torch.distributed.run --nproc-per-node N ..."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mirror_nerf_amd import training  # noqa: E402
+from oracle import mirror_nerf_oracle as O  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--batch", type=int, default=1024)
+a = ap.parse_args()
+world = int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+rays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
+r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch)
+if int(os.environ.get("RANK", "0")) == 0:
+    r["n_gpus"] = world
+    print(json.dumps(r))
+if world > 1:
+    dist.destroy_process_group()
