@@ -155,13 +155,13 @@ int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, i
                              const float* rays, const float* z_vals, int spr, const float* dir_emb,
                              int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                              float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                             float* save_inv, void* stream);
+                             float* save_inv, float* save_invj, void* stream);
 
 /* Backward of the field MLP: given dL/d{sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B)},
  * writes the gradient of every parameter (d_params: HOST array of MNRF_N_PARAMS device pointers,
  * state_dict order, overwritten), dL/dxyz (B,3) and dL/d(view encoding) (B,32 padded) when non-null.
  * The gradient flowing into `normal` (the normalised density gradient: a second-order term) is
- * not propagated by this entry point.
+ * handled by mnrf_field_backward2.
  * Autograd equivalent: loss.backward() through models/mirror_nerf.py:101-212. */
 int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                         const float* rays, const float* z_vals, int spr,
@@ -170,6 +170,17 @@ int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_
                         const float* is_mirror, const float* save_x, const uint64_t* save_mask,
                         const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
                         float* d_dir, void* stream);
+
+/* Second-order term of the field backward: the gradient that reaches the trunk weights, sigma.weight
+ * and xyz through `normal = l2n(-d sigma/d xyz)` (utils/func.py:10-25 with create_graph=True).
+ * g_normal (B,3) = dL/d normal; normal = the forward output; save_invj (B) from the training forward.
+ * ADDS to d_params (trunk weights and sigma.weight only) and to d_xyz (when non-null): call it after
+ * mnrf_field_backward.  workspace: mnrf_train_workspace2_floats(B) floats. */
+int64_t mnrf_train_workspace2_floats(int64_t B);
+int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                         const float* rays, const float* z_vals, int spr, const float* g_normal,
+                         const float* normal, const float* save_invj, const uint64_t* save_mask,
+                         float* workspace, float* const* d_params, float* d_xyz, void* stream);
 
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,

@@ -37,6 +37,7 @@ class CompositeFn(torch.autograd.Function):
                 p(xs), _lib.stream()), "mnrf_composite")
         ctx.save_for_backward(rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, depth)
         ctx.white_back = bool(white_back)
+        ctx.set_materialize_grads(False)
         ctx.present = (rgb_map is not None, depth is not None, mask is not None, sn is not None, sng is not None,
                        nd is not None, xs is not None)
         outs = (weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs)
@@ -83,8 +84,8 @@ class FieldFn(torch.autograd.Function):
     Positions come from `xyz` (B,>=3 columns, row stride = its row length) or from rays (N,8) and
     z_vals (N,spr).  `dir_emb`: (B/spr, 27) view encoding.  `params`: the module's 32 parameters in
     state_dict order (so that autograd routes their gradients).
-    `normal` (the normalised density gradient) is returned non-differentiable: its backward is a
-    second-order term that this round does not build."""
+    The gradient arriving at `normal` (the normalised density gradient) is a second-order term:
+    it is propagated by mnrf_field_backward2 (tangent pass + weight-gradient GEMMs)."""
 
     @staticmethod
     def forward(ctx, module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params):
@@ -100,18 +101,20 @@ class FieldFn(torch.autograd.Function):
         save_x = f(max(1, L.mnrf_train_save_floats(B)))
         save_mask = torch.empty(max(1, L.mnrf_train_mask_words(B)), dtype=torch.int64, device=dev)
         save_inv = f(max(1, B))
+        save_invj = f(max(1, B)) if want_normal else None
         p = _lib.ptr
         xs = xyz.shape[1] if xyz is not None else 3
         if B:
             _lib.check(L.mnrf_field_forward_train(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
-                p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), _lib.stream()), "mnrf_field_forward_train")
+                p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj), _lib.stream()), "mnrf_field_forward_train")
         ctx.module, ctx.spr, ctx.B = module, spr, B
-        ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv)
+        ctx.set_materialize_grads(False)   # an unused `normal` must arrive as None, not as zeros: it gates the second-order pass
+        ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj)
         ctx.param_shapes = [tuple(t.shape) for t in params]
         if normal is None:
             normal = f(0, 3)
-        ctx.mark_non_differentiable(normal)
+            ctx.mark_non_differentiable(normal)
         return sigma, rgb, pn, mir, normal
 
     @staticmethod
@@ -119,7 +122,7 @@ class FieldFn(torch.autograd.Function):
         import ctypes
         from .weights import packed_of
         L = _lib.lib()
-        xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv = ctx.saved_tensors
+        xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj = ctx.saved_tensors
         B, spr = ctx.B, ctx.spr
         packed = packed_of(ctx.module)
         dev = packed.device
@@ -140,6 +143,11 @@ class FieldFn(torch.autograd.Function):
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), _lib.stream()),
                 "mnrf_field_backward")
+            if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
+                ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
+                _lib.check(L.mnrf_field_backward2(
+                    p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
+                    p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz), _lib.stream()), "mnrf_field_backward2")
         else:
             for t in d_params:
                 t.zero_()

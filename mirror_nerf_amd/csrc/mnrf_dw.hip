@@ -150,7 +150,8 @@ struct DwLayer {
     float* d_b;
 };
 struct DwFinishArgs {
-    DwLayer layer[16];
+    DwLayer layer[16];   // out_f == 0: layer not touched by this pass
+    int accumulate;      // 0: overwrite the gradient tensors, 1: add to them (second-order pass)
     int encpos[64];      // logical encoding column -> position in the saved pair-ordered encoding
 };
 
@@ -167,15 +168,16 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
         if (first && ly.kind0 == 1) col = F.encpos[c];
         float v = 0.f;
         for (int sp = 0; sp < s.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];
-        ly.d_w[e] = v;
-    } else if (e < nw + ly.out_f) {
+        ly.d_w[e] = F.accumulate ? ly.d_w[e] + v : v;
+    } else if (e < nw + ly.out_f && ly.bpart) {
         const int n = e - nw;
         const int NB = ly.src[0].N;
         float v = 0.f;
         for (int sp = 0; sp < ly.src[0].splits; ++sp) v += ly.bpart[(long long)sp * NB + n];
-        ly.d_b[n] = v;
+        ly.d_b[n] = F.accumulate ? ly.d_b[n] + v : v;
     }
 }
+
 
 }  // namespace mnrf
 
@@ -219,6 +221,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     auto X = [&](int sec) { return save_x + (long long)sec * B; };
     auto Y = [&](int sec) { return dY + (long long)sec * B; };
     DwFinishArgs F;
+    F.accumulate = 0;
     for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
     for (int gq = 0; gq < 4; ++gq)
         for (int t = 0; t < 16; ++t) {
@@ -288,6 +291,66 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
     if (p - ws > dw_workspace_floats(B)) return -1;
     // largest layer: 256 x 319 + 256 elements
+    hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
+    return 0;
+}
+
+
+// ---- second-order pass: dW_i += b_i^T a'_{i-1} for the 8 trunk layers, dw_sigma += sum a'_8
+constexpr long long DW2_PER_SPLIT = 256LL * 64 * 2 + 256LL * 256 * 7;
+
+long long dw2_workspace_floats(long long B) {
+    return (long long)dw_splits(B) * DW2_PER_SPLIT + (long long)dw_small_splits(B) * (3LL * 256 + 3) + 16;
+}
+
+int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, hipStream_t s) {
+    const int splits = dw_splits(B);
+    const int ssplits = dw_small_splits(B);
+    float* p = ws;
+    auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
+    auto sec = [&](int off) { return so + (long long)off * B; };
+    DwFinishArgs F;
+    F.accumulate = 1;
+    for (int L = 0; L < 16; ++L) { F.layer[L].out_f = 0; F.layer[L].in_f = 0; F.layer[L].bpart = nullptr; }
+    for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
+    for (int gq = 0; gq < 4; ++gq)
+        for (int t = 0; t < 16; ++t) {
+            const int c = enc_col(t, gq);
+            if (c >= 0) F.encpos[c] = 16 * (t >> 2) + 4 * gq + (t & 3);
+        }
+    auto layer = [&](int L, int out_f, int in_f, DwSource s0, DwSource s1, int split_col, int kind0) {
+        DwLayer& ly = F.layer[L];
+        ly.src[0] = s0; ly.src[1] = s1; ly.split_col = split_col; ly.kind0 = kind0; ly.bpart = nullptr;
+        ly.out_f = out_f; ly.in_f = in_f; ly.d_w = d_params[2 * L]; ly.d_b = d_params[2 * L + 1];
+    };
+    for (int i = 0; i < 8; ++i) {
+        const float* b = sec(BS_L + 256 * i);
+        if (i == 0) {
+            float* c = take(256 * 64);
+            gemm<64>(b, 256, 256, sec(TA_ENC), 64, 64, B, splits, c, nullptr, s);
+            layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1);
+        } else if (i == 4) {
+            float* ce = take(256 * 64);
+            float* ch = take(256 * 256);
+            gemm<64>(b, 256, 256, sec(TA_ENC), 64, 64, B, splits, ce, nullptr, s);
+            gemm<128>(b, 256, 256, sec(TA_H + 256 * 3), 256, 256, B, splits, ch, nullptr, s);
+            layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1);
+        } else {
+            float* c = take(256 * 256);
+            gemm<128>(b, 256, 256, sec(TA_H + 256 * (i - 1)), 256, 256, B, splits, c, nullptr, s);
+            layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0);
+        }
+    }
+    {   // sigma.weight: column sums of the masked tangent of h8 (A = a single 1.0 read with stride 0)
+        float* one = p; p += 16;
+        float* bp = p; p += 3LL * ssplits;
+        float* c = p; p += 3LL * 256 * ssplits;
+        static const float h1 = 1.f;
+        (void)hipMemcpyAsync(one, &h1, sizeof(float), hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits), dim3(256), 0, s, one, 0, 1, sec(TA_H + 256 * 7), 256, 256, B, ssplits, c, bp);
+        layer(10, 1, 256, DwSource{c, 256, 3, ssplits}, DwSource{c, 256, 3, ssplits}, 256, 0);
+    }
+    if (p - ws > dw2_workspace_floats(B)) return -1;
     hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
     return 0;
 }

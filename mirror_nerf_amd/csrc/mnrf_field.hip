@@ -45,6 +45,7 @@ struct FieldArgs {
     float* save_x;                 // [SAVE_FLOATS sections][B][width]   (null = inference)
     unsigned long long* save_mask; // [tiles][N_MASKS][S][256]
     float* save_inv;               // [B] 1/|v| of normal_net (negative when the eps clamp was active)
+    float* save_invj;              // [B] 1/|d sigma/dx| of the density-gradient normal, same convention
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,7 +258,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
                                         const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                         int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                         float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                                        float* save_inv, void* stream) {
+                                        float* save_inv, float* save_invj, void* stream) {
     if (!packed || !save_x || !save_mask || !save_inv) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: negative sample count");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: need xyz or rays+z_vals");
@@ -266,7 +267,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: the four head outputs are required (the backward reads them)");
     FieldArgs A{packed, MNRF_GRAD_NORMAL, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
-                save_x, (unsigned long long*)save_mask, save_inv};
+                save_x, (unsigned long long*)save_mask, save_inv, save_invj};
     // always the s2 tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map
     if (s2::launch(A, false, true, (hipStream_t)stream) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: too many samples for one launch");
@@ -300,4 +301,27 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
     if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: workspace accounting error");
     return mnrf_check_launch("mnrf_field_backward (weight gradients)");
+}
+
+extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_FLOATS * B + dw2_workspace_floats(B); }
+
+extern "C" int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                    const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                    const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                    float* workspace, float* const* d_params, float* d_xyz, void* stream) {
+    if (!packed || !g_normal || !normal || !save_invj || !save_mask || !workspace || !d_params)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: negative sample count");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: need xyz or rays+z_vals");
+    float* so = workspace;
+    float* ws = workspace + (int64_t)SO_FLOATS * B;
+    s2::FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
+                        (const unsigned long long*)save_mask, so, d_xyz};
+    hipStream_t s = (hipStream_t)stream;
+    if (s2::launch_bwd2(A, s) != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: too many samples for one launch");
+    int rc = mnrf_check_launch("mnrf_field_backward2 (tangent pass)");
+    if (rc != MNRF_OK) return rc;
+    if (launch_dw2(so, (long long)B, ws, d_params, s) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: workspace accounting error");
+    return mnrf_check_launch("mnrf_field_backward2 (weight gradients)");
 }

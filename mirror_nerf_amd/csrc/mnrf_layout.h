@@ -117,6 +117,13 @@ constexpr int DY_RGB = 2688;          // 16 (3 used)
 constexpr int DY_NRM2 = 2704;         // 16 (3 used)
 constexpr int DY_MIR2 = 2720;         // 16 (1 used)
 constexpr int DY_FLOATS = 2736;       // per sample
+// ---- second-order pass (gradient through the density-gradient normal): tangents and masked
+//      density-gradient signals, [section][sample][width]
+constexpr int TA_ENC = 0;             // 64   tangent of the xyz encoding in direction J^
+constexpr int TA_H = 64;              // 8 x 256  masked tangents of h1..h8
+constexpr int BS_L = 2112;            // 8 x 256  b_i = (dsigma/dh_i) * relu'_i  of layers 1..8
+constexpr int SO_FLOATS = 4160;       // per sample
+constexpr int TRUNK_FWD_TILES = 64 + 3 * 256 + 320 + 3 * 256;   // forward stream prefix L1..L8
 
 static_assert(FWD_TILES % CHUNK_TILES == 0 && FWD_TILES_SIGMA % CHUNK_TILES == 0, "chunking");
 static_assert(BWD_TILES % CHUNK_TILES == 0 && HBWD_TILES % CHUNK_TILES == 0, "chunking");

@@ -14,8 +14,8 @@ Differences from the reference that do not change values:
   * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
 Outputs live on rays.device.  When autograd is enabled and a model parameter (or `rays`) requires
 grad, the field evaluation and the compositing run through `autograd.FieldFn` / `CompositeFn`,
-whose backward passes are HIP kernels too; everything else is unchanged.  The gradient through
-the normalised density gradient (`normal_*` keys, a second-order term) is not propagated.
+whose backward passes are HIP kernels too (including the second-order term that reaches the
+weights through the normalised density gradient, `normal_*` keys); everything else is unchanged.
 """
 import torch
 

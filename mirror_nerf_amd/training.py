@@ -78,4 +78,4 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0)
     return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)",
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
             "samples_per_ray": 64 + 128, "steps": steps, "loss": float(loss.item()),
-            "note": "gradient through the normalised density gradient (second-order normal loss) not propagated"}
+            "note": "colour + mirror-mask loss; the second-order pass (normal losses) only runs when a loss reads normal_*"}

@@ -306,10 +306,11 @@ def eval_case(name, n_rays, tweaks, max_level, chunk=32768, rough=False, n_imp=6
 
 
 # ---------------------------------------------------------------- G9
-from make_golden_loss import first_order_loss, grad_summary  # noqa: E402
+from make_golden_loss import first_order_loss, full_loss, grad_summary  # noqa: E402
 
 
-def grad_case(name, n_rays):
+def grad_case(name, n_rays, loss_fn=None):
+    loss_fn = loss_fn or first_order_loss
     import train as ref_train
 
     hp = R.get_hparams(predict_normal=True, predict_mirror_mask=True, trace_secondary_rays=True,
@@ -327,7 +328,7 @@ def grad_case(name, n_rays):
     target = rs.uniform(size=(n_rays, 3)).astype(np.float32)
     extra = {"mirror_mask": torch.from_numpy(gt.copy()), "is_eval": False, "train_geometry_stage": False}
     res = system(torch.from_numpy(rays), extra)
-    loss = first_order_loss(res, torch.from_numpy(target), torch.from_numpy(gt))
+    loss = loss_fn(res, torch.from_numpy(target), torch.from_numpy(gt))
     loss.backward()
     outs = {"loss": np.array(loss.item())}
     for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
@@ -340,7 +341,7 @@ def grad_case(name, n_rays):
     system.zero_grad()
     extra64 = {"mirror_mask": torch.from_numpy(gt.copy()).double(), "is_eval": False, "train_geometry_stage": False}
     res64 = system(torch.from_numpy(rays).double(), extra64)
-    first_order_loss(res64, torch.from_numpy(target).double(), torch.from_numpy(gt).double()).backward()
+    loss_fn(res64, torch.from_numpy(target).double(), torch.from_numpy(gt).double()).backward()
     floor = 0.0
     for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
         for pn_, p_ in mod.named_parameters():
@@ -353,7 +354,7 @@ def grad_case(name, n_rays):
                 trace_secondary_rays=True, only_one_field=False, max_recursive_level=1,
                 only_trace_rays_in_mirrors=True, for_vis=False)
     print(f"  {name}: loss {loss.item():.6f}, |grad| coarse L1 weight {outs['grad__coarse__xyz_encoding_1.0.weight'][1]:.3e}")
-    meta = dict(seed=0, n_models=2, tweaks=W.OPAQUE, checksum=[W.checksum(s) for s in sds], hp=hp_o, grad_floor=floor)
+    meta = dict(seed=0, n_models=2, tweaks=W.OPAQUE, checksum=[W.checksum(s) for s in sds], hp=hp_o, grad_floor=floor, loss=loss_fn.__name__)
     save(name, meta, {"rays": rays, "gt_mask": gt, "target": target}, outs)
 
 
@@ -402,6 +403,7 @@ def main():
         eval_case("g8_rough_allmirror", 48, W.ALL_MIRROR, 1, rough=True)
     if want("g9"):
         grad_case("g9_train_grads", 64)
+        grad_case("g9_train_grads_full", 64, full_loss)
 
 
 if __name__ == "__main__":

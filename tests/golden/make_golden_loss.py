@@ -16,6 +16,15 @@ def first_order_loss(res, target, gt):
     return L
 
 
+def full_loss(res, target, gt):
+    """first_order_loss + terms on the keys derived from the autograd normal (second-order gradients)."""
+    c = torch.tensor([0.3, -0.5, 0.8], device=target.device)
+    L = first_order_loss(res, target, gt)
+    L = L + 0.05 * res["normal_dif_fine"].mean() + 0.05 * res["normal_dif_coarse"].mean()
+    L = L + 0.02 * (res["surface_normal_grad_fine"] * c).sum(-1).mean()
+    return L
+
+
 def grad_summary(t, like=None):
     if t is None:   # parameter not reached by the loss
         t = torch.zeros_like(like)

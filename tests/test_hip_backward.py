@@ -114,7 +114,7 @@ def test_field_backward_ray_mode_accumulates_over_samples():
     de2 = de.clone().requires_grad_(True)
     params = list(m.parameters())
     got = FieldFn.apply(m, S, None, r2, z, de2, True, *params)
-    assert got[4].shape == (N * S, 3) and not got[4].requires_grad
+    assert got[4].shape == (N * S, 3)
     sum((o * c).sum() for o, c in zip(got[:4], cot)).backward()
     assert _rel(r2.grad[:, :6], r1.grad[:, :6]) <= 2e-3
     assert _rel(de2.grad, de1.grad) <= 2e-3
@@ -122,15 +122,18 @@ def test_field_backward_ray_mode_accumulates_over_samples():
         assert _rel(p.grad, w[n].grad) <= 2e-3, n
 
 
-def test_train_step_gradients_golden():
+@pytest.mark.parametrize("name", ["g9_train_grads", "g9_train_grads_full"])
+def test_train_step_gradients_golden(name):
     """G9: gradients of a first-order loss through the whole train-semantics render (coarse + fine
     pass, GT mirror mask, compacted reflected rays, blend) against the reference's autograd,
     captured by tests/golden/make_golden.py.  Tolerance: 1e-3 of each tensor's largest gradient."""
     from types import SimpleNamespace
     import mirror_nerf_amd as M
     from tests.golden import fixtures as FX
-    from tests.golden.make_golden_loss import first_order_loss, grad_summary
-    fx = FX.Fixture("g9_train_grads")
+    from tests.golden import make_golden_loss as GL
+    from tests.golden.make_golden_loss import grad_summary
+    fx = FX.Fixture(name)
+    first_order_loss = getattr(GL, fx.meta.get("loss", "first_order_loss"))
     sds = fx.state_dicts()
     hp = dict(fx.meta["hp"])
     hp.update(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf")
@@ -141,7 +144,7 @@ def test_train_step_gradients_golden():
     t = lambda k: torch.from_numpy(fx.inputs[k]).to(DEV)  # noqa: E731
     res = system(t("rays"), {"mirror_mask": t("gt_mask"), "is_eval": False, "train_geometry_stage": False})
     loss = first_order_loss(res, t("target"), t("gt_mask"))
-    assert abs(loss.item() - float(fx.outputs["loss"])) <= 1e-5
+    assert abs(loss.item() - float(fx.outputs["loss"])) <= (1e-5 if name == "g9_train_grads" else 2e-3)
     loss.backward()
     worst = 0.0
     report = []
@@ -162,3 +165,32 @@ def test_train_step_gradients_golden():
     tol = max(1e-3, 4 * floor)
     bad = [r for r in report if r[0] > tol or r[1] > tol]
     assert not bad, bad[:4]
+
+
+def test_field_second_order_backward_matches_double_backward():
+    """The gradient that reaches the weights (and xyz) through normal = l2n(-d sigma/d xyz):
+    hand-written tangent pass vs torch's double backward (create_graph=True)."""
+    from mirror_nerf_amd.autograd import FieldFn
+    m, sd = _field_setup(11)
+    torch.manual_seed(3)
+    B = 300
+    xyz = (torch.rand(B, 3, device=DEV) * 4 - 2)
+    de = TR.embed(TR.l2n(torch.randn(B, 3, device=DEV)), 4)
+    cot_n = torch.randn(B, 3, device=DEV)
+    cot_s = torch.randn(B, device=DEV)
+    w = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in sd.items()}
+    x1 = xyz.clone().requires_grad_(True)
+    outs = TR.field(w, x1, de, with_normal=True)
+    ((outs[4] * cot_n).sum() + (outs[0] * cot_s).sum()).backward()
+    x2 = xyz.clone().requires_grad_(True)
+    params = list(m.parameters())
+    got = FieldFn.apply(m, 1, x2, None, None, de, True, *params)
+    # forward normals agree where the gradient is well conditioned
+    assert float((got[4] - outs[4]).abs().median()) <= 1e-5
+    ((got[4] * cot_n).sum() + (got[0] * cot_s).sum()).backward()
+    names = [n for n, _ in m.named_parameters()]
+    report = sorted(((_rel(p.grad, w[n].grad if w[n].grad is not None else torch.zeros_like(p)), n)
+                     for n, p in zip(names, params)), reverse=True)
+    print("second-order: worst relative gradient errors", report[:4])
+    assert report[0][0] <= 5e-3, report[:4]
+    assert _rel(x2.grad, x1.grad) <= 5e-3

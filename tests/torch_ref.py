@@ -16,8 +16,11 @@ def embed(x, n):
     return torch.cat(out, -1)
 
 
-def field(w, xyz, dir_emb):
-    """w: dict name -> tensor (reference parameter names); returns sigma (B), rgb, pred_normal, is_mirror (B)."""
+def field(w, xyz, dir_emb, with_normal=False):
+    """w: dict name -> tensor (reference parameter names); returns sigma (B), rgb, pred_normal, is_mirror (B)
+    [, normal = l2n(-d sigma/d xyz) built with create_graph=True like utils/func.py:10-25]."""
+    if with_normal and not xyz.requires_grad:
+        xyz = xyz.requires_grad_(True)
     enc = embed(xyz, 10)
     h = enc
     for i in range(8):
@@ -32,6 +35,9 @@ def field(w, xyz, dir_emb):
     pn = l2n(hn @ w["normal_net.1.weight"].T + w["normal_net.1.bias"])
     hm = torch.nn.functional.leaky_relu(h @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
     m = torch.sigmoid(hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"])[:, 0]
+    if with_normal:
+        (grad,) = torch.autograd.grad(sigma, xyz, torch.ones_like(sigma), create_graph=True, retain_graph=True)
+        return sigma, rgb, pn, m, l2n(-grad)
     return sigma, rgb, pn, m
 
 
