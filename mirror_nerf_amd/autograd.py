@@ -56,7 +56,9 @@ class CompositeFn(torch.autograd.Function):
         d_rgb = f(N * S, 3) if (need[4] and rgb is not None) else None
         d_m = f(N * S) if (need[5] and is_mirror is not None) else None
         d_pn = f(N * S, 3) if (need[6] and pred_normal is not None) else None
-        d_n = f(N * S, 3) if (need[7] and normal is not None) else None
+        # dL/dnormal is identically zero unless a loss reads surface_normal_grad / normal_dif: returning None
+        # then lets FieldFn skip the second-order pass
+        d_n = f(N * S, 3) if (need[7] and normal is not None and (g_sng is not None or g_nd is not None)) else None
         p = _lib.ptr
         g = [None if t is None else t.contiguous().float() for t in (g_w, g_op, g_rgb, g_depth, g_mask, g_sn, g_sng, g_nd, g_xs)]
         if N:
