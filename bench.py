@@ -106,7 +106,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -129,7 +129,7 @@ def main():
                                    trace_secondary_rays=True, to_cpu=False)
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +143,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -197,7 +197,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, a.cpu_rays)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

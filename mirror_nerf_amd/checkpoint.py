@@ -1,0 +1,43 @@
+"""Checkpoint interchange with the reference (utils/__init__.py:109-136; train.py:56,66;
+eval.py:996-1001): a Lightning `.ckpt` (or a plain dict) whose `state_dict` keys are
+`nerf_coarse.<param>` / `nerf_fine.<param>` loads into our MirrorNeRF modules unchanged, and
+`save_ckpt` writes the same layout back."""
+import torch
+
+
+def extract_model_state_dict(ckpt, model_name="model", prefixes_to_ignore=()):
+    """ckpt: path or an already loaded dict.  Returns {param name: tensor} of `model_name`."""
+    checkpoint = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) else ckpt
+    if "state_dict" in checkpoint:   # pytorch-lightning checkpoint
+        checkpoint = checkpoint["state_dict"]
+    out = {}
+    for k, v in checkpoint.items():
+        if not k.startswith(model_name):
+            continue
+        k = k[len(model_name) + 1:]
+        if any(k.startswith(p) for p in prefixes_to_ignore):
+            continue
+        out[k] = v
+    return out
+
+
+def load_ckpt(model, ckpt, model_name="model", prefixes_to_ignore=()):
+    if not ckpt:
+        return
+    sd = model.state_dict()
+    got = extract_model_state_dict(ckpt, model_name, prefixes_to_ignore)
+    assert len(got) > 0, "[Error] can not find {} in checkpoint".format(model_name)
+    sd.update(got)
+    model.load_state_dict(sd, strict=False)
+
+
+def save_ckpt(path, system, epoch=0, global_step=0):
+    """Writes {"state_dict": {"nerf_coarse.*", "nerf_fine.*"}, "epoch", "global_step"} like Lightning's
+    ModelCheckpoint does for train.NeRFSystem."""
+    sd = {}
+    for name in ("nerf_coarse", "nerf_fine"):
+        m = getattr(system, name, None)
+        if m is not None:
+            for k, v in m.state_dict().items():
+                sd[f"{name}.{k}"] = v.detach().cpu()
+    torch.save({"state_dict": sd, "epoch": epoch, "global_step": global_step}, path)

@@ -8,10 +8,15 @@ appear only (a) optionally, to assemble a frame on rank 0, and (b) in training, 
 of the flat gradient buffer (1 324 304 fp32 = 5.3 MB for the coarse+fine pair; the reference
 gets the same from Lightning DDP, train.py:577-584).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 TILE = 4096
+# MNRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box
+# exercise the RCCL code path that the 8-GPU run uses).
+FORCE = os.environ.get("MNRF_FORCE_COLLECTIVES", "0") == "1"
 
 
 def world():
@@ -68,7 +73,7 @@ def _all_gather_ragged(parts, mine, counts):
 def max_over_ranks(seconds, device):
     """The slowest rank's time (bench.py contract)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (FORCE and dist.is_initialized()):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -80,7 +85,7 @@ def allreduce_gradients(params, average=True):
     inside RCCL uses all 7 xGMI links; a 5.3 MB message is latency-, not bandwidth-bound)."""
     rank, ws = world()
     grads = [p.grad for p in params if p.grad is not None]
-    if ws == 1 or not grads:
+    if (ws == 1 and not (FORCE and dist.is_initialized())) or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

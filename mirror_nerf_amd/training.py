@@ -63,7 +63,7 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0)
 
     for _ in range(warmup):
         one()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -71,7 +71,7 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0)
     for _ in range(steps):
         loss, n = one()
         refl += n
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)

@@ -22,7 +22,7 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-if world > 1:
+if world > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=dev)
 rays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
@@ -30,5 +30,5 @@ r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch)
 if int(os.environ.get("RANK", "0")) == 0:
     r["n_gpus"] = world
     print(json.dumps(r))
-if world > 1:
+if dist.is_initialized():
     dist.destroy_process_group()

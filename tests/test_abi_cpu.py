@@ -20,7 +20,7 @@ def L():
 
 def test_exports_match_header(L):
     text = open(HEADER).read()
-    declared = set(re.findall(r"\b(mnrf_[a-z_]+)\s*\(", text))
+    declared = set(re.findall(r"\b(mnrf_[a-z0-9_]+)\s*\(", text))
     from mirror_nerf_amd import _lib
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
