@@ -182,6 +182,23 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, void* stream);
 
+/* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
+ * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);
+ * log2_per_level_scale, base_resolution, bound: the encoding configuration (mirror_nerf_tcnn.py:36-49);
+ * weights: mnrf_tcnn_weight_floats() floats = [sigma_net.0 (64x32) | sigma_net.1 (16x64) | color_net.0
+ * (64x32, col 31 zero) | color_net.1 (64x64) | color_net.2 (3x64) | normal_net.0 (64x16, col 15 zero) |
+ * normal_net.1 (3x64) | is_mirror_net.0 (32x16, col 15 zero) | its bias (32) | is_mirror_net.2 (1x32) |
+ * its bias (1)], rows padded to a multiple of 4.
+ * Positions/directions: `xyz` rows [x y z dx dy dz] (stride >= 6, or >= 3 with SIGMA_ONLY), or rays+z_vals
+ * with per-ray raw directions `dirs` (null: the ray direction).  sigma is the RAW output h[0] (the ReLU is
+ * applied at compositing, mirror_nerf_tcnn.py:235).  geo_feat: (B,15).  Parity vs tinycudann: unpinned. */
+int mnrf_tcnn_weight_floats(void);
+int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                      int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
+                      const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
+                      const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                      float* is_mirror, float* normal, float* geo_feat, void* stream);
+
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
                        float* rays, void* stream);

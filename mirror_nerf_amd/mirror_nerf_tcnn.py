@@ -1,0 +1,126 @@
+"""MirrorNeRFTcnn with the reference's constructor/forward contract (models/mirror_nerf_tcnn.py:13-276),
+evaluated by the fused HIP hash-grid field kernel (csrc/mnrf_tcnn.hip).
+
+The reference builds the multiresolution hash encoding with tinycudann and the view encoding with a
+CUDA spherical-harmonics extension; here both live inside one kernel, and the hash table is an
+ordinary parameter `encoder.embeddings` of shape (entries, 2) fp32 laid out level after level with
+the sizing of models/gridencoder/grid.py:181-194.  tinycudann's private parameter layout is not
+reproduced, so tcnn checkpoints do not interchange (and parity against tcnn is unpinned);
+the small MLPs keep the reference's names (`sigma_net.N.weight`, `color_net.N.weight`,
+`normal_net.N.weight`, `is_mirror_net.{0,2}.{weight,bias}`).  Forward / inference only this round.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def hashgrid_config(bound=1.0, n_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19):
+    per_level_scale = np.exp2(np.log2(2048 * bound / n_levels) / (n_levels - 1))   # mirror_nerf_tcnn.py:38
+    max_params = 2 ** log2_hashmap_size
+    offsets, off = [], 0
+    for i in range(n_levels):                                                       # grid.py:181-194
+        res = int(np.ceil(base_resolution * per_level_scale ** i))
+        n = int(np.ceil(min(max_params, (res + 1) ** 3) / 8) * 8)
+        offsets.append(off)
+        off += n
+    offsets.append(off)
+    return dict(offsets=np.array(offsets, dtype=np.int64), S=float(np.log2(per_level_scale)), H=base_resolution,
+                n_levels=n_levels, level_dim=level_dim, bound=float(bound))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_entries):
+        super().__init__()
+        self.embeddings = nn.Parameter(torch.empty(n_entries, 2).uniform_(-1e-4, 1e-4))   # grid.py:203-205
+
+
+class MirrorNeRFTcnn(nn.Module):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2,
+                 hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2,
+                 hidden_dim_bg=64, bound=1, **kwargs):
+        super().__init__()
+        if (encoding, encoding_dir, num_layers, hidden_dim, geo_feat_dim, num_layers_color, hidden_dim_color) != (
+                "hashgrid", "sphere_harmonics", 2, 64, 15, 3, 64) or kwargs.get("bg_radius", 0):
+            raise NotImplementedError("the HIP kernel covers the reference configuration of train.py:71-82 only")
+        self.bound = bound
+        self.cfg = hashgrid_config(bound)
+        self.encoder = _Encoder(int(self.cfg["offsets"][-1]))
+        self.in_dim = 32
+        self.sigma_net = nn.ModuleList([nn.Linear(32, 64, bias=False), nn.Linear(64, 16, bias=False)])
+        self.color_net = nn.ModuleList([nn.Linear(31, 64, bias=False), nn.Linear(64, 64, bias=False),
+                                        nn.Linear(64, 3, bias=False)])
+        self.bg_net = None
+        self.predict_normal = kwargs.get("predict_normal", False)
+        self.predict_mirror_mask = kwargs.get("predict_mirror_mask", False)
+        if not (self.predict_normal and self.predict_mirror_mask):
+            raise NotImplementedError("predict_normal and predict_mirror_mask are required (run.sh always sets them)")
+        self.normal_net = nn.ModuleList([nn.Linear(15, 64, bias=False), nn.Linear(64, 3, bias=False)])
+        self.is_mirror_net = nn.Sequential(nn.Linear(15, 32), nn.LeakyReLU(inplace=True), nn.Linear(32, 1), nn.Sigmoid())
+        self._blob = None
+        self._blob_key = None
+
+    # ---- weight blob of the small MLPs in the order include/mnrf.h documents
+    def _weights(self):
+        ps = [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight, self.color_net[1].weight,
+              self.color_net[2].weight, self.normal_net[0].weight, self.normal_net[1].weight, self.is_mirror_net[0].weight,
+              self.is_mirror_net[0].bias, self.is_mirror_net[2].weight, self.is_mirror_net[2].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._blob_key:
+            def pad(w, cols):
+                w = w.detach().float()
+                return torch.nn.functional.pad(w, (0, cols - w.shape[1])).reshape(-1)
+            parts = [pad(ps[0], 32), pad(ps[1], 64), pad(ps[2], 32), pad(ps[3], 64), pad(ps[4], 64), pad(ps[5], 16),
+                     pad(ps[6], 64), pad(ps[7], 16), ps[8].detach().float(), pad(ps[9], 32), ps[10].detach().float()]
+            blob = torch.cat(parts)
+            n = _lib.lib().mnrf_tcnn_weight_floats()
+            self._blob = torch.nn.functional.pad(blob, (0, n - blob.numel())).contiguous()
+            self._blob_key = key
+        return self._blob
+
+    def field(self, B, *, xyz=None, xyz_stride=6, rays=None, z_vals=None, spr=1, dirs=None, sigma_only=False,
+              grad_normal=False, want_geo=False):
+        """Run the fused kernel; returns flat per-sample tensors like mirror_nerf.field_forward."""
+        table = self.encoder.embeddings.detach()
+        dev = table.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        out = {"sigma": f(B), "pred_normal": f(B, 3)}
+        if not sigma_only:
+            out["rgb"] = f(B, 3)
+            out["is_mirror"] = f(B)
+        if grad_normal:
+            out["normal"] = f(B, 3)
+        if want_geo:
+            out["geo_feat"] = f(B, 15)
+        flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
+        offs = (ctypes.c_int64 * 17)(*[int(v) for v in self.cfg["offsets"]])
+        p = _lib.ptr
+        if B:
+            _lib.check(_lib.lib().mnrf_tcnn_forward(
+                p(table.contiguous()), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
+                p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3,
+                p(out["sigma"]), p(out.get("rgb")), p(out["pred_normal"]), p(out.get("is_mirror")), p(out.get("normal")),
+                p(out.get("geo_feat")), _lib.stream()), "mnrf_tcnn_forward")
+        return out
+
+    def forward(self, x, compute_normal=True, sigma_only=False, embedding_xyz=None, embedding_dir=None,
+                mirror_mask=None, detach_density_outside_mirror_for_mask_loss=False,
+                detach_density_for_mask_loss=False, detach_density_for_normal_loss=False):
+        """x: (B,3) when sigma_only else (B,6) = [xyz, raw direction] (mirror_nerf_tcnn.py:165-170).
+        `sigma` has shape (B,) here, as in the reference (235)."""
+        x = x.float().contiguous()
+        B = x.shape[0]
+        o = self.field(B, xyz=x, xyz_stride=x.shape[1], sigma_only=sigma_only, grad_normal=compute_normal, want_geo=True)
+        out = {}
+        if compute_normal:
+            out["normal"] = o["normal"]
+        out["sigma"] = o["sigma"]
+        out["geo_feat"] = o["geo_feat"]
+        out["pred_normal"] = o["pred_normal"]
+        if not sigma_only:
+            out["rgb"] = o["rgb"]
+            out["is_mirror"] = o["is_mirror"].view(B, 1)
+        return out

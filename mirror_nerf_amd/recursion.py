@@ -203,19 +203,25 @@ class NeRFSystem(nn.Module):
         super().__init__()
         self.hparams = hparams if not isinstance(hparams, dict) else SimpleNamespace(**hparams)
         hp = self.hparams
-        if getattr(hp, "model_type", "nerf") != "nerf":
-            raise NotImplementedError("model_type nerf_tcnn (hash grid) is not built yet")
         self.train_geometry_stage = getattr(hp, "train_geometry_stage", False)
         self.white_back = white_back
-        self.embedding_xyz = Embedding(hp.N_emb_xyz)
-        self.embedding_dir = Embedding(hp.N_emb_dir)
+        if getattr(hp, "model_type", "nerf") == "nerf_tcnn":                       # train.py:67-99
+            from .mirror_nerf_tcnn import MirrorNeRFTcnn
+            self.embedding_xyz = Embedding(0)
+            self.embedding_dir = Embedding(0)
+            make = lambda: MirrorNeRFTcnn(encoding="hashgrid", bound=hp.bound, predict_normal=hp.predict_normal,  # noqa: E731
+                                          predict_mirror_mask=hp.predict_mirror_mask)
+        else:
+            self.embedding_xyz = Embedding(hp.N_emb_xyz)
+            self.embedding_dir = Embedding(hp.N_emb_dir)
+            kw = dict(in_channels_xyz=6 * hp.N_emb_xyz + 3, in_channels_dir=6 * hp.N_emb_dir + 3,
+                      predict_normal=hp.predict_normal, predict_mirror_mask=hp.predict_mirror_mask)
+            make = lambda: MirrorNeRF(**kw)  # noqa: E731
         self.embeddings = {"xyz": self.embedding_xyz, "dir": self.embedding_dir}
-        kw = dict(in_channels_xyz=6 * hp.N_emb_xyz + 3, in_channels_dir=6 * hp.N_emb_dir + 3,
-                  predict_normal=hp.predict_normal, predict_mirror_mask=hp.predict_mirror_mask)
-        self.nerf_coarse = MirrorNeRF(**kw)
+        self.nerf_coarse = make()
         self.models = {"coarse": self.nerf_coarse}
         if hp.N_importance > 0 and not hp.only_one_field:
-            self.nerf_fine = MirrorNeRF(**kw)
+            self.nerf_fine = make()
             self.models["fine"] = self.nerf_fine
 
     def forward(self, rays, extra=dict()):

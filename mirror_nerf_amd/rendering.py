@@ -81,11 +81,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     N = rays.shape[0]
     compute_normal = kwargs.get("compute_normal", True)
     n_fx, n_fd = _n_freqs(embeddings["xyz"]), _n_freqs(embeddings["dir"])
-    if n_fx != 10 or n_fd != 4:
+    from .mirror_nerf_tcnn import MirrorNeRFTcnn
+    hashgrid = isinstance(models["coarse"], MirrorNeRFTcnn)     # BASELINE config 5 (train.py:67-99)
+    if hashgrid and (n_fx, n_fd) != (0, 0):
+        raise NotImplementedError("the hash-grid field takes raw positions and directions: Embedding(0)/Embedding(0)")
+    if not hashgrid and (n_fx, n_fd) != (10, 4):
         raise NotImplementedError("the HIP field kernel is built for Embedding(10)/Embedding(4)")
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
 
-    train = torch.is_grad_enabled() and (rays.requires_grad or any(
+    train = (not hashgrid) and torch.is_grad_enabled() and (rays.requires_grad or any(
         q.requires_grad for mdl in models.values() for q in mdl.parameters()))
 
     # rendering.py:275-277 -- view encoding once per ray
@@ -115,7 +119,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         B = N * S
         if train and not sigma_only and N:
             return inference_train(model, typ, z, noise_key)
-        if N:
+        if N and hashgrid:
+            o = model.field(B, rays=rays, z_vals=z, spr=S, dirs=dir_emb, sigma_only=sigma_only,
+                            grad_normal=compute_normal and not sigma_only)
+        elif N:
             o = field_forward(model, B, rays=rays, z_vals=z, spr=S, dir_emb=dir_emb, dir_stride=dir_emb.shape[1],
                               sigma_only=sigma_only, grad_normal=compute_normal and not sigma_only)
         else:

@@ -652,3 +652,163 @@ def synthetic_rays(H, W, near=0.05, far=8.0, camera_angle_x=0.6911112):
 def psnr(pred, gt):
     """metrics.py:5-15."""
     return float(-10.0 * np.log10(np.mean((np.asarray(pred, F64) - np.asarray(gt, F64)) ** 2)))
+
+
+# --------------------------------------------------------------------------
+# a15  hash-grid field (config 5)                models/mirror_nerf_tcnn.py:13-276
+# --------------------------------------------------------------------------
+# PARITY UNPINNED for this section: the reference evaluates the multiresolution hash encoding with
+# tinycudann (un-vendored, un-pinned, CUDA-only -- README.md:33) and the SH encoding with a CUDA-only
+# extension, so neither can run here and the reference holds no vectors for them.  The restatement
+# follows the only in-tree statement of the algorithm, models/gridencoder/src/gridencoder.cu
+# (fast_hash 51-66, get_grid_index 68-89, kernel_grid 91-272) with the level sizing of
+# models/gridencoder/grid.py:181-194 and tinycudann's per_level_scale of mirror_nerf_tcnn.py:38;
+# SH from models/shencoder/src/shencoder.cu:49-79 (degree 4); MLPs from mirror_nerf_tcnn.py:52-149,
+# 220-259.  It is validated for self-consistency only (HIP kernel vs this file).
+HASH_PRIMES = (np.uint32(1), np.uint32(2654435761), np.uint32(805459861))
+
+
+def hashgrid_config(bound=1.0, n_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19):
+    """Level offsets (grid.py:181-194) and log2(per_level_scale) (mirror_nerf_tcnn.py:38)."""
+    per_level_scale = np.exp2(np.log2(2048 * bound / n_levels) / (n_levels - 1))
+    max_params = 2 ** log2_hashmap_size
+    offsets, off = [], 0
+    for i in range(n_levels):
+        res = int(np.ceil(base_resolution * per_level_scale ** i))
+        n = min(max_params, (res + 1) ** 3)
+        n = int(np.ceil(n / 8) * 8)
+        offsets.append(off)
+        off += n
+    offsets.append(off)
+    return dict(offsets=np.array(offsets, dtype=np.int64), S=float(np.log2(per_level_scale)), H=base_resolution,
+                n_levels=n_levels, level_dim=level_dim, bound=float(bound))
+
+
+def hashgrid_encode(x01, table, cfg, want_grad=False):
+    """gridencoder.cu:91-272 (linear interpolation, align_corners=False, gridtype hash).
+    x01 (B,3) in [0,1]; table (n_entries, 2) fp32.  Returns (B, 32) [level-major, like tcnn's output]
+    and, optionally, d out / d x01 as (B, 32, 3)."""
+    x01 = np.asarray(x01, dtype=F32)
+    B = x01.shape[0]
+    L, C = cfg["n_levels"], cfg["level_dim"]
+    out = np.zeros((B, L * C), dtype=F32)
+    dydx = np.zeros((B, L * C, 3), dtype=F32) if want_grad else None
+    oob = ((x01 < 0) | (x01 > 1)).any(-1)
+    for lv in range(L):
+        off0, off1 = int(cfg["offsets"][lv]), int(cfg["offsets"][lv + 1])
+        hsize = off1 - off0
+        # gridencoder.cu:150 (exp2f on the device there); fixed in double precision here and in the kernel's host code
+        scale = F32(np.exp2(np.float64(lv) * np.float64(cfg["S"])) * np.float64(cfg["H"]) - 1.0)
+        res = np.uint32(np.ceil(scale)) + np.uint32(1)
+        pos = x01 * scale + F32(0.5)
+        pg = np.floor(pos).astype(np.uint32)
+        fr = (pos - pg.astype(F32)).astype(F32)
+        acc = np.zeros((B, C), dtype=F32)
+        gacc = np.zeros((B, 3, C), dtype=F32)
+        for idx in range(8):
+            w = np.ones(B, dtype=F32)
+            loc = np.empty((B, 3), dtype=np.uint32)
+            for d in range(3):
+                if idx & (1 << d):
+                    w = w * fr[:, d]
+                    loc[:, d] = pg[:, d] + np.uint32(1)
+                else:
+                    w = w * (F32(1) - fr[:, d])
+                    loc[:, d] = pg[:, d]
+            index = _grid_index(loc, hsize, res)
+            val = table[off0 + index]                     # (B, C)
+            acc = acc + w[:, None] * val
+            if want_grad:
+                for gd in range(3):
+                    wg = np.full(B, scale, dtype=F32)
+                    for d in range(3):
+                        if d == gd:
+                            continue
+                        wg = wg * (fr[:, d] if idx & (1 << d) else (F32(1) - fr[:, d]))
+                    sign = F32(1) if idx & (1 << gd) else F32(-1)
+                    gacc[:, gd, :] += (sign * wg)[:, None] * val
+        acc[oob] = 0
+        out[:, lv * C:(lv + 1) * C] = acc
+        if want_grad:
+            gacc[oob] = 0
+            dydx[:, lv * C:(lv + 1) * C, :] = gacc.transpose(0, 2, 1)
+    return (out, dydx) if want_grad else out
+
+
+def _grid_index(loc, hsize, res):
+    """get_grid_index (gridencoder.cu:68-89), gridtype hash, align_corners False."""
+    stride = np.uint64(1)
+    index = np.zeros(loc.shape[0], dtype=np.uint64)
+    d = 0
+    while d < 3 and stride <= np.uint64(hsize):
+        index = index + loc[:, d].astype(np.uint64) * stride
+        stride = stride * np.uint64(int(res) + 1)
+        d += 1
+    index = index.astype(np.uint32)   # the CUDA code does this arithmetic in uint32
+    if stride > np.uint64(hsize):
+        h = np.zeros(loc.shape[0], dtype=np.uint32)
+        for k in range(3):
+            h ^= (loc[:, k] * HASH_PRIMES[k]).astype(np.uint32)
+        index = h
+    return (index % np.uint32(hsize)).astype(np.int64)
+
+
+def sh4(d):
+    """Real spherical harmonics, degree 4 (16 values): shencoder.cu:49-79."""
+    d = np.asarray(d, dtype=F32)
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    o = np.empty((d.shape[0], 16), dtype=F32)
+    o[:, 0] = 0.28209479177387814
+    o[:, 1] = -0.48860251190291987 * y
+    o[:, 2] = 0.48860251190291987 * z
+    o[:, 3] = -0.48860251190291987 * x
+    o[:, 4] = 1.0925484305920792 * xy
+    o[:, 5] = -1.0925484305920792 * yz
+    o[:, 6] = 0.94617469575755997 * z2 - 0.31539156525251999
+    o[:, 7] = -1.0925484305920792 * xz
+    o[:, 8] = 0.54627421529603959 * x2 - 0.54627421529603959 * y2
+    o[:, 9] = 0.59004358992664352 * y * (-3.0 * x2 + y2)
+    o[:, 10] = 2.8906114426405538 * xy * z
+    o[:, 11] = 0.45704579946446572 * y * (1.0 - 5.0 * z2)
+    o[:, 12] = 0.3731763325901154 * z * (5.0 * z2 - 3.0)
+    o[:, 13] = 0.45704579946446572 * x * (1.0 - 5.0 * z2)
+    o[:, 14] = 1.4453057213202769 * z * (x2 - y2)
+    o[:, 15] = 0.59004358992664352 * x * (-x2 + 3.0 * y2)
+    return o.astype(F32)
+
+
+def tcnn_field_forward(w, x, cfg, sigma_only=False, compute_normal=False):
+    """MirrorNeRFTcnn.forward (mirror_nerf_tcnn.py:151-259).  w: dict with `encoder.embeddings`
+    (n,2), `sigma_net.{0,1}.weight`, `color_net.{0,1,2}.weight`, `normal_net.{0,1}.weight`,
+    `is_mirror_net.{0,2}.{weight,bias}`.  x: (B,3) or (B,6) = [xyz, raw direction]."""
+    x = np.asarray(x, dtype=F32)
+    xyz = x[:, :3]
+    bound = F32(cfg["bound"])
+    x01 = ((xyz + bound) / (F32(2) * bound)).astype(F32)                   # 224
+    out = {}
+    if compute_normal:
+        enc, dydx = hashgrid_encode(x01, w["encoder.embeddings"], cfg, want_grad=True)
+    else:
+        enc = hashgrid_encode(x01, w["encoder.embeddings"], cfg)
+    pre = (enc @ w["sigma_net.0.weight"].T).astype(F32)
+    h = (np.maximum(pre, 0) @ w["sigma_net.1.weight"].T).astype(F32)       # 228-233
+    sigma, geo = h[:, 0], h[:, 1:]                                         # sigma is NOT rectified here
+    out["sigma"] = sigma
+    out["geo_feat"] = geo
+    if compute_normal:
+        g1 = np.broadcast_to(w["sigma_net.1.weight"][0], pre.shape) * (pre > 0)
+        genc = (g1.astype(F32) @ w["sigma_net.0.weight"]).astype(F32)       # (B,32)
+        grad = np.einsum("bk,bkd->bd", genc, dydx).astype(F32) / (F32(2) * bound)
+        out["normal"] = l2_normalize(-grad)
+    hn = np.maximum(geo @ w["normal_net.0.weight"].T, 0).astype(F32)       # 249-255
+    out["pred_normal"] = l2_normalize((hn @ w["normal_net.1.weight"].T).astype(F32))
+    if not sigma_only:
+        hc = np.concatenate([sh4(x[:, 3:6]), geo], -1)                     # 238-247
+        hc = np.maximum(hc @ w["color_net.0.weight"].T, 0).astype(F32)
+        hc = np.maximum(hc @ w["color_net.1.weight"].T, 0).astype(F32)
+        out["rgb"] = _sigmoid((hc @ w["color_net.2.weight"].T).astype(F32))
+        hm = (geo @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"]).astype(F32)
+        hm = np.where(hm > 0, hm, F32(0.01) * hm).astype(F32)
+        out["is_mirror"] = _sigmoid((hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"]).astype(F32))
+    return out
