@@ -1,3 +1,13 @@
+#!/usr/bin/env python3
+"""Tuning experiment: per-phase cycle counts inside one workgroup of the field kernel (s_memtime marks).
+Build the instrumented library first (marks are compiled out of the product build):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -mllvm -pragma-unroll-threshold=1000000 \
+        -DMNRF_EXP_MARKS -c mirror_nerf_amd/csrc/mnrf_field.hip -o /tmp/f.o
+  hipcc --offload-arch=gfx950 -shared -fPIC /tmp/f.o mirror_nerf_amd/csrc/mnrf_render.o mirror_nerf_amd/csrc/mnrf_dw.o \
+        mirror_nerf_amd/csrc/mnrf_tcnn.o -o /tmp/libmnrf_marks.so
+  MNRF_LIB=/tmp/libmnrf_marks.so MNRF_FIELD_VARIANT=s2 python scripts/exp_phase_marks.py
+(-DMNRF_EXP_NO_DMA / -DMNRF_EXP_NO_READ build the "no barrier+DMA" / "no LDS read" timing variants the
+same way; their results are garbage by construction.)"""
 import sys, torch
 sys.path.insert(0,'.')
 import bench, mirror_nerf_amd as M

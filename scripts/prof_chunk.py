@@ -18,9 +18,25 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--rays", type=int, default=32768)
 ap.add_argument("--train", action="store_true", help="train-mode forward: full coarse pass + density-gradient normals")
+ap.add_argument("--tcnn", action="store_true", help="hash-grid field (config 5) instead of the 8x256 MLP")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 models, sds, emb = bench.build_models(dev)
+if a.tcnn:
+    import time
+    torch.manual_seed(0)
+    models = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev)
+              for k in ("coarse", "fine")}
+    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    rays = torch.from_numpy(O.synthetic_rays(800, 800)[300 * 800: 300 * 800 + a.rays]).to(dev)
+    for it in range(a.reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"tcnn chunk: {dt * 1e3:.2f} ms  {a.rays * 256 / dt / 1e6:.1f} M samples/s  {a.rays / dt / 1e3:.1f} k rays/s")
+    sys.exit(0)
 rays = torch.from_numpy(O.synthetic_rays(800, 800)[300 * 800: 300 * 800 + a.rays]).to(dev)
 MN.LAUNCH_LOG = []
 for _ in range(a.reps + 1):

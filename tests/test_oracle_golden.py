@@ -106,3 +106,38 @@ def test_synthetic_rays_shape_and_norm():
     assert rays.shape == (600, 8)
     assert np.allclose(np.linalg.norm(rays[:, 3:6], axis=1), 1, atol=1e-6)
     assert np.all(rays[:, 6] == np.float32(0.05)) and np.all(rays[:, 7] == 8)
+
+
+# ---- a15 (parity unpinned): internal consistency of the hash-grid restatement
+def test_hashgrid_restatement_is_self_consistent():
+    cfg = O.hashgrid_config(bound=6.0)
+    assert int(cfg["offsets"][-1]) == 6616280            # table size at bound 6
+    assert np.all(np.diff(cfg["offsets"]) % 8 == 0) and np.diff(cfg["offsets"]).max() == 2 ** 19
+    rs = np.random.RandomState(0)
+    table = rs.uniform(-0.1, 0.1, (int(cfg["offsets"][-1]), 2)).astype(np.float32)
+    x = rs.uniform(0.02, 0.98, (64, 3)).astype(np.float32)
+    enc, dydx = O.hashgrid_encode(x, table, cfg, want_grad=True)
+    assert enc.shape == (64, 32) and dydx.shape == (64, 32, 3)
+    for d in range(3):                                    # analytic d/dx against a finite difference (coarse levels)
+        x2 = x.copy()
+        x2[:, d] += 1e-4
+        num = (O.hashgrid_encode(x2, table, cfg).astype(np.float64) - enc) / 1e-4
+        assert np.median(np.abs(num[:, :6] - dydx[:, :6, d])) <= 2e-3
+    out = O.hashgrid_encode(np.array([[1.5, 0.5, 0.5]], np.float32), table, cfg)
+    assert np.all(out == 0)                               # outside the unit box: zeros (gridencoder.cu:118-147)
+    # trilinear interpolation reproduces the stored value at a dense-level vertex
+    lv = 0
+    scale = np.float32(np.exp2(0.0) * 16 - 1.0)
+    v = (np.array([[3, 5, 7]], np.float32) - 0.5) / scale + 1e-7
+    res = int(np.ceil(scale)) + 1
+    idx = 3 + 5 * (res + 1) + 7 * (res + 1) ** 2
+    assert np.allclose(O.hashgrid_encode(v.astype(np.float32), table, cfg)[0, :2], table[idx], atol=1e-5)
+
+
+def test_sh4_is_orthonormal_on_the_sphere():
+    rs = np.random.RandomState(1)
+    d = rs.normal(size=(200000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    Y = O.sh4(d).astype(np.float64)
+    gram = 4 * np.pi * (Y.T @ Y) / d.shape[0]
+    assert np.max(np.abs(gram - np.eye(16))) < 0.03
