@@ -29,8 +29,8 @@ constexpr int NFREQ_DIR = 4;
 
 constexpr int TILE_FLOATS = 256;
 constexpr int TILE_BYTES = 1024;
-constexpr int CHUNK_TILES = 16;  // LDS staging granule: 16 KiB (every part is padded to whole chunks)
-constexpr int CHUNK_BYTES = CHUNK_TILES * TILE_BYTES;
+constexpr int PAD_TILES = 16;    // every part of a weight stream is padded to a multiple of this many tiles (the LDS
+                                 // staging chunk of a kernel tuning must divide it; 32-tile chunks measured 1 % SLOWER)
 
 // how the 4*ntq k-steps of a part map to columns of the nn.Linear weight
 enum PartKind : int {
@@ -61,7 +61,7 @@ struct Part {
     int tile0;      // first tile of the part inside its stream
 };
 
-__host__ __device__ constexpr int padded_tiles(int n) { return (n + CHUNK_TILES - 1) / CHUNK_TILES * CHUNK_TILES; }
+__host__ __device__ constexpr int padded_tiles(int n) { return (n + PAD_TILES - 1) / PAD_TILES * PAD_TILES; }
 
 // ---- forward stream -------------------------------------------------------------------
 // stage:       L1   L2..L4  L5(enc,h)  L6..L8  SIG | NRM1 NRM2 MIR1 MIR2 FIN  DIR(h,dir)  RGB
@@ -125,7 +125,7 @@ constexpr int BS_L = 2112;            // 8 x 256  b_i = (dsigma/dh_i) * relu'_i 
 constexpr int SO_FLOATS = 4160;       // per sample
 constexpr int TRUNK_FWD_TILES = 64 + 3 * 256 + 320 + 3 * 256;   // forward stream prefix L1..L8
 
-static_assert(FWD_TILES % CHUNK_TILES == 0 && FWD_TILES_SIGMA % CHUNK_TILES == 0, "chunking");
-static_assert(BWD_TILES % CHUNK_TILES == 0 && HBWD_TILES % CHUNK_TILES == 0, "chunking");
+static_assert(FWD_TILES % PAD_TILES == 0 && FWD_TILES_SIGMA % PAD_TILES == 0, "chunking");
+static_assert(BWD_TILES % PAD_TILES == 0 && HBWD_TILES % PAD_TILES == 0, "chunking");
 
 }  // namespace mnrf

@@ -41,9 +41,11 @@ rays = torch.from_numpy(O.synthetic_rays(800, 800)[300 * 800: 300 * 800 + a.rays
 MN.LAUNCH_LOG = []
 for _ in range(a.reps + 1):
     if a.train:
-        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=False, compute_normal=True)
+        with torch.no_grad():   # the train-MODE forward kernels (4 heads + density gradient), without saving activations
+            M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=False, compute_normal=True)
     else:
-        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+        with torch.no_grad():   # inference kernels (with autograd on, render_rays takes the training forward)
+            M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
 torch.cuda.synchronize()
 for flags, B, e0, e1 in MN.LAUNCH_LOG[2:]:
     ms = e0.elapsed_time(e1)

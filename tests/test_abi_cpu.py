@@ -29,7 +29,7 @@ def test_exports_match_header(L):
 
 def test_packed_size_matches_layout(L):
     # forward tiles 2640 + bias block 3072 floats + backward tiles 1920 (mnrf_layout.h)
-    assert L.mnrf_packed_floats() == 2640 * 256 + 3072 + 1920 * 256 + 704 * 256   # + head-backward stream
+    assert L.mnrf_packed_floats() == 2640 * 256 + 3072 + 1920 * 256 + 704 * 256   # fwd + bias + trunk^T + heads^T
     assert L.mnrf_version() >= 1
 
 
