@@ -142,6 +142,18 @@ int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const floa
                             float* d_sigma, float* d_rgb, float* d_is_mirror, float* d_pred_normal,
                             float* d_normal, float* d_rays, void* stream);
 
+/* ---- backward of the per-ray glue (training; autograd through train.py:217-296, mirror_nerf.py:20-38)
+ * reflect: g_sec (n_sec,8) = dL/d secondary rays -> dL/dx_surface (n_rays,3), dL/d normal (n_rays,3),
+ *          dL/d rays (n_rays,8: direction and far columns); rows without a selected ray get zeros.
+ * blend:   g_out (n,c) -> dL/d base (n,c) = (1-m) g_out and dL/d sec (n_sec,c) = m g_out gathered by index.
+ * embed:   g_out (n, c*(2N+1)) -> dL/dx (n,c). */
+int mnrf_reflect_backward(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                          const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                          void* stream);
+int mnrf_blend_backward(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                        float* g_base, float* g_sec, void* stream);
+int mnrf_embed_backward(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, void* stream);
+
 /* ---- training (forward with saved activations, backward) -----------------------------------
  * Buffer sizes for B samples: activations (floats), ReLU bit masks (uint64 words), workspace of
  * the backward (floats: pre-activation gradients + split-K partials of the weight gradients). */

@@ -40,6 +40,9 @@ SIGNATURES = {
     "mnrf_composite": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
                               _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
     "mnrf_composite_backward": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_str]),
+    "mnrf_reflect_backward": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _str]),
+    "mnrf_blend_backward": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _str]),
+    "mnrf_embed_backward": (_int, [_c_f, _c_f, _i64, _int, _int, _c_f, _str]),
     "mnrf_train_save_floats": (_i64, [_i64]),
     "mnrf_train_mask_words": (_i64, [_i64]),
     "mnrf_train_workspace_floats": (_i64, [_i64]),

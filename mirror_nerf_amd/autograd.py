@@ -170,8 +170,8 @@ class FieldFn(torch.autograd.Function):
 
 
 class EmbedFn(torch.autograd.Function):
-    """Embedding.forward with its analytic backward (per-ray tensors only: the view encoding of
-    reflected rays carries gradient back to the surface normal, train.py:205 "not detach()")."""
+    """mnrf_embed / mnrf_embed_backward (Embedding.forward, models/mirror_nerf.py:20-38): the view encoding of
+    reflected rays carries gradient back to the surface normal (train.py:205 "not detach()")."""
 
     @staticmethod
     def forward(ctx, x, n_freqs):
@@ -187,11 +187,81 @@ class EmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        c = x.shape[1]
-        gx = g[:, :c].clone()
-        for k in range(ctx.n_freqs):
-            fr = 2.0 ** k
-            gs = g[:, c * (1 + 2 * k): c * (2 + 2 * k)]
-            gc = g[:, c * (2 + 2 * k): c * (3 + 2 * k)]
-            gx += fr * (gs * torch.cos(fr * x) - gc * torch.sin(fr * x))
+        n, c = x.shape
+        gx = torch.empty_like(x)
+        if n:
+            _lib.check(_lib.lib().mnrf_embed_backward(_lib.ptr(x), _lib.ptr(g.contiguous().float()), n, c, ctx.n_freqs,
+                                                      _lib.ptr(gx), _lib.stream()), "mnrf_embed_backward")
         return gx, None
+
+
+class ReflectFn(torch.autograd.Function):
+    """mnrf_reflect_compact / mnrf_reflect_backward (train.py:192-252): reflected-ray construction and
+    order-preserving compaction.  apply(rays, x_surface, normal, mask, compact) -> (sec (M,8), index (M) int32
+    [empty when not compacted], reflect_dir (N,3) [not differentiable: visualisation output])."""
+
+    @staticmethod
+    def forward(ctx, rays, x_surface, normal, mask, compact):
+        rays, x_surface, normal = _c(rays.float()), _c(x_surface.float()), _c(normal.float())
+        N = rays.shape[0]
+        dev = rays.device
+        sec = torch.empty(N, 8, dtype=torch.float32, device=dev)
+        index = torch.empty(N, dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        rdir = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mnrf_reflect_compact(
+            p(rays), p(x_surface), p(normal), None, 0.0, p(_c(mask.float())) if mask is not None else None, N,
+            int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), _lib.stream()), "mnrf_reflect_compact")
+        M = int(count.item()) if compact else N     # the one host sync per level (train.py:175 does the same)
+        sec, index = sec[:M].contiguous(), index[:M].contiguous()
+        ctx.save_for_backward(rays, normal, index)
+        ctx.compact = bool(compact)
+        ctx.mark_non_differentiable(index, rdir)
+        return sec, index, rdir
+
+    @staticmethod
+    def backward(ctx, g_sec, _gi, _gr):
+        rays, normal, index = ctx.saved_tensors
+        N, M = rays.shape[0], index.shape[0]
+        dev = rays.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        g_xs, g_n, g_rays = f(N, 3), f(N, 3), f(N, 8)
+        p = _lib.ptr
+        if g_sec is None:
+            return torch.zeros_like(rays), torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev), None, None
+        _lib.check(_lib.lib().mnrf_reflect_backward(
+            p(rays), p(normal), p(index) if ctx.compact else None, M, p(g_sec.contiguous().float()), N, p(g_xs), p(g_n),
+            p(g_rays), _lib.stream()), "mnrf_reflect_backward")
+        return g_rays, g_xs, g_n, None, None
+
+
+class BlendFn(torch.autograd.Function):
+    """mnrf_blend_scatter / mnrf_blend_backward (train.py:261-296): out = m*part + (1-m)*base with part = sec
+    scattered through index (rows without a source keep base.detach()).  `index` None/empty + M == N: direct."""
+
+    @staticmethod
+    def forward(ctx, base, sec, index, mask, compact):
+        base, sec, mask = _c(base.float()), _c(sec.float()), _c(mask.float())
+        N = base.shape[0]
+        c = base.shape[1] if base.dim() == 2 else 1
+        out = torch.empty_like(base)
+        p = _lib.ptr
+        idx = index if compact else None
+        _lib.check(_lib.lib().mnrf_blend_scatter(p(base), p(sec), p(idx), sec.shape[0], p(mask), N, c, p(out), None,
+                                                 _lib.stream()), "mnrf_blend_scatter")
+        ctx.save_for_backward(mask, index)
+        ctx.compact, ctx.c, ctx.m = bool(compact), c, sec.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        mask, index = ctx.saved_tensors
+        N = mask.shape[0]
+        g_out = g_out.contiguous().float()
+        g_base = torch.empty_like(g_out)
+        g_sec = torch.empty((ctx.m,) + tuple(g_out.shape[1:]), dtype=torch.float32, device=g_out.device)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mnrf_blend_backward(p(g_out), p(mask), p(index) if ctx.compact else None, ctx.m, N, ctx.c,
+                                                  p(g_base), p(g_sec), _lib.stream()), "mnrf_blend_backward")
+        return g_base, g_sec, None, None, None

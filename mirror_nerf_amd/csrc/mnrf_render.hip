@@ -497,6 +497,73 @@ __global__ void generate_rays_kernel(int H, int W, float focal, Pose c2w, float 
     o[6] = near; o[7] = far;
 }
 
+// ------------------------------------------------------------------ backward of the per-ray glue (training)
+// reflect: r = 2 (w.n) n - w with n = l2n(normal), w = l2n(-d); secondary = [x_surface, r, near2, far]
+__global__ void reflect_backward_kernel(const float* __restrict__ rays, const float* __restrict__ normal,
+                                        const int* __restrict__ index, long long n_sec, const float* __restrict__ g_sec,
+                                        float* __restrict__ g_xs, float* __restrict__ g_normal, float* __restrict__ g_rays) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sec) return;
+    const long long i = index ? index[j] : j;
+    float nv[3], wv[3], gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nv[k] = normal[i * 3 + k]; wv[k] = -rays[i * 8 + 3 + k]; gr[k] = g_sec[j * 8 + 3 + k]; }
+    const float nsq = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2];
+    const float wsq = wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2];
+    const float ninv = 1.f / sqrtf(fmaxf(nsq, EPS32)), winv = 1.f / sqrtf(fmaxf(wsq, EPS32));
+    float nh[3], wh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nh[k] = nv[k] * ninv; wh[k] = wv[k] * winv; }
+    const float c = wh[0] * nh[0] + wh[1] * nh[1] + wh[2] * nh[2];
+    const float grn = gr[0] * nh[0] + gr[1] * nh[1] + gr[2] * nh[2];
+    float gnh[3], gwh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gnh[k] = 2.f * grn * wh[k] + 2.f * c * gr[k]; gwh[k] = 2.f * grn * nh[k] - gr[k]; }
+    const float pn = nsq > EPS32 ? nh[0] * gnh[0] + nh[1] * gnh[1] + nh[2] * gnh[2] : 0.f;   // clamped norm: constant denominator
+    const float pw = wsq > EPS32 ? wh[0] * gwh[0] + wh[1] * gwh[1] + wh[2] * gwh[2] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g_xs[i * 3 + k] = g_sec[j * 8 + k];
+        g_normal[i * 3 + k] = (gnh[k] - nh[k] * pn) * ninv;
+        g_rays[i * 8 + 3 + k] = -(gwh[k] - wh[k] * pw) * winv;     // w = -d / |d|
+    }
+    g_rays[i * 8 + 7] = g_sec[j * 8 + 7];                           // far is passed through
+}
+
+// blend: out = m*part + (1-m)*base, part = sec scattered by index (rows without a source: base.detach())
+__global__ void blend_backward_kernel(const float* __restrict__ g_out, const float* __restrict__ mask, long long n, int c,
+                                      float* __restrict__ g_base) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    g_base[i] = (1.f - mask[i / c]) * g_out[i];
+}
+__global__ void blend_backward_sec_kernel(const float* __restrict__ g_out, const float* __restrict__ mask,
+                                          const int* __restrict__ index, long long n_sec, int c, float* __restrict__ g_sec) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sec * c) return;
+    const long long row = index ? index[j / c] : j / c;
+    g_sec[j] = mask[row] * g_out[row * c + (j % c)];
+}
+
+// Embedding backward: dx = g_x + sum_k 2^k (g_sin_k cos(2^k x) - g_cos_k sin(2^k x))
+__global__ void embed_backward_kernel(const float* __restrict__ x, const float* __restrict__ g, long long n, int c,
+                                      int n_freqs, float* __restrict__ gx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const long long row = i / c;
+    const int ch = (int)(i % c);
+    const int ld = c * (2 * n_freqs + 1);
+    const float v = x[i];
+    const float* gr = g + row * ld;
+    float a = gr[ch];
+    for (int f = 0; f < n_freqs; ++f) {
+        float s, co;
+        sincosf(ldexpf(v, f), &s, &co);
+        a += ldexpf(gr[c * (1 + 2 * f) + ch] * co - gr[c * (2 + 2 * f) + ch] * s, f);
+    }
+    gx[i] = a;
+}
+
 inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
@@ -620,6 +687,45 @@ extern "C" int mnrf_blend_scatter(const float* base, const float* sec, const int
         hipLaunchKernelGGL(blend_scatter_kernel, dim3(blocks_for(n_sec * c, 256)), dim3(256), 0, s, base, sec, index,
                            (long long)n_sec, mask, c, out, reflect_out);
     return mnrf_check_launch("mnrf_blend_scatter");
+}
+
+extern "C" int mnrf_reflect_backward(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                                     const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                                     void* stream) {
+    if (n_rays < 0 || n_sec < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward: bad size");
+    if (n_rays == 0) return MNRF_OK;
+    if (!rays || !normal || !g_x_surface || !g_normal || !g_rays || (n_sec > 0 && !g_sec))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(g_x_surface, 0, n_rays * 3 * sizeof(float), s);
+    (void)hipMemsetAsync(g_normal, 0, n_rays * 3 * sizeof(float), s);
+    (void)hipMemsetAsync(g_rays, 0, n_rays * 8 * sizeof(float), s);
+    if (n_sec > 0)
+        hipLaunchKernelGGL(reflect_backward_kernel, dim3(blocks_for(n_sec, 256)), dim3(256), 0, s, rays, normal, index, (long long)n_sec,
+                           g_sec, g_x_surface, g_normal, g_rays);
+    return mnrf_check_launch("mnrf_reflect_backward");
+}
+
+extern "C" int mnrf_blend_backward(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                                   float* g_base, float* g_sec, void* stream) {
+    if (n < 0 || n_sec < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_backward: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!g_out || !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (g_base) hipLaunchKernelGGL(blend_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, s, g_out, mask, (long long)n, c, g_base);
+    if (g_sec && n_sec > 0)
+        hipLaunchKernelGGL(blend_backward_sec_kernel, dim3(blocks_for(n_sec * c, 256)), dim3(256), 0, s, g_out, mask, index,
+                           (long long)n_sec, c, g_sec);
+    return mnrf_check_launch("mnrf_blend_backward");
+}
+
+extern "C" int mnrf_embed_backward(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, void* stream) {
+    if (n < 0 || c < 1 || n_freqs < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed_backward: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!x || !g_out || !g_x) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed_backward: null pointer");
+    hipLaunchKernelGGL(embed_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, x, g_out, (long long)n, c,
+                       n_freqs, g_x);
+    return mnrf_check_launch("mnrf_embed_backward");
 }
 
 extern "C" int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far, float* rays,

@@ -69,39 +69,23 @@ def _blend(base, sec, index, mask, want_reflect):
 
 
 def _reflect_autograd(rays, x_surface, normal, mask, compact):
-    """The same reflected-ray construction with torch ops, used only when gradients must flow from
-    the reflected render back into the surface point and normal (train.py:205 "not detach() to
-    jointly optimize").  Per-ray tensors; the heavy lifting stays in the HIP kernels."""
-    eps = torch.tensor(torch.finfo(torch.float32).eps, device=rays.device)
-
-    def l2n(v):
-        return v / torch.sqrt(torch.maximum((v * v).sum(-1, keepdim=True), eps))
-    n = l2n(normal)
-    w = l2n(-rays[:, 3:6])
-    cos = (w * n).sum(-1)
-    rdir = 2 * cos[:, None] * n - w
-    far = rays[:, 7:8]
-    sec = torch.cat([x_surface, rdir, torch.ones_like(far) * RAY_FORWARD_OFFSET, far], -1)
-    index = None
-    if compact:
-        index = torch.nonzero(mask != 0)[:, 0].to(torch.int32)
-        sec = sec[index.long()]
-    return sec, index, rdir
+    """Reflected rays with gradient history (train.py:205 "not detach() to jointly optimize"): the same HIP
+    kernel forward, mnrf_reflect_backward backward."""
+    from .autograd import ReflectFn
+    sec, index, rdir = ReflectFn.apply(rays, x_surface, normal, mask, bool(compact))
+    return sec, (index if compact else None), rdir
 
 
 def _blend_autograd(base, sec, index, mask, want_reflect):
-    """train.py:263-296 with torch ops (autograd path)."""
-    if index is not None:
-        part = base.clone().detach()
-        part[index.long()] = sec
-    else:
-        part = sec
-    m = mask.float()[:, None]
-    out = m * part + (1 - m) * base
+    """train.py:263-296 with gradient history (BlendFn); the optional visualisation output is detached."""
+    from .autograd import BlendFn
+    compact = index is not None
+    idx = index if compact else torch.empty(0, dtype=torch.int32, device=base.device)
+    out = BlendFn.apply(base, sec, idx, mask, compact)
     refl = None
     if want_reflect:
         refl = torch.zeros_like(base)
-        if index is not None:
+        if compact:
             refl[index.long()] = sec.detach()
         else:
             refl = sec.detach()

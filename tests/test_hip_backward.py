@@ -194,3 +194,44 @@ def test_field_second_order_backward_matches_double_backward():
     print("second-order: worst relative gradient errors", report[:4])
     assert report[0][0] <= 5e-3, report[:4]
     assert _rel(x2.grad, x1.grad) <= 5e-3
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_reflect_blend_embed_backward(compact):
+    """Per-ray glue of the training path: HIP forward + HIP backward vs torch.autograd."""
+    from mirror_nerf_amd.autograd import BlendFn, EmbedFn, ReflectFn
+    torch.manual_seed(4)
+    N = 1500
+    rays = torch.randn(N, 8, device=DEV)
+    xs = torch.randn(N, 3, device=DEV)
+    nrm = torch.randn(N, 3, device=DEV)
+    nrm[3] = 0                                     # eps-clamped normal
+    mask = (torch.rand(N, device=DEV) < 0.3).float()
+    M = int(mask.sum().item()) if compact else N
+    cot = torch.randn(M, 8, device=DEV)
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    r1, x1, n1 = leaf(rays), leaf(xs), leaf(nrm)
+    (TR.reflect(r1, x1, n1, mask, compact) * cot).sum().backward()
+    r2, x2, n2 = leaf(rays), leaf(xs), leaf(nrm)
+    sec, index, rdir = ReflectFn.apply(r2, x2, n2, mask, compact)
+    assert sec.shape == (M, 8)
+    (sec * cot).sum().backward()
+    assert _rel(x2.grad, x1.grad) <= 1e-6 and _rel(n2.grad, n1.grad) <= 1e-5 and _rel(r2.grad, r1.grad) <= 1e-5
+    # blend
+    base = torch.rand(N, 3, device=DEV)
+    srgb = torch.rand(M, 3, device=DEV)
+    cot2 = torch.randn(N, 3, device=DEV)
+    b1, s1 = leaf(base), leaf(srgb)
+    (TR.blend(b1, s1, mask, compact) * cot2).sum().backward()
+    b2, s2 = leaf(base), leaf(srgb)
+    out = BlendFn.apply(b2, s2, index, mask, compact)
+    assert _rel(out, TR.blend(base, srgb, mask, compact)) <= 1e-6
+    (out * cot2).sum().backward()
+    assert _rel(b2.grad, b1.grad) <= 1e-6 and _rel(s2.grad, s1.grad) <= 1e-6
+    # embedding
+    d = TR.l2n(torch.randn(N, 3, device=DEV))
+    cot3 = torch.randn(N, 27, device=DEV)
+    d1, d2 = leaf(d), leaf(d)
+    (TR.embed(d1, 4) * cot3).sum().backward()
+    (EmbedFn.apply(d2, 4) * cot3).sum().backward()
+    assert _rel(d2.grad, d1.grad) <= 1e-5

@@ -60,3 +60,27 @@ def composite(rays, sigma, z, noise, rgb, is_mirror, pn, nrm, white_back=False):
         out["nd"] = (w * ((nrm - pn) ** 2).sum(-1)).sum(1)
     out["xs"] = rays[:, :3] + rays[:, 3:6] * depth[:, None]
     return out
+
+
+def reflect(rays, x_surface, normal, mask, compact):
+    """train.py:217-252 with torch ops (reference for ReflectFn)."""
+    n = l2n(normal)
+    w = l2n(-rays[:, 3:6])
+    cos = (w * n).sum(-1)
+    rdir = 2 * cos[:, None] * n - w
+    far = rays[:, 7:8]
+    sec = torch.cat([x_surface, rdir, torch.ones_like(far) * 0.1, far], -1)
+    if compact:
+        sec = sec[mask != 0]
+    return sec
+
+
+def blend(base, sec, mask, compact):
+    """train.py:263-296 with torch ops (reference for BlendFn)."""
+    if compact:
+        part = base.clone().detach()
+        part[mask != 0] = sec
+    else:
+        part = sec
+    m = mask[:, None]
+    return m * part + (1 - m) * base
