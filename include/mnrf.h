@@ -42,6 +42,9 @@ extern "C" {
 /* flags of mnrf_field_forward */
 #define MNRF_SIGMA_ONLY 1u     /* stop after sigma (rendering.py:139-150) */
 #define MNRF_GRAD_NORMAL 2u    /* also emit normal = l2n(-d sigma/d xyz) (mirror_nerf.py:136-146) */
+#define MNRF_SPLIT_F16 4u      /* evaluate the Linears on the f16 matrix pipe with every fp32 operand carried as a
+                                  hi/lo f16 pair (3 MFMAs per product block, fp32 accumulation; ~2^-20 relative per
+                                  product instead of the bit-exact fp32 fmaf chain of the default) */
 
 const char* mnrf_last_error(void);
 int mnrf_version(void);

@@ -25,6 +25,7 @@ _str = ctypes.c_void_p      # hipStream_t
 
 MNRF_SIGMA_ONLY = 1
 MNRF_GRAD_NORMAL = 2
+MNRF_SPLIT_F16 = 4
 N_PARAMS = 32
 
 # name -> (restype, argtypes): exactly the prototypes of include/mnrf.h

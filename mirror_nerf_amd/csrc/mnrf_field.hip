@@ -19,34 +19,9 @@
 #include <stdlib.h>
 
 #include "mnrf_layout.h"
+#include "mnrf_field_args.h"
 
 namespace mnrf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct FieldArgs {
-    const float* packed;
-    unsigned flags;
-    long long B;
-    const float* xyz;
-    long long xyz_stride;
-    const float* rays;
-    const float* z_vals;
-    int spr;
-    const float* dir_emb;
-    long long dir_stride;
-    float* sigma;
-    float* rgb;
-    float* pred_normal;
-    float* is_mirror;
-    float* normal;
-    float* geo_feat;
-    // training forward: activations / relu masks / normal-head norm kept for the backward pass
-    float* save_x;                 // [SAVE_FLOATS sections][B][width]   (null = inference)
-    unsigned long long* save_mask; // [tiles][N_MASKS][S][256]
-    float* save_inv;               // [B] 1/|v| of normal_net (negative when the eps clamp was active)
-    float* save_invj;              // [B] 1/|d sigma/dx| of the density-gradient normal, same convention
-};
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,57 +49,9 @@ struct PackArgs {
     float* packed;
 };
 
-struct PartTable {
-    Part fwd[N_FWD_PARTS];
-    Part bwd[N_BWD_PARTS];
-    Part hbwd[N_HBWD_PARTS];
-};
-
-__host__ __device__ inline void build_parts(PartTable& T) {
-    int n = 0, tile = 0;
-    auto add = [&](Part* arr, int& cnt, int param, int n_true, int ld, int ntq, int nb, int col_off, int kind) {
-        arr[cnt] = Part{param, n_true, ld, ntq, nb, col_off, kind, tile};
-        tile += padded_tiles(ntq * nb);
-        cnt++;
-    };
-    add(T.fwd, n, 0, 256, 63, 4, 16, 0, KIND_ENC);                             // L1
-    for (int i = 1; i < 4; ++i) add(T.fwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // L2..L4
-    add(T.fwd, n, 8, 256, 319, 4, 16, 0, KIND_ENC);                            // L5 encoding columns
-    add(T.fwd, n, 8, 256, 319, 16, 16, 63, KIND_H);                            // L5 hidden columns
-    for (int i = 5; i < 8; ++i) add(T.fwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // L6..L8
-    add(T.fwd, n, 20, 1, 256, 16, 1, 0, KIND_H);                               // sigma
-    add(T.fwd, n, 24, 128, 256, 16, 8, 0, KIND_H);                             // normal_net.0
-    add(T.fwd, n, 26, 3, 128, 8, 1, 0, KIND_H);                                // normal_net.1
-    add(T.fwd, n, 28, 128, 256, 16, 8, 0, KIND_H);                             // is_mirror_net.0
-    add(T.fwd, n, 30, 1, 128, 8, 1, 0, KIND_H);                                // is_mirror_net.2
-    add(T.fwd, n, 16, 256, 256, 16, 16, 0, KIND_H);                            // xyz_encoding_final
-    add(T.fwd, n, 18, 128, 283, 16, 8, 0, KIND_H);                             // dir_encoding: final part
-    add(T.fwd, n, 18, 128, 283, 2, 8, 256, KIND_DIR);                          // dir_encoding: view part
-    add(T.fwd, n, 22, 3, 128, 8, 1, 0, KIND_H);                                // rgb
-    // backward: A = W_i^T, rows = input columns of layer i, contraction over its 256 outputs
-    n = 0;
-    tile = 0;
-    for (int i = 7; i >= 5; --i) add(T.bwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // layers 8,7,6
-    add(T.bwd, n, 8, 256, 319, 16, 4, 0, KIND_ENC);                             // layer 5: 4 encoding row blocks
-    add(T.bwd, n, 8, 256, 319, 16, 16, ENC_XYZ, KIND_H);                        // layer 5: 16 hidden row blocks
-    for (int i = 3; i >= 1; --i) add(T.bwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // layers 4,3,2
-    add(T.bwd, n, 0, 256, 63, 16, 4, 0, KIND_ENC);                              // layer 1: 4 encoding row blocks
-    // head backward (training): n_true = rows of W = contraction length, nb = 16-blocks of W's columns
-    n = 0;
-    tile = 0;
-    add(T.hbwd, n, 22, 3, 128, 1, 8, 0, KIND_H);        // rgb^T
-    add(T.hbwd, n, 18, 128, 283, 8, 16, 0, KIND_H);     // dir_encoding^T, xyz_encoding_final columns
-    add(T.hbwd, n, 18, 128, 283, 8, 2, 256, KIND_DIR);  // dir_encoding^T, view-encoding columns
-    add(T.hbwd, n, 16, 256, 256, 16, 16, 0, KIND_H);    // xyz_encoding_final^T
-    add(T.hbwd, n, 26, 3, 128, 1, 8, 0, KIND_H);        // normal_net.1^T
-    add(T.hbwd, n, 24, 128, 256, 8, 16, 0, KIND_H);     // normal_net.0^T
-    add(T.hbwd, n, 30, 1, 128, 1, 8, 0, KIND_H);        // is_mirror_net.2^T
-    add(T.hbwd, n, 28, 128, 256, 8, 16, 0, KIND_H);     // is_mirror_net.0^T
-}
-
 __global__ void pack_kernel(PackArgs P, PartTable T) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= PACKED_FLOATS) return;
+    if (p >= PACKED_F32_FLOATS) return;
     float v = 0.f;
     if (p < OFF_BIAS) {
         // ---- forward tiles
@@ -212,8 +139,9 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     PartTable T;
     build_parts(T);
     const int threads = 256;
-    const int blocks = (int)((PACKED_FLOATS + threads - 1) / threads);
+    const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
+    launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
     return mnrf_check_launch("mnrf_pack_weights");
 }
 
@@ -235,15 +163,19 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
     if (grad && !normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward: GRAD_NORMAL needs the normal output");
     FieldArgs A{packed, flags, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, geo_feat};
-    // Tuning: s2 (32 samples/wave, one wave per SIMD) is fastest for the forward-only kernels, s1
-    // (16 samples/wave, two workgroups per CU) for the ones with the density-gradient pass.
-    // MNRF_FIELD_VARIANT=s1|s2 forces one (experiments).
+    // Tunings.  fp32 MFMA (bit-exact fmaf chains): s2 (32 samples/wave, one wave per SIMD) is fastest for the
+    // forward-only kernels, s1 (16 samples/wave, two workgroups per CU) for the ones with the density-gradient
+    // pass.  MNRF_SPLIT_F16 selects the split-f16 tuning (fp32 operands as hi/lo f16 pairs on the f16 matrix
+    // pipe).  MNRF_FIELD_VARIANT=s1|s2|h|hx forces one (experiments).
     static const int forced = [] {
         const char* e = getenv("MNRF_FIELD_VARIANT");
-        return (e && e[0] == 's' && (e[1] == '1' || e[1] == '2')) ? e[1] - '0' : 0;
+        if (e && e[0] == 's' && (e[1] == '1' || e[1] == '2')) return e[1] - '0';
+        if (e && e[0] == 'h') return e[1] == 'x' ? 4 : 3;
+        return 0;
     }();
-    const int variant = forced ? forced : (grad ? 1 : 2);
-    const int rc = variant == 1 ? s1::launch(A, sigma_only, grad, (hipStream_t)stream)
+    const int variant = forced ? forced : ((flags & MNRF_SPLIT_F16) ? ((flags & 8u) ? 4 : 3) : (grad ? 1 : 2));   // 8u: experimental big-chunk tuning
+    const int rc = variant >= 3 ? launch_split(A, sigma_only, grad, variant - 3, (hipStream_t)stream)
+                 : variant == 1 ? s1::launch(A, sigma_only, grad, (hipStream_t)stream)
                                 : s2::launch(A, sigma_only, grad, (hipStream_t)stream);
     if (rc != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_forward");

@@ -1,0 +1,42 @@
+// mnrf_field_args.h -- argument block of the field kernels, shared by the fp32 (mnrf_field.hip) and the
+// split-f16 (mnrf_field_split.hip) translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mnrf_layout.h"
+
+namespace mnrf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FieldArgs {
+    const float* packed;
+    unsigned flags;
+    long long B;
+    const float* xyz;
+    long long xyz_stride;
+    const float* rays;
+    const float* z_vals;
+    int spr;
+    const float* dir_emb;
+    long long dir_stride;
+    float* sigma;
+    float* rgb;
+    float* pred_normal;
+    float* is_mirror;
+    float* normal;
+    float* geo_feat;
+    // training forward: activations / relu masks / normal-head norm kept for the backward pass
+    float* save_x;                 // [SAVE_FLOATS sections][B][width]   (null = inference)
+    unsigned long long* save_mask; // [tiles][N_MASKS][S][256]
+    float* save_inv;               // [B] 1/|v| of normal_net (negative when the eps clamp was active)
+    float* save_invj;              // [B] 1/|d sigma/dx| of the density-gradient normal, same convention
+};
+
+// split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.
+int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s);
+// builds the split streams of a packed image from its fp32 streams (same stream, after pack_kernel)
+void launch_split_pack(float* packed, hipStream_t s);
+
+}  // namespace mnrf

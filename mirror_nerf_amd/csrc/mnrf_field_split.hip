@@ -1,0 +1,85 @@
+// mnrf_field_split.hip -- split-f16 tunings of the fused field kernel and the packer of their
+// weight streams (see mnrf_field_split.inc for the arithmetic, mnrf_layout.h for the layout).
+// Replaces the same reference code as mnrf_field.hip: models/mirror_nerf.py:101-212, 20-38,
+// models/rendering.py:302, 134-179.
+// Compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mnrf_layout.h"
+#include "mnrf_field_args.h"
+
+namespace mnrf {
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// h2: 32 samples per wave, one wave per SIMD; 16 KiB chunks, 48 KiB ring
+namespace h2 {
+constexpr int S = 2;
+constexpr int MIN_WAVES_PER_SIMD = 1;
+constexpr int CHUNK_PAIRS = 8;
+#include "mnrf_field_split.inc"
+}  // namespace h2
+#ifdef MNRF_SPLIT_BIG_CHUNKS
+// h2x: 32 KiB chunks, 96 KiB ring (half the barriers; needs LDS-DMA destinations above 64 KiB)
+namespace h2x {
+constexpr int S = 2;
+constexpr int MIN_WAVES_PER_SIMD = 1;
+constexpr int CHUNK_PAIRS = 16;
+#include "mnrf_field_split.inc"
+}  // namespace h2x
+#endif
+
+int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s) {
+#ifdef MNRF_SPLIT_BIG_CHUNKS
+    if (variant == 1) return h2x::launch(A, sigma_only, grad, s);
+#endif
+    (void)variant;
+    return h2::launch(A, sigma_only, grad, s);
+}
+
+// ------------------------------------------------------------------ split-stream packer
+// One thread per f16 of the split streams.  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l
+// of the part's fp32 tile (2T + (j>>2), nb); hi = f16(w) (round to nearest), lo = f16(w - hi).
+__global__ void split_pack_kernel(float* packed, PartTable T) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr long long FWD_HALVES = (long long)SPLIT_FWD_PAIRS * (PAIR_BYTES / 2);
+    constexpr long long BWD_HALVES = (long long)SPLIT_BWD_PAIRS * (PAIR_BYTES / 2);
+    if (q >= FWD_HALVES + BWD_HALVES) return;
+    const bool bwd = q >= FWD_HALVES;
+    const long long r = bwd ? q - FWD_HALVES : q;
+    const int pair = (int)(r / (PAIR_BYTES / 2));
+    const int within = (int)(r % (PAIR_BYTES / 2));
+    const bool is_lo = within >= 512;
+    const int lane = (within & 511) >> 3, j = within & 7;
+    const Part* parts = bwd ? T.bwd : T.fwd;
+    const int nparts = bwd ? N_BWD_PARTS : N_FWD_PARTS;
+    int k = 0, pair0 = 0;
+    for (;;) {
+        const int np = padded_pairs(parts[k].ntq / 2 * parts[k].nb);
+        if (k + 1 >= nparts || pair < pair0 + np) break;
+        pair0 += np;
+        ++k;
+    }
+    const Part pt = parts[k];
+    const int lp = pair - pair0;
+    const int Tq = lp / pt.nb, nb = lp % pt.nb;
+    float w = 0.f;
+    if (Tq < pt.ntq / 2) {
+        const long long tile = pt.tile0 + (long long)(2 * Tq + (j >> 2)) * pt.nb + nb;
+        w = packed[(bwd ? OFF_BWD : OFF_FWD) + tile * TILE_FLOATS + lane * 4 + (j & 3)];
+    }
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    _Float16* dst = (_Float16*)(packed + (bwd ? OFF_SPLIT_BWD : OFF_SPLIT_FWD));
+    dst[r] = is_lo ? lo : hi;
+}
+
+void launch_split_pack(float* packed, hipStream_t s) {
+    PartTable T;
+    build_parts(T);
+    const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS) * (PAIR_BYTES / 2);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, packed, T);
+}
+
+}  // namespace mnrf

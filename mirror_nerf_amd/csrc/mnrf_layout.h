@@ -95,7 +95,25 @@ constexpr int64_t OFF_FWD = 0;
 constexpr int64_t OFF_BIAS = (int64_t)FWD_TILES * TILE_FLOATS;
 constexpr int64_t OFF_BWD = OFF_BIAS + BIAS_FLOATS;
 constexpr int64_t OFF_HBWD = OFF_BWD + (int64_t)BWD_TILES * TILE_FLOATS;
-constexpr int64_t PACKED_FLOATS = OFF_HBWD + (int64_t)HBWD_TILES * TILE_FLOATS;
+constexpr int64_t PACKED_F32_FLOATS = OFF_HBWD + (int64_t)HBWD_TILES * TILE_FLOATS;
+
+// ---- split-f16 streams (mnrf_field_split.inc): every fp32 weight w is stored as the f16 pair
+//      hi = f16(w), lo = f16(w - hi) (22 significand bits together; f16 subnormals are honoured by the
+//      gfx950 MFMA, measured in scripts/exp_f16split.hip) and a Linear is evaluated as
+//      hi.hi + lo.hi + hi.lo on v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+//      One MFMA contracts 32 columns = two fp32 k-blocks: half j of lane l of "pair" (T, nb) is float
+//      (j&3) of lane l of the fp32 tile (2T + (j>>2), nb) -- the fp32 B operands 8T..8T+7 of a lane,
+//      in order, are the 8 halves of its f16 B operand, so activations still never leave their lane.
+//      A pair = [hi tile 1 KiB][lo tile 1 KiB]; parts are padded to PAD_PAIRS pairs.
+constexpr int PAIR_BYTES = 2048;
+constexpr int PAD_PAIRS = 16;
+__host__ __device__ constexpr int padded_pairs(int n) { return (n + PAD_PAIRS - 1) / PAD_PAIRS * PAD_PAIRS; }
+constexpr int SPLIT_FWD_PAIRS_SIGMA = 32 + 3 * 128 + (32 + 128) + 3 * 128 + 16;                   // 976
+constexpr int SPLIT_FWD_PAIRS = SPLIT_FWD_PAIRS_SIGMA + 64 + 16 + 64 + 16 + 128 + 64 + 16 + 16;     // 1360
+constexpr int SPLIT_BWD_PAIRS = 3 * 128 + 32 + 128 + 3 * 128 + 32;                                  // 960
+constexpr int64_t OFF_SPLIT_FWD = PACKED_F32_FLOATS;
+constexpr int64_t OFF_SPLIT_BWD = OFF_SPLIT_FWD + (int64_t)SPLIT_FWD_PAIRS * (PAIR_BYTES / 4);
+constexpr int64_t PACKED_FLOATS = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4);
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order
 constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)
@@ -127,5 +145,54 @@ constexpr int TRUNK_FWD_TILES = 64 + 3 * 256 + 320 + 3 * 256;   // forward strea
 
 static_assert(FWD_TILES % PAD_TILES == 0 && FWD_TILES_SIGMA % PAD_TILES == 0, "chunking");
 static_assert(BWD_TILES % PAD_TILES == 0 && HBWD_TILES % PAD_TILES == 0, "chunking");
+
+// ---- part tables of the three fp32 streams (tile0 = first tile of the part inside its stream)
+struct PartTable {
+    Part fwd[N_FWD_PARTS];
+    Part bwd[N_BWD_PARTS];
+    Part hbwd[N_HBWD_PARTS];
+};
+
+__host__ __device__ inline void build_parts(PartTable& T) {
+    int n = 0, tile = 0;
+    auto add = [&](Part* arr, int& cnt, int param, int n_true, int ld, int ntq, int nb, int col_off, int kind) {
+        arr[cnt] = Part{param, n_true, ld, ntq, nb, col_off, kind, tile};
+        tile += padded_tiles(ntq * nb);
+        cnt++;
+    };
+    add(T.fwd, n, 0, 256, 63, 4, 16, 0, KIND_ENC);                             // L1
+    for (int i = 1; i < 4; ++i) add(T.fwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // L2..L4
+    add(T.fwd, n, 8, 256, 319, 4, 16, 0, KIND_ENC);                            // L5 encoding columns
+    add(T.fwd, n, 8, 256, 319, 16, 16, 63, KIND_H);                            // L5 hidden columns
+    for (int i = 5; i < 8; ++i) add(T.fwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // L6..L8
+    add(T.fwd, n, 20, 1, 256, 16, 1, 0, KIND_H);                               // sigma
+    add(T.fwd, n, 24, 128, 256, 16, 8, 0, KIND_H);                             // normal_net.0
+    add(T.fwd, n, 26, 3, 128, 8, 1, 0, KIND_H);                                // normal_net.1
+    add(T.fwd, n, 28, 128, 256, 16, 8, 0, KIND_H);                             // is_mirror_net.0
+    add(T.fwd, n, 30, 1, 128, 8, 1, 0, KIND_H);                                // is_mirror_net.2
+    add(T.fwd, n, 16, 256, 256, 16, 16, 0, KIND_H);                            // xyz_encoding_final
+    add(T.fwd, n, 18, 128, 283, 16, 8, 0, KIND_H);                             // dir_encoding: final part
+    add(T.fwd, n, 18, 128, 283, 2, 8, 256, KIND_DIR);                          // dir_encoding: view part
+    add(T.fwd, n, 22, 3, 128, 8, 1, 0, KIND_H);                                // rgb
+    // backward: A = W_i^T, rows = input columns of layer i, contraction over its 256 outputs
+    n = 0;
+    tile = 0;
+    for (int i = 7; i >= 5; --i) add(T.bwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // layers 8,7,6
+    add(T.bwd, n, 8, 256, 319, 16, 4, 0, KIND_ENC);                             // layer 5: 4 encoding row blocks
+    add(T.bwd, n, 8, 256, 319, 16, 16, ENC_XYZ, KIND_H);                        // layer 5: 16 hidden row blocks
+    for (int i = 3; i >= 1; --i) add(T.bwd, n, 2 * i, 256, 256, 16, 16, 0, KIND_H);  // layers 4,3,2
+    add(T.bwd, n, 0, 256, 63, 16, 4, 0, KIND_ENC);                              // layer 1: 4 encoding row blocks
+    // head backward (training): n_true = rows of W = contraction length, nb = 16-blocks of W's columns
+    n = 0;
+    tile = 0;
+    add(T.hbwd, n, 22, 3, 128, 1, 8, 0, KIND_H);        // rgb^T
+    add(T.hbwd, n, 18, 128, 283, 8, 16, 0, KIND_H);     // dir_encoding^T, xyz_encoding_final columns
+    add(T.hbwd, n, 18, 128, 283, 8, 2, 256, KIND_DIR);  // dir_encoding^T, view-encoding columns
+    add(T.hbwd, n, 16, 256, 256, 16, 16, 0, KIND_H);    // xyz_encoding_final^T
+    add(T.hbwd, n, 26, 3, 128, 1, 8, 0, KIND_H);        // normal_net.1^T
+    add(T.hbwd, n, 24, 128, 256, 8, 16, 0, KIND_H);     // normal_net.0^T
+    add(T.hbwd, n, 30, 1, 128, 1, 8, 0, KIND_H);        // is_mirror_net.2^T
+    add(T.hbwd, n, 28, 128, 256, 8, 16, 0, KIND_H);     // is_mirror_net.0^T
+}
 
 }  // namespace mnrf

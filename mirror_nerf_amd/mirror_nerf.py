@@ -7,6 +7,8 @@ reference checkpoints load with `load_state_dict`).  `forward` does no arithmeti
 Python: it hands pointers to `mnrf_field_forward`.  Outputs carry no autograd history
 (inference / forward path; see DESIGN.md "out of scope this round").
 """
+import os
+
 import torch
 from torch import nn
 
@@ -32,6 +34,22 @@ class Embedding(nn.Module):
             _lib.check(_lib.lib().mnrf_embed(_lib.ptr(x), n, c, self.N_freqs, _lib.ptr(out), _lib.stream()),
                        "mnrf_embed")
         return out
+
+
+# Arithmetic of the field kernel's Linears (inference launches):
+#   "fp32"  -- v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain (default);
+#   "split" -- every fp32 operand carried as a hi/lo f16 pair on the f16 matrix pipe with fp32 accumulation
+#              (MNRF_SPLIT_F16; ~1e-6 relative, see csrc/mnrf_field_split.inc).
+# The training forward (saved activations) always runs the fp32 kernel.
+PRECISION = os.environ.get("MNRF_PRECISION", "fp32")
+
+
+def set_precision(mode):
+    """Select the arithmetic of the inference field kernel: "fp32" or "split"."""
+    global PRECISION
+    if mode not in ("fp32", "split", "splitx"):
+        raise ValueError("precision must be 'fp32' or 'split'")
+    PRECISION = mode
 
 
 # When a list is installed here, every field-kernel launch is bracketed by two events on the
@@ -62,6 +80,10 @@ def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, 
     if want_geo:
         out["geo_feat"] = f(B, 256)
     flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
+    if PRECISION == "split":
+        flags |= _lib.MNRF_SPLIT_F16
+    elif PRECISION == "splitx":   # experiments only
+        flags |= _lib.MNRF_SPLIT_F16 | 8
     p = _lib.ptr
     if LAUNCH_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
