@@ -29,6 +29,10 @@ sys.path.insert(0, ROOT)
 H = W = 800
 N_SAMPLES, N_IMPORTANCE, CHUNK = 64, 128, 32768
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide, dense f16/bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+# MFMA FLOPs the split kernel EXECUTES per full sample: 1308 hi/lo tile pairs x 3 products x 2 groups x 4 waves x
+# 16384 FLOP per v_mfma_f32_16x16x32_f16 / 128 samples (= 3 x the padded fp32 count; algorithmic: MN.FLOP_FULL)
+SPLIT_EXECUTED_FLOP_FULL = 1308 * 3 * 2 * 4 * 16384 // 128
 # HBM bytes per full-kernel sample from the PMC passes in profiles/r01_pmc (FETCH_SIZE doubled per the
 # guide's gfx950 correction + WRITE_SIZE): (2 x 33758 + 196608) KiB / 6291456 samples
 PMC_HBM_BYTES_PER_FULL_SAMPLE = (2 * 33758 + 196608) * 1024 / 6291456
@@ -97,6 +101,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement")
+    ap.add_argument("--precision", choices=("split", "fp32"), default="split",
+                    help="arithmetic of the field kernel's Linears: fp32 operands as hi/lo f16 pairs on the f16 matrix "
+                         "pipe (default, ~1e-6 of fp32) or the bit-exact fp32 MFMA chain")
     a = ap.parse_args()
 
     import torch
@@ -114,6 +121,7 @@ def main():
     from mirror_nerf_amd import mirror_nerf as MN
     from oracle import mirror_nerf_oracle as O
 
+    MN.set_precision(a.precision)
     models, sds, emb = build_models(dev)
     # every rank renders its own view: same camera model, pose rotated about z by the rank index
     pose = O.look_at_pose(eye=(4.0 * np.sin(0.3 * rank), -4.0 * np.cos(0.3 * rank), 1.5))
@@ -164,16 +172,36 @@ def main():
     ms_sig = sum(t for _, t in sig)
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
 
+    # the other arithmetic on one fine-pass launch of the same chunk size, for the record
+    other = "fp32" if a.precision == "split" else "split"
+    other_tf = None
+    if rank == 0:
+        MN.set_precision(other)
+        MN.LAUNCH_LOG = []
+        with torch.no_grad():
+            for _ in range(3):
+                M.render_rays(models, emb, rays[:CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, test_time=True,
+                              compute_normal=False)
+        torch.cuda.synchronize()
+        t_o = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG[2:] if not (flags & 1)]
+        other_tf = sum(B for B, _ in t_o) * MN.FLOP_FULL / (sum(t for _, t in t_o) * 1e-3) / 1e12
+        MN.LAUNCH_LOG = None
+        MN.set_precision(a.precision)
+
     train = None
     if not a.no_train:
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
 
     if rank == 0:
+        split = a.precision == "split"
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         res = {
             "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 carried as hi/lo f16 pairs (f16 MFMA, f32 accumulate; max |diff| to the fp32 chain 3e-6)"
+                     if split else "f32",
             "data": "synthetic",
             "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
                                    "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
@@ -181,12 +209,20 @@ def main():
                        "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames"},
             "samples_per_s": value * evals_per_ray,
             "field_evals_per_ray": evals_per_ray,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         "peak_note": ("dense f16 MFMA peak; `achieved` counts ALGORITHMIC fp32 FLOPs (1 318 912 per sample), "
+                                       "the kernel executes 3 f16 products per fp32 product") if split else "fp32 MFMA peak",
+                         "executed_tflops": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL),
+                         "executed_frac": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL) / peak,
+                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_HBM_BYTES_PER_FULL_SAMPLE * (sum(B for B, _ in full) / max(1, len(full))),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/r01_pmc), "
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/), "
                                          "not re-measured in this run; algorithmic bytes are 36 B/sample",
-                         "kernel": "mnrf::field_kernel<false,false> (full 4-head evaluation, fine pass)",
+                         "kernel": ("mnrf::h2::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>")
+                                   + " (full 4-head evaluation, fine pass)",
+                         "other_precision": {"precision": other, "achieved": other_tf,
+                                             "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS},
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
                          "flop_per_sample": MN.FLOP_FULL,
                          "sigma_only_kernel_tflops": sig_tf,

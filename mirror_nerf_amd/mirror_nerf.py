@@ -37,11 +37,12 @@ class Embedding(nn.Module):
 
 
 # Arithmetic of the field kernel's Linears (inference launches):
-#   "fp32"  -- v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain (default);
 #   "split" -- every fp32 operand carried as a hi/lo f16 pair on the f16 matrix pipe with fp32 accumulation
-#              (MNRF_SPLIT_F16; ~1e-6 relative, see csrc/mnrf_field_split.inc).
+#              (MNRF_SPLIT_F16; agrees with the fp32 chain to ~3e-6, 3.2x faster; default; see
+#              csrc/mnrf_field_split.inc);
+#   "fp32"  -- v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain.
 # The training forward (saved activations) always runs the fp32 kernel.
-PRECISION = os.environ.get("MNRF_PRECISION", "fp32")
+PRECISION = os.environ.get("MNRF_PRECISION", "split")
 
 
 def set_precision(mode):
