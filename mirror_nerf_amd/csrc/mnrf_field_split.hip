@@ -13,27 +13,14 @@ namespace mnrf {
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-// h2: 32 samples per wave, one wave per SIMD; 16 KiB chunks, 48 KiB ring
+// h2: 32 samples per wave, one wave per SIMD; 16 KiB chunks, 64 KiB ring of four slots
 namespace h2 {
 constexpr int S = 2;
 constexpr int MIN_WAVES_PER_SIMD = 1;
 constexpr int CHUNK_PAIRS = 8;
 #include "mnrf_field_split.inc"
 }  // namespace h2
-#ifdef MNRF_SPLIT_BIG_CHUNKS
-// h2x: 32 KiB chunks, 96 KiB ring (half the barriers; needs LDS-DMA destinations above 64 KiB)
-namespace h2x {
-constexpr int S = 2;
-constexpr int MIN_WAVES_PER_SIMD = 1;
-constexpr int CHUNK_PAIRS = 16;
-#include "mnrf_field_split.inc"
-}  // namespace h2x
-#endif
-
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s) {
-#ifdef MNRF_SPLIT_BIG_CHUNKS
-    if (variant == 1) return h2x::launch(A, sigma_only, grad, s);
-#endif
     (void)variant;
     return h2::launch(A, sigma_only, grad, s);
 }

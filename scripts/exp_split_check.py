@@ -25,13 +25,26 @@ for sigma_only, grad in ((False, False), (True, False), (False, True)):
         MN.LAUNCH_LOG = []
         for _ in range(3):
             o = MN.field_forward(m, B, rays=rays, z_vals=z, spr=192, dir_emb=de, dir_stride=27,
-                                 sigma_only=sigma_only, grad_normal=grad)
+                                 sigma_only=sigma_only, grad_normal=grad, want_geo=bool(os.environ.get("MNRF_EXP_CYCLES")))
         torch.cuda.synchronize()
         ms = min(e0.elapsed_time(e1) for _, _, e0, e1 in MN.LAUNCH_LOG[1:])
         flop = B * ((MN.FLOP_SIGMA if sigma_only else MN.FLOP_FULL) + (MN.FLOP_GRAD if grad else 0))
         print(f"sigma_only={sigma_only} grad={grad} {mode}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s algorithmic  "
               f"{B / ms / 1e3:.1f} M samples/s")
         res[mode] = o
+        if os.environ.get("MNRF_EXP_CYCLES") and mode != "fp32":   # library built with -DMNRF_EXP_CYCLES: s_memtime per tile
+            mk = o.pop("geo_feat").view(-1).view(torch.int64)[: (B // 128) * 16].view(-1, 16).double()
+            names = {1: "prologue", 2: "L1", 3: "L2-4", 4: "L5", 5: "L6-8", 6: "sigma", 7: "normal", 8: "mirror", 9: "final",
+                     10: "dir+rgb", 15: "rest (grad pass)"}
+            prev, line = 0, []
+            for k in sorted(names):
+                if sigma_only and 7 <= k <= 10:
+                    continue
+                line.append(f"{names[k]} {(mk[:, k] - mk[:, prev]).mean().item():.0f}")
+                prev = k
+            tot = (mk[:, 15] - mk[:, 0]).mean().item()
+            print("   cycles per 128-sample tile: " + " | ".join(line) + f" | total {tot:.0f}"
+                  f"  -> clock {tot * (B // 128) / 256 / (ms * 1e-3) / 1e9:.3f} GHz if the 256 CUs were always busy")
     for mode in list(res)[1:]:
       for k in res["fp32"]:
         a, b = res["fp32"][k], res[mode][k]
