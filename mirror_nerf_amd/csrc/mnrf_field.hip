@@ -166,14 +166,14 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
     // Tunings.  fp32 MFMA (bit-exact fmaf chains): s2 (32 samples/wave, one wave per SIMD) is fastest for the
     // forward-only kernels, s1 (16 samples/wave, two workgroups per CU) for the ones with the density-gradient
     // pass.  MNRF_SPLIT_F16 selects the split-f16 tuning (fp32 operands as hi/lo f16 pairs on the f16 matrix
-    // pipe).  MNRF_FIELD_VARIANT=s1|s2|h|hx forces one (experiments).
+    // pipe).  MNRF_FIELD_VARIANT=s1|s2|h|h2|hx forces one (experiments; h = split with its own default).
     static const int forced = [] {
         const char* e = getenv("MNRF_FIELD_VARIANT");
         if (e && e[0] == 's' && (e[1] == '1' || e[1] == '2')) return e[1] - '0';
-        if (e && e[0] == 'h') return e[1] == 'x' ? 4 : 3;
+        if (e && e[0] == 'h') return e[1] == 'x' ? 5 : (e[1] == '2' ? 4 : 3);
         return 0;
     }();
-    const int variant = forced ? forced : ((flags & MNRF_SPLIT_F16) ? ((flags & 8u) ? 4 : 3) : (grad ? 1 : 2));   // 8u: experimental big-chunk tuning
+    const int variant = forced ? forced : ((flags & MNRF_SPLIT_F16) ? 3 + (int)((flags >> 3) & 3u) : (grad ? 1 : 2));   // bits 3-4: experimental split tunings
     const int rc = variant >= 3 ? launch_split(A, sigma_only, grad, variant - 3, (hipStream_t)stream)
                  : variant == 1 ? s1::launch(A, sigma_only, grad, (hipStream_t)stream)
                                 : s2::launch(A, sigma_only, grad, (hipStream_t)stream);

@@ -18,11 +18,24 @@ namespace h2 {
 constexpr int S = 2;
 constexpr int MIN_WAVES_PER_SIMD = 1;
 constexpr int CHUNK_PAIRS = 8;
+constexpr int RING_SLOTS = 4;
 #include "mnrf_field_split.inc"
 }  // namespace h2
+// h2x: 32 KiB chunks (half the seams), 96 KiB ring of three slots
+namespace h2x {
+constexpr int S = 2;
+constexpr int MIN_WAVES_PER_SIMD = 1;
+constexpr int CHUNK_PAIRS = 16;
+constexpr int RING_SLOTS = 3;
+#include "mnrf_field_split.inc"
+}  // namespace h2x
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s) {
-    (void)variant;
-    return h2::launch(A, sigma_only, grad, s);
+    // variant 0: measured default -- 16 KiB chunks for the forward-only kernels (17.2 vs 17.3 ms per 6.29 M full
+    // samples), 32 KiB chunks when the density-gradient pass is on (32.1 vs 34.1 ms); 1 / 2 force h2 / h2x.
+    // A 16-samples-per-wave tuning with two workgroups per CU (as s1 of the fp32 kernel) was tried and dropped:
+    // 18.2 / 32.5 ms -- it hides the waits but issues twice the LDS-DMA per sample.
+    const bool big = variant == 0 ? grad : variant == 2;
+    return big ? h2x::launch(A, sigma_only, grad, s) : h2::launch(A, sigma_only, grad, s);
 }
 
 // ------------------------------------------------------------------ split-stream packer

@@ -113,8 +113,8 @@ constexpr int SPLIT_FWD_PAIRS = SPLIT_FWD_PAIRS_SIGMA + 64 + 16 + 64 + 16 + 128 
 constexpr int SPLIT_BWD_PAIRS = 3 * 128 + 32 + 128 + 3 * 128 + 32;                                  // 960
 constexpr int64_t OFF_SPLIT_FWD = PACKED_F32_FLOATS;
 constexpr int64_t OFF_SPLIT_BWD = OFF_SPLIT_FWD + (int64_t)SPLIT_FWD_PAIRS * (PAIR_BYTES / 4);
-// tail pad: the split kernel's static LDS-DMA schedule reads two 16 KiB chunks past the end of a stream
-constexpr int64_t SPLIT_TAIL_FLOATS = 2 * 8 * (PAIR_BYTES / 4);
+// tail pad: the split kernel's static LDS-DMA schedule reads two chunks (of up to 32 KiB) past the end of a stream
+constexpr int64_t SPLIT_TAIL_FLOATS = 2 * 16 * (PAIR_BYTES / 4);
 constexpr int64_t PACKED_FLOATS = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order

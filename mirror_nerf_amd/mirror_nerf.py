@@ -48,7 +48,7 @@ PRECISION = os.environ.get("MNRF_PRECISION", "split")
 def set_precision(mode):
     """Select the arithmetic of the inference field kernel: "fp32" or "split"."""
     global PRECISION
-    if mode not in ("fp32", "split", "splitx"):
+    if mode not in ("fp32", "split", "split_h2", "split_h2x"):
         raise ValueError("precision must be 'fp32' or 'split'")
     PRECISION = mode
 
@@ -83,8 +83,10 @@ def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, 
     flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
     if PRECISION == "split":
         flags |= _lib.MNRF_SPLIT_F16
-    elif PRECISION == "splitx":   # experiments only
+    elif PRECISION == "split_h2":    # experiments only: force 16 KiB chunks
         flags |= _lib.MNRF_SPLIT_F16 | 8
+    elif PRECISION == "split_h2x":   # experiments only: force 32 KiB chunks
+        flags |= _lib.MNRF_SPLIT_F16 | 16
     p = _lib.ptr
     if LAUNCH_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

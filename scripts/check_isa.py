@@ -17,6 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "mirror_nerf_amd", "csrc", "mnrf_field.hip")
+SRC_SPLIT = os.path.join(ROOT, "mirror_nerf_amd", "csrc", "mnrf_field_split.hip")
 
 
 def main():
@@ -39,6 +40,31 @@ def main():
               f"{len(smem)} scalar loads inside, {len(scratch)} scratch ops inside")
         if smem or (scratch and not grad) or counted < 100:
             ok = False
+    # split-f16 kernels: same rule for their counted lgkmcnt waits; M0 is written by hand for the LDS-DMA pieces,
+    # so nothing else may touch it; and nothing may spill
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "split.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-S",
+                        "--cuda-device-only", SRC_SPLIT, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    n = 0
+    for m in re.finditer(r"^(_ZN4mnrf\d+h2x?18field_split_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        mf = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_f16" in l]
+        inner = body[mf[0]:mf[-1] + 1]
+        smem = [l for l in inner if re.search(r"\bs_(buffer_)?load_", l)]
+        scratch = [l for l in body if "scratch_" in l]
+        counted = sum(bool(re.search(r"s_waitcnt lgkmcnt\([24]\)", l)) for l in inner)
+        other_m0 = [l for l in body if re.search(r"\bm0\b", l) and "s_mov_b32 m0" not in l]
+        dma = sum("global_load_lds_dwordx4" in l for l in body)
+        print(f"{name}: {len(mf)} MFMA, {dma} LDS-DMA pieces, {counted} counted waits, {len(smem)} scalar loads inside, "
+              f"{len(scratch)} scratch ops, {len(other_m0)} other M0 uses")
+        n += 1
+        if smem or scratch or other_m0 or counted < 100:
+            ok = False
+    if n != 8:
+        print(f"expected 8 split kernels, found {n}")
+        ok = False
     if not ok:
         print("ISA CHECK FAILED")
         sys.exit(1)

@@ -20,7 +20,7 @@ de = emb["dir"](rays[:, 3:6].contiguous())
 B = 32768 * 192
 for sigma_only, grad in ((False, False), (True, False), (False, True)):
     res = {}
-    for mode in ("fp32", "split") + (("splitx",) if os.environ.get("MNRF_EXP_X") else ()):
+    for mode in ("fp32", "split") + (("split_h2", "split_h2x") if os.environ.get("MNRF_EXP_X") else ()):
         MN.set_precision(mode)
         MN.LAUNCH_LOG = []
         for _ in range(3):
