@@ -33,7 +33,8 @@ int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hi
     // variant 0: measured default -- 16 KiB chunks for the forward-only kernels (17.2 vs 17.3 ms per 6.29 M full
     // samples), 32 KiB chunks when the density-gradient pass is on (32.1 vs 34.1 ms); 1 / 2 force h2 / h2x.
     // A 16-samples-per-wave tuning with two workgroups per CU (as s1 of the fp32 kernel) was tried and dropped:
-    // 18.2 / 32.5 ms -- it hides the waits but issues twice the LDS-DMA per sample.
+    // 18.2 / 32.5 ms -- it hides the waits but issues twice the LDS-DMA per sample.  So was a 48-samples-per-wave tuning
+    // (a third less LDS-DMA per sample): it needs all 512 registers, spills 200 bytes and ends up 1 % slower.
     const bool big = variant == 0 ? grad : variant == 2;
     return big ? h2x::launch(A, sigma_only, grad, s) : h2::launch(A, sigma_only, grad, s);
 }
@@ -52,18 +53,33 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     const int within = (int)(r % (PAIR_BYTES / 2));
     const bool is_lo = within >= 512;
     const int lane = (within & 511) >> 3, j = within & 7;
+    // Segments of the forward stream: the nine trunk parts (L1, L2-4, L5 encoding, L5 hidden, L6-8) are stored in two
+    // HALVES of 8 row blocks each (mnrf_field_split.inc: the kernel evaluates a trunk layer half by half), L5's two
+    // parts interleaved by half; the head parts and the whole backward stream are stored part by part.
     const Part* parts = bwd ? T.bwd : T.fwd;
-    const int nparts = bwd ? N_BWD_PARTS : N_FWD_PARTS;
-    int k = 0, pair0 = 0;
-    for (;;) {
-        const int np = padded_pairs(parts[k].ntq / 2 * parts[k].nb);
-        if (k + 1 >= nparts || pair < pair0 + np) break;
-        pair0 += np;
-        ++k;
+    int k = 0, half = -1, pair0 = 0;
+    if (bwd) {
+        for (;;) {
+            const int np = padded_pairs(parts[k].ntq / 2 * parts[k].nb);
+            if (k + 1 >= N_BWD_PARTS || pair < pair0 + np) break;
+            pair0 += np;
+            ++k;
+        }
+    } else {
+        const signed char seg_part[27] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 5, 4, 5, 6, 6, 7, 7, 8, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+        const signed char seg_half[27] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 0, 1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+        for (int sg = 0;; ++sg) {
+            k = seg_part[sg];
+            half = seg_half[sg];
+            const int np = padded_pairs(parts[k].ntq / 2 * (half >= 0 ? 8 : parts[k].nb));
+            if (sg + 1 >= 27 || pair < pair0 + np) break;
+            pair0 += np;
+        }
     }
     const Part pt = parts[k];
     const int lp = pair - pair0;
-    const int Tq = lp / pt.nb, nb = lp % pt.nb;
+    const int rows = half >= 0 ? 8 : pt.nb;
+    const int Tq = lp / rows, nb = (half >= 0 ? 8 * half : 0) + lp % rows;
     float w = 0.f;
     if (Tq < pt.ntq / 2) {
         const long long tile = pt.tile0 + (long long)(2 * Tq + (j >> 2)) * pt.nb + nb;

@@ -20,7 +20,8 @@ de = emb["dir"](rays[:, 3:6].contiguous())
 B = 32768 * 192
 for sigma_only, grad in ((False, False), (True, False), (False, True)):
     res = {}
-    for mode in ("fp32", "split") + (("split_h2", "split_h2x") if os.environ.get("MNRF_EXP_X") else ()):
+    tile_samples = 128
+    for mode in ("fp32", "split") + (tuple(os.environ["MNRF_EXP_X"].split(",")) if os.environ.get("MNRF_EXP_X") else ()):
         MN.set_precision(mode)
         MN.LAUNCH_LOG = []
         for _ in range(3):
@@ -33,7 +34,7 @@ for sigma_only, grad in ((False, False), (True, False), (False, True)):
               f"{B / ms / 1e3:.1f} M samples/s")
         res[mode] = o
         if os.environ.get("MNRF_EXP_CYCLES") and mode != "fp32":   # library built with -DMNRF_EXP_CYCLES: s_memtime per tile
-            mk = o.pop("geo_feat").view(-1).view(torch.int64)[: (B // 128) * 16].view(-1, 16).double()
+            mk = o.pop("geo_feat").view(-1).view(torch.int64)[: (B // tile_samples) * 16].view(-1, 16).double()
             names = {1: "prologue", 2: "L1", 3: "L2-4", 4: "L5", 5: "L6-8", 6: "sigma", 7: "normal", 8: "mirror", 9: "final",
                      10: "dir+rgb", 15: "rest (grad pass)"}
             prev, line = 0, []
@@ -44,7 +45,7 @@ for sigma_only, grad in ((False, False), (True, False), (False, True)):
                 prev = k
             tot = (mk[:, 15] - mk[:, 0]).mean().item()
             print("   cycles per 128-sample tile: " + " | ".join(line) + f" | total {tot:.0f}"
-                  f"  -> clock {tot * (B // 128) / 256 / (ms * 1e-3) / 1e9:.3f} GHz if the 256 CUs were always busy")
+                  f"  -> clock {tot * (B // tile_samples) / 256 / (ms * 1e-3) / 1e9:.3f} GHz if the 256 CUs were always busy")
     for mode in list(res)[1:]:
       for k in res["fp32"]:
         a, b = res["fp32"][k], res[mode][k]
