@@ -192,6 +192,8 @@ def main():
     if not a.no_train:
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
+        full = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
+        train["with_total_loss"] = {k: full[k] for k in ("value", "ms_per_step", "loss", "loss_fn")}
 
     if rank == 0:
         split = a.precision == "split"

@@ -218,6 +218,53 @@ int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double 
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
                        float* rays, void* stream);
 
+/* ---- loss reductions of the training step (losses.py:7-255: ColorLoss, MirrorMaskLoss, PlaneConsistentLoss,
+ * NormalLoss, NormalRegLoss, TotalLoss), value and gradient in one pass.  Index [0] = coarse, [1] = fine; a null
+ * input pointer = "key absent from the result dict" (losses.py tests `f"rgb_{typ}" in inputs`).  Every g_* buffer
+ * receives d(total)/d(input) (same shape as the input; may be null).  `out` (6 floats): color, mirror_mask, plane,
+ * normal, normal_reg (each already multiplied by its coefficient; 0 when the term is switched off), total.
+ * In the train_geometry_stage / invalid-GT branch of ColorLoss the reference thresholds the predicted mask IN PLACE
+ * (losses.py:27-33, a detach() shares storage); so does this entry point: mirror_mask[] is not const. */
+#define MNRF_LOSS_GEOMETRY_STAGE 1u              /* train_geometry_stage */
+#define MNRF_LOSS_WO_MASK_RGB_TO_BLACK 2u        /* hparams.woMaskRGBtoBlack */
+#define MNRF_LOSS_NORMAL_ONLY_INSIDE_MIRROR 4u   /* hparams.normal_loss_only_inside_mirror */
+#define MNRF_LOSS_EXT_GRAD_NORMAL 8u             /* NormalRegLoss.ext_supervise_grad_normal (default on) */
+#define MNRF_LOSS_TCNN_BCE 16u                   /* model_type == "nerf_tcnn": utils/func.py:32-37 instead of nn.BCELoss */
+#define MNRF_LOSS_USE_MASK 32u                   /* epoch gates of TotalLoss.forward (losses.py:233-249) */
+#define MNRF_LOSS_USE_PLANE 64u
+#define MNRF_LOSS_USE_NORMAL 128u
+typedef struct {
+    const float* rgb[2];          /* (N,3) */
+    float* mirror_mask[2];        /* (N)   */
+    const float* normal_dif[2];   /* (N)   */
+    const float* pred_normal[2];  /* (N,S,3) */
+    const float* weights[2];      /* (N,S) */
+    const float* x_surface[2];    /* (N,3) */
+    const float* normal_fine;     /* (N,S_fine,3) */
+    int n_samples[2];
+    const float* targets;         /* batch["rgbs"] (N,3) */
+    const float* gt_mask;         /* batch["mirror_mask"] (N) as float, < 0 = invalid; null = absent */
+    const float* rays;            /* batch["rays"] (N,8): directions in columns 3..5 */
+    const unsigned char* valid_mask;   /* batch["valid_mask"] (N) or null */
+    int64_t n_rays;
+    const int64_t* plane_idx[2];  /* (times,4) draws of torch.randint, rows of the GT-mirror subset */
+    int64_t plane_times[2];
+    float w_color, w_normal, w_normal_reg, w_mask, w_plane;
+    unsigned flags;
+    float* g_rgb[2];
+    float* g_mirror_mask[2];
+    float* g_normal_dif[2];
+    float* g_pred_normal[2];
+    float* g_weights[2];
+    float* g_x_surface[2];
+    float* g_normal_fine;
+    float* out;
+} MnrfLossArgs;
+int64_t mnrf_loss_workspace_floats(int64_t n_rays, int n_samples_coarse, int n_samples_fine, int64_t plane_times);
+int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void* stream);
+/* counts only: workspace[0] = #rays with gt < 0, workspace[1] = #rays with gt != 0 (what the plane loss draws from) */
+int mnrf_loss_count(const MnrfLossArgs* args, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

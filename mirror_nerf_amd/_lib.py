@@ -62,6 +62,9 @@ SIGNATURES = {
                                     _c_i, _c_f, _str]),
     "mnrf_blend_scatter": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _int, _c_f, _c_f, _str]),
     "mnrf_generate_rays": (_int, [_int, _int, _flt, ctypes.POINTER(ctypes.c_float), _flt, _flt, _c_f, _str]),
+    "mnrf_loss_workspace_floats": (_i64, [_i64, _int, _int, _i64]),
+    "mnrf_total_loss": (_int, [ctypes.c_void_p, _c_f, _str]),     # const MnrfLossArgs* (losses._Args)
+    "mnrf_loss_count": (_int, [ctypes.c_void_p, _c_f, _str]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@ algorithm in the reference files
     eval.py                 batched_inference core (114-172, 293-360, 506-548, 614-740)
     datasets/ray_utils.py   get_ray_directions / get_rays (6-53)
     metrics.py              psnr (5-15)
+    losses.py               ColorLoss, NormalLoss, PlaneConsistentLoss, NormalRegLoss, MirrorMaskLoss, TotalLoss (7-255)
 
 Parity status: PINNED.  `tests/golden/make_golden.py` imports the reference in
 the build container, captures inputs/outputs into `tests/golden/*.npz`, and
@@ -652,6 +653,154 @@ def synthetic_rays(H, W, near=0.05, far=8.0, camera_angle_x=0.6911112):
 def psnr(pred, gt):
     """metrics.py:5-15."""
     return float(-10.0 * np.log10(np.mean((np.asarray(pred, F64) - np.asarray(gt, F64)) ** 2)))
+
+
+# --------------------------------------------------------------------------
+# losses (losses.py:7-255)
+# --------------------------------------------------------------------------
+LOSS_DEFAULTS = dict(color_loss_weight=1.0, woMaskRGBtoBlack=False, normal_loss_weight=1e-4,
+                     normal_loss_only_inside_mirror=False, normal_reg_loss_weight=0.1, mirror_mask_loss_weight=0.1,
+                     model_type="nerf", use_plane_consistent_loss=False, plane_consistent_loss_weight=0.1,
+                     smooth_mirror_start_epoch=2, train_mirror_mask_start_epoch=2, train_normal_start_epoch=1)   # opt.py:207-243
+
+
+def _mean(x):
+    """torch's mean of an empty selection is nan (0/0), numpy's warns: restate it explicitly."""
+    x = np.asarray(x, F32)
+    return F32(np.nan) if x.size == 0 else F32(x.mean(dtype=F32))
+
+
+def _mse(a, b):
+    return _mean((a - b) ** 2)      # nn.MSELoss(reduction="mean") over rows x 3
+
+
+def color_loss(inputs, batch, hp, train_geometry_stage=False):
+    """losses.py:7-51.  In the train_geometry_stage branch with an invalid GT mask (any entry < 0) the reference thresholds
+    `inputs["mirror_mask_fine"].detach()` IN PLACE (detach shares storage, losses.py:27-33): the dict entry the mask
+    loss reads afterwards holds the thresholded values.  Restated as such: `inputs` is mutated."""
+    targets = batch["rgbs"].reshape(-1, 3)
+    gt = batch.get("mirror_mask")
+    loss = F32(0)
+    if train_geometry_stage and gt is not None and (gt < 0).any():
+        key = "mirror_mask_fine" if "mirror_mask_fine" in inputs else ("mirror_mask_coarse" if "mirror_mask_coarse" in inputs else None)
+        if key is not None:
+            m = inputs[key]
+            m[m > 0.5] = 1
+            m[m < 0.5] = 0
+            sel = ~(m != 0)             # .bool(): exactly 0.5 counts as mirror
+            for typ in ("coarse", "fine"):
+                if f"rgb_{typ}" in inputs:
+                    loss = loss + _mse(inputs[f"rgb_{typ}"][sel], targets[sel])
+    elif train_geometry_stage and gt is not None and hp["woMaskRGBtoBlack"]:
+        sel = ~(gt.reshape(-1) != 0)
+        for typ in ("coarse", "fine"):
+            if f"rgb_{typ}" in inputs:
+                loss = loss + _mse(inputs[f"rgb_{typ}"][sel], targets[sel])
+    else:
+        for typ in ("coarse", "fine"):
+            if f"rgb_{typ}" in inputs:
+                loss = loss + _mse(inputs[f"rgb_{typ}"], targets)
+    return F32(hp["color_loss_weight"]) * loss
+
+
+def normal_loss(inputs, batch, hp):
+    """losses.py:54-78."""
+    gt = batch.get("mirror_mask")
+    mm = (gt.reshape(-1) != 0) if (gt is not None and not (gt < 0).any()) else None
+    loss = F32(0)
+    for typ in ("coarse", "fine"):
+        k = f"normal_dif_{typ}"
+        if k not in inputs:
+            continue
+        if mm is not None:
+            if not hp["normal_loss_only_inside_mirror"]:
+                loss = loss + _mean(inputs[k][~mm])
+            loss = loss + _mean(inputs[k][mm]) * F32(100)
+        else:
+            loss = loss + _mean(inputs[k])
+    return F32(hp["normal_loss_weight"]) * loss
+
+
+def plane_consistent_loss(inputs, batch, hp, plane_idx):
+    """losses.py:81-130.  `plane_idx[typ]` (times, 4) are the reference's torch.randint draws, "fine" first
+    (4 draws per iteration, in order); rows index the x_surface points INSIDE the GT mirror mask."""
+    gt = batch.get("mirror_mask")
+    mm = (gt.reshape(-1) != 0) if (gt is not None and not (gt < 0).any()) else None
+    loss = F32(0)
+    if mm is not None:
+        for typ in ("fine", "coarse"):
+            k = f"x_surface_{typ}"
+            if k not in inputs:
+                continue
+            pts = inputs[k][mm]
+            times = pts.shape[0] // 4
+            if times > 0:
+                ix = np.asarray(plane_idx[typ]).reshape(times, 4)
+                p0, p1, p2, p3 = (pts[ix[:, j]] for j in range(4))
+                tri = np.sum(np.cross(p1 - p0, p2 - p0).astype(F32) * (p3 - p0), -1, dtype=F32)
+                acc = F32(0)
+                for v in np.abs(tri):      # the reference accumulates one iteration at a time
+                    acc = F32(acc + v)
+                loss = loss + acc / F32(times)
+    return F32(hp["plane_consistent_loss_weight"]) * loss
+
+
+def normal_reg_loss(inputs, batch, hp, ext_supervise_grad_normal=True):
+    """losses.py:134-172."""
+    rays_d = batch["rays"][..., 3:6].reshape(-1, 3)
+    mask = batch["valid_mask"].reshape(-1).astype(bool) if "valid_mask" in batch else np.ones(rays_d.shape[0], bool)
+    loss = F32(0)
+
+    def term(nkey, wkey):
+        n = inputs[nkey][mask]
+        t = np.maximum(n * rays_d[mask][:, None, :], F32(0)).sum(-1, dtype=F32) * inputs[wkey][mask]
+        return _mean(t)
+
+    for typ in ("coarse", "fine"):
+        if f"pred_normal_{typ}" in inputs:
+            loss = loss + term(f"pred_normal_{typ}", f"weights_{typ}")
+    if ext_supervise_grad_normal and "normal_fine" in inputs:
+        loss = loss + term("normal_fine", "weights_fine")
+    return F32(hp["normal_reg_loss_weight"]) * loss
+
+
+def mirror_mask_loss(inputs, batch, hp):
+    """losses.py:175-198.  nn.BCELoss clamps each log at -100; utils/func.py:32-37 (nerf_tcnn) does not."""
+    loss = F32(0)
+    if "mirror_mask" not in batch:
+        return loss
+    gt = batch["mirror_mask"].reshape(-1).astype(F32)
+    valid = (gt >= 0).astype(F32)
+    for typ in ("coarse", "fine"):
+        k = f"mirror_mask_{typ}"
+        if k not in inputs:
+            continue
+        p = np.clip(inputs[k].astype(F32), F32(1e-7), F32(1 - 1e-7))
+        with np.errstate(divide="ignore"):
+            lp, l1p = np.log(p), np.log(F32(1) - p)
+        if hp["model_type"] != "nerf_tcnn":
+            lp, l1p = np.maximum(lp, F32(-100)), np.maximum(l1p, F32(-100))
+        l_ = -(gt * lp + (F32(1) - gt) * l1p)
+        loss = loss + _mean(l_ * valid)
+    return F32(hp["mirror_mask_loss_weight"]) * loss
+
+
+def total_loss(inputs, batch, hp=None, train_geometry_stage=False, epoch=-1, plane_idx=None):
+    """losses.py:201-255 TotalLoss.forward -> (loss_sum, loss_dict).  `inputs` may be mutated (see color_loss)."""
+    h = dict(LOSS_DEFAULTS)
+    h.update(hp or {})
+    d = {"color_loss": color_loss(inputs, batch, h, train_geometry_stage)}
+    if not train_geometry_stage or epoch >= h["train_mirror_mask_start_epoch"]:
+        d["mirror_mask_loss"] = mirror_mask_loss(inputs, batch, h)
+    if epoch >= h["smooth_mirror_start_epoch"] and h["use_plane_consistent_loss"]:
+        d["plane_consistent_loss"] = plane_consistent_loss(inputs, batch, h, plane_idx)
+    if not train_geometry_stage or epoch >= h["train_normal_start_epoch"]:
+        d["normal_loss"] = normal_loss(inputs, batch, h)
+        d["normal_reg_loss"] = normal_reg_loss(inputs, batch, h)
+    total = F32(0)
+    for v in d.values():
+        total = F32(total + v)
+    return total, d
 
 
 # --------------------------------------------------------------------------

@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--loss", choices=("color_mask", "total"), default="color_mask",
+                help="total = the reference's TotalLoss through the fused HIP loss kernels (reads normal_*: second-order pass on)")
 a = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -26,7 +28,7 @@ if world > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES") == "1" and "RANK" in o
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=dev)
 rays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
-r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch)
+r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch, loss_name=a.loss)
 if int(os.environ.get("RANK", "0")) == 0:
     r["n_gpus"] = world
     print(json.dumps(r))
