@@ -265,6 +265,13 @@ int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void* stream);
 /* counts only: workspace[0] = #rays with gt < 0, workspace[1] = #rays with gt != 0 (what the plane loss draws from) */
 int mnrf_loss_count(const MnrfLossArgs* args, float* workspace, void* stream);
 
+/* metrics.py:5-15 on device: out[0] = mse = mean((pred - gt)^2) over the n elements whose mask byte is non-zero
+ * (mask may be null; element i uses mask[i / per_mask], so per_mask = 3 selects whole RGB pixels), out[1] = psnr =
+ * -10 log10(mse), out[2] = number of elements.  `partials`: 2 * mnrf_mse_blocks() floats.  Deterministic. */
+int mnrf_mse_blocks(void);
+int mnrf_mse_psnr(const float* pred, const float* gt, const unsigned char* mask, int64_t n, int per_mask,
+                  float* partials, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ SIGNATURES = {
     "mnrf_loss_workspace_floats": (_i64, [_i64, _int, _int, _i64]),
     "mnrf_total_loss": (_int, [ctypes.c_void_p, _c_f, _str]),     # const MnrfLossArgs* (losses._Args)
     "mnrf_loss_count": (_int, [ctypes.c_void_p, _c_f, _str]),
+    "mnrf_mse_blocks": (_int, []),
+    "mnrf_mse_psnr": (_int, [_c_f, _c_f, ctypes.c_void_p, _i64, _int, _c_f, _c_f, _str]),
 }
 
 _lib = None

@@ -316,7 +316,50 @@ __global__ void finish_kernel(FinishArgs F) {
     F.out[N_TERMS] = total;
 }
 
+// metrics.py:5-15: mse = mean((pred - gt)^2 [mask]), psnr = -10 log10(mse)
+__global__ void mse_partial_kernel(const float* a, const float* b, const unsigned char* mask, long long n, int per_mask,
+                                   float* partials) {
+    __shared__ float sh[TPB / 64];
+    float s = 0.f, c = 0.f;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        if (!mask || mask[i / per_mask]) {
+            const float d = a[i] - b[i];
+            s += d * d;
+            c += 1.f;
+        }
+    }
+    const float bs = block_sum(s, sh), bc = block_sum(c, sh);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = bs;
+        partials[2 * blockIdx.x + 1] = bc;
+    }
+}
+
+__global__ void mse_finish_kernel(const float* partials, int blocks, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f, c = 0.f;
+    for (int b = 0; b < blocks; ++b) { s += partials[2 * b]; c += partials[2 * b + 1]; }
+    const float m = s / c;                 // an empty selection is 0/0 = nan, like torch.mean
+    out[0] = m;
+    out[1] = -10.f * log10f(m);
+    out[2] = c;
+}
+
 }  // namespace
+
+extern "C" int mnrf_mse_blocks(void) { return 1024; }
+
+extern "C" int mnrf_mse_psnr(const float* pred, const float* gt, const unsigned char* mask, int64_t n, int per_mask,
+                             float* partials, float* out, void* stream) {
+    if (!pred || !gt || !partials || !out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_mse_psnr: null pointer");
+    if (n < 0 || per_mask < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_mse_psnr: bad size");
+    int64_t blocks = (n + TPB - 1) / TPB;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, pred, gt, mask,
+                       (long long)n, per_mask, partials);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)blocks, out);
+    return mnrf_check_launch("mnrf_mse_psnr");
+}
 
 extern "C" int64_t mnrf_loss_workspace_floats(int64_t n_rays, int n_samples_coarse, int n_samples_fine, int64_t plane_times) {
     const int64_t rb = (n_rays + TPB - 1) / TPB;

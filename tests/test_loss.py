@@ -129,3 +129,20 @@ def test_hip_total_loss_full_batch_properties():
     fd = (float(lp) - float(lm)) / (2 * eps)
     an = float((t["rgb_fine"].grad * d).sum())
     assert abs(fd - an) <= 2e-3 * max(abs(an), 1e-6), (fd, an)
+
+
+@pytest.mark.gpu
+def test_device_psnr_matches_oracle():
+    """metrics.py:5-15 on the device: full 800x800 frame, with and without a per-pixel mask."""
+    from mirror_nerf_amd import metrics
+    rs = np.random.RandomState(3)
+    a = rs.uniform(size=(640000, 3)).astype(np.float32)
+    b = np.clip(a + rs.normal(scale=0.05, size=a.shape), 0, 1).astype(np.float32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    want = float(O.psnr(a, b))
+    assert abs(float(metrics.psnr(ta, tb)) - want) <= 1e-4
+    assert abs(float(metrics.mse(ta, tb)) - float(np.mean((a.astype(np.float64) - b) ** 2))) <= 1e-8
+    m = rs.uniform(size=640000) < 0.3
+    want_m = -10 * np.log10(np.mean((a[m].astype(np.float64) - b[m]) ** 2))
+    assert abs(float(metrics.psnr(ta, tb, torch.from_numpy(m).cuda())) - want_m) <= 1e-4
+    assert torch.isnan(metrics.psnr(ta, tb, torch.zeros(640000, dtype=torch.bool).cuda()))
