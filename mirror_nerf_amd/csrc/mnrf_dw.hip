@@ -13,6 +13,7 @@
 // Autograd equivalent: the .grad accumulation of loss.backward() for models/mirror_nerf.py:59-99.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
@@ -104,6 +105,163 @@ __global__ __launch_bounds__(256) void dw_gemm_kernel(const float* __restrict__ 
             v += __shfl_xor(v, 32);
             if (g == 0) bpart[(long long)split * N + n0 + wn * 64 + mb * 16 + i] = v;
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix pipe at fp32 accuracy.  A fp32 number is EXACTLY the sum of three bf16 numbers
+// obtained by truncation (8 + 8 + 8 significand bits, fp32's exponent range -- gradients of 1e-10 are as safe as
+// activations of 100, which is why this kernel does not use the f16 split of the field kernel):
+//     v = hi + mid + lo,   hi = trunc16(v), mid = trunc16(v - hi), lo = trunc16(v - hi - mid)   (both subtractions exact)
+// and dY^T X is evaluated as  hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi  (the three dropped products are
+// <= 2^-24 relative) with six v_mfma_f32_16x16x32_bf16 per 32-sample step into fp32 accumulators: 6 x 16 cycles
+// against 8 x 32 cycles of v_mfma_f32_16x16x4_f32 for the same step.
+// Staging: each thread converts (2 samples x 4 columns) blocks and stores them TRANSPOSED, [column][sample] with two
+// samples per 32-bit word, so that an MFMA operand (8 consecutive samples of one column) is one ds_read_b128; the
+// 96-byte column stride (64 + 32 pad) is conflict-free for the 4 x 16 lane groups of ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int DWS_CH = 32;       // samples per stage = one MFMA k-step
+constexpr int DWS_STRIDE = 96;   // bytes per column in LDS
+
+__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+    const float r1 = v - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    l = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+}
+
+// rows (s, s+1) x 4 columns -> three planes, word [column][s/2] = (bf16(row s) | bf16(row s+1) << 16)
+__device__ __forceinline__ void stage_block(char* plane0, int plane_bytes, int col, int rp, const f32x4& r0, const f32x4& r1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(r0[c], h0, m0, l0);
+        split3(r1[c], h1, m1, l1);
+        char* w = plane0 + (col + c) * DWS_STRIDE + rp * 4;
+        *(unsigned*)(w) = (h0 >> 16) | h1;
+        *(unsigned*)(w + plane_bytes) = (m0 >> 16) | m1;
+        *(unsigned*)(w + 2 * plane_bytes) = (l0 >> 16) | l1;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int TK>
+__global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
+                                                           long long B, int splits, int N, int K, float* __restrict__ Cpart,
+                                                           float* __restrict__ bpart) {
+    extern __shared__ __attribute__((aligned(16))) char dws[];
+    constexpr int PA = DW_TN * DWS_STRIDE;      // one plane of dY^T
+    constexpr int PX = TK * DWS_STRIDE;         // one plane of X^T
+    char* As = dws;                              // 3 planes
+    char* Xs = dws + 3 * PA;                     // 3 planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int wn = wave >> 1, wk = wave & 1;
+    constexpr int MB = 4;              // 64 rows of dW per wave
+    constexpr int KB = TK / 32;        // TK/2 columns per wave
+    constexpr int XQ = (TK / 4 + 15) / 16;               // column-quad rounds of the X tile (16 quads per round)
+    const int n0 = blockIdx.x * DW_TN, k0 = blockIdx.y * TK, split = blockIdx.z;
+    const long long per = (B + splits - 1) / splits;
+    const long long s_begin = split * per;
+    const long long s_end = s_begin + per < B ? s_begin + per : B;
+
+    f32x4 acc[MB][KB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Work split of the staging: a thread owns ROW PAIR rp = lane & 15 of every stage and column quads
+    // cq = (lane >> 4) + 4 * wave + 16 * q.  Within one ds_write_b32 the 32 lanes of a bank group then cover 16 row
+    // pairs x 2 quads: bank = (24 * column + rp) mod 32 differs in rp, 2-way in the quad (free for stores).  (Column
+    // quads across lanes -- the coalesced choice -- put all 32 lanes on ONE bank: 22.5 ms per training step vs 20.0.)
+    const int rp = lane & 15, cq0 = (lane >> 4) + 4 * wave;
+    float bsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // this thread's dY columns (the same in every stage)
+    f32x4 ra[2][2], rx[XQ][2];
+    auto fetch = [&](long long s0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const long long row = s0 + 2 * rp + r;
+                ra[q][r] = row < s_end ? *(const f32x4*)(A + row * lda + n0 + (cq0 + 16 * q) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int cq = cq0 + 16 * q;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const long long row = s0 + 2 * rp + r;
+                rx[q][r] = (cq < TK / 4 && row < s_end) ? *(const f32x4*)(X + row * ldx + k0 + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    fetch(s_begin);
+    for (long long s0 = s_begin; s0 < s_end; s0 += DWS_CH) {
+        __syncthreads();      // the previous stage's operands have been read
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            stage_block(As, PA, (cq0 + 16 * q) * 4, rp, ra[q][0], ra[q][1]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bsum[q][c] += ra[q][0][c] + ra[q][1][c];
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+            if (cq0 + 16 * q < TK / 4) stage_block(Xs, PX, (cq0 + 16 * q) * 4, rp, rx[q][0], rx[q][1]);
+        __syncthreads();
+        if (s0 + DWS_CH < s_end) fetch(s0 + DWS_CH);      // next stage's rows travel during the MFMAs
+        u32x4 b[KB][3];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[kb][pl] = *(const u32x4*)(Xs + pl * PX + (wk * (TK / 2) + kb * 16 + i) * DWS_STRIDE + g * 16);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = *(const u32x4*)(As + pl * PA + (wn * 64 + mb * 16 + i) * DWS_STRIDE + g * 16);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                f32x4 c = acc[mb][kb];
+                c = mfma_bf16(a[2], b[kb][0], c);    // lo . hi
+                c = mfma_bf16(a[0], b[kb][2], c);    // hi . lo
+                c = mfma_bf16(a[1], b[kb][1], c);    // mid . mid
+                c = mfma_bf16(a[1], b[kb][0], c);    // mid . hi
+                c = mfma_bf16(a[0], b[kb][1], c);    // hi . mid
+                c = mfma_bf16(a[0], b[kb][0], c);    // hi . hi
+                acc[mb][kb] = c;
+            }
+        }
+    }
+    // partial tile: C[n = 4g + r][k = i] of every 16x16 block
+    float* C = Cpart + (long long)split * N * K;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + mb * 16 + 4 * g + r;
+                const int k = k0 + wk * (TK / 2) + kb * 16 + i;
+                C[(long long)n * K + k] = acc[mb][kb][r];
+            }
+    if (bpart && blockIdx.y == 0) {
+        // column sums of dY: the 16 lanes of a lane group hold the 16 row pairs of the same columns
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = bsum[q][c];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (rp == 0) bpart[(long long)split * N + n0 + (cq0 + 16 * q) * 4 + c] = v;
+            }
     }
 }
 
@@ -208,7 +366,10 @@ template <int TK>
 static void gemm(const float* A, int lda, int N, const float* X, int ldx, int K, long long B, int splits, float* C, float* bp,
                  hipStream_t s) {
     dim3 grid(N / DW_TN, K / TK, splits);
-    hipLaunchKernelGGL((dw_gemm_kernel<TK>), grid, dim3(256), 0, s, A, lda, X, ldx, B, splits, N, K, C, bp);
+    // MNRF_DW=fp32 selects the v_mfma_f32_16x16x4_f32 kernel (bit-for-bit fp32 fmaf chains); default: bf16 x 6
+    static const bool fp32 = [] { const char* e = getenv("MNRF_DW"); return e && e[0] == 'f'; }();
+    if (fp32) hipLaunchKernelGGL((dw_gemm_kernel<TK>), grid, dim3(256), 0, s, A, lda, X, ldx, B, splits, N, K, C, bp);
+    else hipLaunchKernelGGL((dw_gemm_bf16_kernel<TK>), grid, dim3(256), 3 * (DW_TN + TK) * DWS_STRIDE, s, A, lda, X, ldx, B, splits, N, K, C, bp);
 }
 
 int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
