@@ -170,7 +170,7 @@ int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, i
                              const float* rays, const float* z_vals, int spr, const float* dir_emb,
                              int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                              float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                             float* save_inv, float* save_invj, void* stream);
+                             float* save_inv, float* save_invj, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
 
 /* Backward of the field MLP: given dL/d{sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B)},
  * writes the gradient of every parameter (d_params: HOST array of MNRF_N_PARAMS device pointers,

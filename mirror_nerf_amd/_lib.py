@@ -47,7 +47,7 @@ SIGNATURES = {
     "mnrf_train_save_floats": (_i64, [_i64]),
     "mnrf_train_mask_words": (_i64, [_i64]),
     "mnrf_train_workspace_floats": (_i64, [_i64]),
-    "mnrf_field_forward_train": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 9 + [_str]),
+    "mnrf_field_forward_train": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 9 + [_u32, _str]),
     "mnrf_train_workspace2_floats": (_i64, [_i64]),
     "mnrf_field_backward2": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _c_f, _c_f, _c_f, _c_f,
                                     ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),

@@ -92,6 +92,7 @@ class FieldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params):
         from .weights import packed_of
+        from . import mirror_nerf as _mn
         L = _lib.lib()
         packed = packed_of(module)
         dev = packed.device
@@ -109,7 +110,8 @@ class FieldFn(torch.autograd.Function):
         if B:
             _lib.check(L.mnrf_field_forward_train(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
-                p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj), _lib.stream()), "mnrf_field_forward_train")
+                p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj),
+                _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()), "mnrf_field_forward_train")
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.set_materialize_grads(False)   # an unused `normal` must arrive as None, not as zeros: it gates the second-order pass
         ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj)

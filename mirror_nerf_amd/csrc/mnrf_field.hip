@@ -192,7 +192,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
                                         const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                         int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                         float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                                        float* save_inv, float* save_invj, void* stream) {
+                                        float* save_inv, float* save_invj, unsigned flags, void* stream) {
     if (!packed || !save_x || !save_mask || !save_inv) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: negative sample count");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: need xyz or rays+z_vals");
@@ -202,8 +202,11 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
     FieldArgs A{packed, MNRF_GRAD_NORMAL, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
                 save_x, (unsigned long long*)save_mask, save_inv, save_invj};
-    // always the s2 tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map
-    if (s2::launch(A, false, true, (hipStream_t)stream) != 0)
+    // always a 128-sample tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map.
+    // MNRF_SPLIT_F16: the split-f16 tuning (same saved quantities, fp32 activations from its fp32 accumulators)
+    const int rc = (flags & MNRF_SPLIT_F16) ? launch_split(A, false, true, 0, (hipStream_t)stream)
+                                            : s2::launch(A, false, true, (hipStream_t)stream);
+    if (rc != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_forward_train");
 }

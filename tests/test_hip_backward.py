@@ -11,6 +11,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["split", "fp32"])
+def precision(request):
+    """The training forward runs on either arithmetic of the field kernel (split-f16 default, bit-exact fp32); the
+    backward kernels and tolerances are the same."""
+    from mirror_nerf_amd import mirror_nerf as MN
+    old = MN.PRECISION
+    MN.set_precision(request.param)
+    yield request.param
+    MN.set_precision(old)
+
+
 def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
