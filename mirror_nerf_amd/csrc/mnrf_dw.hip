@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__
     const long long s_begin = split * per;
     const long long s_end = s_begin + per < B ? s_begin + per : B;
     float acc[3] = {0.f, 0.f, 0.f}, bs[3] = {0.f, 0.f, 0.f};
+#pragma unroll 8
     for (long long s = s_begin; s < s_end; ++s) {
         const float x = k < K ? X[s * ldx + k] : 0.f;
 #pragma unroll
@@ -344,9 +345,11 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
 namespace mnrf {
 
 // Split counts: enough workgroups to fill 256 CUs even for a 1024-ray training batch.
-int dw_splits(long long B) {          // MFMA GEMMs: >= 512 samples per workgroup, <= 128 splits
-    long long s = (B + 511) / 512;
-    return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+int dw_splits(long long B) {          // MFMA GEMMs: >= 256 samples per workgroup, <= 256 splits (measured: 11.75 ms/step; 512/128: 12.0; 128/512: 12.8)
+    static const int cap = [] { const char* e = getenv("MNRF_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 256; }();
+    static const int per = [] { const char* e = getenv("MNRF_DW_PER"); const int v = e ? atoi(e) : 0; return v >= 32 ? v : 256; }();
+    long long s = (B + per - 1) / per;
+    return (int)(s < 1 ? 1 : (s > cap ? cap : s));
 }
 int dw_small_splits(long long B) {    // 1-/3-row Linears: HBM-bound streaming, 128 samples per workgroup
     long long s = (B + 127) / 128;
