@@ -33,8 +33,9 @@ PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide, dense f16/bf16: 256 CU x 4 SIMD 
 # MFMA FLOPs the split kernel EXECUTES per full sample: 1308 hi/lo tile pairs x 3 products x 2 groups x 4 waves x
 # 16384 FLOP per v_mfma_f32_16x16x32_f16 / 128 samples (= 3 x the padded fp32 count; algorithmic: MN.FLOP_FULL)
 SPLIT_EXECUTED_FLOP_FULL = 1308 * 3 * 2 * 4 * 16384 // 128
-# HBM bytes per full-kernel sample from the PMC passes in profiles/r01_pmc (FETCH_SIZE doubled per the
-# guide's gfx950 correction + WRITE_SIZE): (2 x 33758 + 196608) KiB / 6291456 samples
+# HBM bytes per full-kernel sample from the PMC passes (profiles/r01_pmc for the fp32 kernel, profiles/r01e_pmc_split
+# for the split kernel: the same traffic; FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE):
+# (2 x 33758 + 196608) KiB / 6291456 samples
 PMC_HBM_BYTES_PER_FULL_SAMPLE = (2 * 33758 + 196608) * 1024 / 6291456
 
 
@@ -192,8 +193,8 @@ def main():
     if not a.no_train:
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
-        full = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
-        train["with_total_loss"] = {k: full[k] for k in ("value", "ms_per_step", "loss", "loss_fn")}
+        train_total = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
+        train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn")}
 
     if rank == 0:
         split = a.precision == "split"
