@@ -151,10 +151,28 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// All GEMMs of one backward pass with the same TK run as ONE launch (grid.z = job): a 1024-ray training batch gives
+// each GEMM only a few hundred workgroups, and launching them one after the other needed 256 sample-range splits to
+// fill the chip -- 600 MB of partial tiles written and re-read per pass.  Batched, 64 splits fill it.
+struct DwJob {
+    const float* A; const float* X; float* C; float* bp;
+    int lda, ldx, N, K;
+};
+struct DwJobs {
+    DwJob job[12];
+};
+
 template <int TK>
-__global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ X, int ldx,
-                                                           long long B, int splits, int N, int K, float* __restrict__ Cpart,
-                                                           float* __restrict__ bpart) {
+__global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(DwJobs J, long long B, int splits) {
+    const DwJob jb = J.job[blockIdx.z];
+    const float* __restrict__ A = jb.A;
+    const float* __restrict__ X = jb.X;
+    float* __restrict__ Cpart = jb.C;
+    float* __restrict__ bpart = jb.bp;
+    const int lda = jb.lda, ldx = jb.ldx, N = jb.N, K = jb.K;
+    const int tiles_n = N / DW_TN;
+    const int tile_n = blockIdx.x % tiles_n, tile_k = blockIdx.x / tiles_n;
+    if (tile_k >= K / TK) return;
     extern __shared__ __attribute__((aligned(16))) char dws[];
     constexpr int PA = DW_TN * DWS_STRIDE;      // one plane of dY^T
     constexpr int PX = TK * DWS_STRIDE;         // one plane of X^T
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const float* __restri
     constexpr int MB = 4;              // 64 rows of dW per wave
     constexpr int KB = TK / 32;        // TK/2 columns per wave
     constexpr int XQ = (TK / 4 + 15) / 16;               // column-quad rounds of the X tile (16 quads per round)
-    const int n0 = blockIdx.x * DW_TN, k0 = blockIdx.y * TK, split = blockIdx.z;
+    const int n0 = tile_n * DW_TN, k0 = tile_k * TK, split = blockIdx.y;
     const long long per = (B + splits - 1) / splits;
     const long long s_begin = split * per;
     const long long s_end = s_begin + per < B ? s_begin + per : B;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const float* __restri
                 const int k = k0 + wk * (TK / 2) + kb * 16 + i;
                 C[(long long)n * K + k] = acc[mb][kb][r];
             }
-    if (bpart && blockIdx.y == 0) {
+    if (bpart && tile_k == 0) {
         // column sums of dY: the 16 lanes of a lane group hold the 16 row pairs of the same columns
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -344,10 +362,17 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
 
 namespace mnrf {
 
+// MNRF_DW=fp32 selects the v_mfma_f32_16x16x4_f32 kernel (bit-for-bit fp32 fmaf chains, one launch per GEMM); default:
+// bf16 x 6, batched per TK
+static bool dw_fp32() {
+    static const bool v = [] { const char* e = getenv("MNRF_DW"); return e && e[0] == 'f'; }();
+    return v;
+}
+
 // Split counts: enough workgroups to fill 256 CUs even for a 1024-ray training batch.
-int dw_splits(long long B) {          // MFMA GEMMs: >= 256 samples per workgroup, <= 256 splits (measured: 11.75 ms/step; 512/128: 12.0; 128/512: 12.8)
-    static const int cap = [] { const char* e = getenv("MNRF_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 256; }();
-    static const int per = [] { const char* e = getenv("MNRF_DW_PER"); const int v = e ? atoi(e) : 0; return v >= 32 ? v : 256; }();
+int dw_splits(long long B) {          // MFMA GEMMs, batched launches: >= 512 samples per workgroup, <= 64 splits: 11.4 ms/step (48: 11.9, 32: 11.7, 96 x 256: 11.6; un-batched fp32 path: 256 / 256)
+    static const int cap = [] { const char* e = getenv("MNRF_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : (dw_fp32() ? 256 : 64); }();
+    static const int per = [] { const char* e = getenv("MNRF_DW_PER"); const int v = e ? atoi(e) : 0; return v >= 32 ? v : (dw_fp32() ? 256 : 512); }();
     long long s = (B + per - 1) / per;
     return (int)(s < 1 ? 1 : (s > cap ? cap : s));
 }
@@ -365,20 +390,43 @@ long long dw_workspace_floats(long long B) {
     return (long long)dw_splits(B) * DW_PER_SPLIT + (long long)dw_small_splits(B) * DW_PER_SMALL_SPLIT;
 }
 
+struct DwBatch {
+    DwJobs j128, j64, j32;
+    int n128 = 0, n64 = 0, n32 = 0;
+    long long B;
+    int splits;
+    hipStream_t s;
+    template <int TK>
+    void launch(const DwJobs& J, int n) {
+        if (n) hipLaunchKernelGGL((dw_gemm_bf16_kernel<TK>), dim3(4, splits, n), dim3(256), 3 * (DW_TN + TK) * DWS_STRIDE, s, J, B, splits);
+    }
+    void flush() {
+        launch<128>(j128, n128);
+        launch<64>(j64, n64);
+        launch<32>(j32, n32);
+        n128 = n64 = n32 = 0;
+    }
+};
+
 template <int TK>
-static void gemm(const float* A, int lda, int N, const float* X, int ldx, int K, long long B, int splits, float* C, float* bp,
-                 hipStream_t s) {
-    dim3 grid(N / DW_TN, K / TK, splits);
-    // MNRF_DW=fp32 selects the v_mfma_f32_16x16x4_f32 kernel (bit-for-bit fp32 fmaf chains); default: bf16 x 6
-    static const bool fp32 = [] { const char* e = getenv("MNRF_DW"); return e && e[0] == 'f'; }();
-    if (fp32) hipLaunchKernelGGL((dw_gemm_kernel<TK>), grid, dim3(256), 0, s, A, lda, X, ldx, B, splits, N, K, C, bp);
-    else hipLaunchKernelGGL((dw_gemm_bf16_kernel<TK>), grid, dim3(256), 3 * (DW_TN + TK) * DWS_STRIDE, s, A, lda, X, ldx, B, splits, N, K, C, bp);
+static void gemm(DwBatch& bt, const float* A, int lda, int N, const float* X, int ldx, int K, float* C, float* bp) {
+    if (dw_fp32()) {
+        dim3 grid(N / DW_TN, K / TK, bt.splits);
+        hipLaunchKernelGGL((dw_gemm_kernel<TK>), grid, dim3(256), 0, bt.s, A, lda, X, ldx, bt.B, bt.splits, N, K, C, bp);
+        return;
+    }
+    const DwJob jb{A, X, C, bp, lda, ldx, N, K};
+    if (TK == 128) bt.j128.job[bt.n128++] = jb;
+    else if (TK == 64) bt.j64.job[bt.n64++] = jb;
+    else bt.j32.job[bt.n32++] = jb;
 }
 
 int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
               hipStream_t s) {
     const int splits = dw_splits(B);
     const int ssplits = dw_small_splits(B);
+    DwBatch bt;
+    bt.B = B; bt.splits = splits; bt.s = s;
     float* p = ws;
     auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
     auto take_small = [&](long long n) { float* r = p; p += n * ssplits; return r; };
@@ -402,17 +450,17 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* bp = take(256);
         if (i == 0) {
             float* c = take(256 * 64);
-            gemm<64>(Y(DY_L), 256, 256, X(SEC_ENC), 64, 64, B, splits, c, bp, s);
+            gemm<64>(bt, Y(DY_L), 256, 256, X(SEC_ENC), 64, 64, c, bp);
             layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1, bp);
         } else if (i == 4) {
             float* ce = take(256 * 64);
             float* ch = take(256 * 256);
-            gemm<64>(Y(DY_L + 256 * 4), 256, 256, X(SEC_ENC), 64, 64, B, splits, ce, bp, s);
-            gemm<128>(Y(DY_L + 256 * 4), 256, 256, X(SEC_H + 256 * 3), 256, 256, B, splits, ch, nullptr, s);
+            gemm<64>(bt, Y(DY_L + 256 * 4), 256, 256, X(SEC_ENC), 64, 64, ce, bp);
+            gemm<128>(bt, Y(DY_L + 256 * 4), 256, 256, X(SEC_H + 256 * 3), 256, 256, ch, nullptr);
             layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1, bp);
         } else {
             float* c = take(256 * 256);
-            gemm<128>(Y(DY_L + 256 * i), 256, 256, X(SEC_H + 256 * (i - 1)), 256, 256, B, splits, c, bp, s);
+            gemm<128>(bt, Y(DY_L + 256 * i), 256, 256, X(SEC_H + 256 * (i - 1)), 256, 256, c, bp);
             layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
         }
     }
@@ -420,15 +468,15 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     {   // xyz_encoding_final (L = 8)
         float* bp = take(256);
         float* c = take(256 * 256);
-        gemm<128>(Y(DY_FIN), 256, 256, h8, 256, 256, B, splits, c, bp, s);
+        gemm<128>(bt, Y(DY_FIN), 256, 256, h8, 256, 256, c, bp);
         layer(8, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
     }
     {   // dir_encoding.0 (L = 9): columns [0,256) from final, [256,283) from the view encoding
         float* bp = take(128);
         float* cf = take(128 * 256);
         float* cd = take(128 * 32);
-        gemm<128>(Y(DY_DIR), 128, 128, X(SEC_FIN), 256, 256, B, splits, cf, bp, s);
-        gemm<32>(Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, B, splits, cd, nullptr, s);
+        gemm<128>(bt, Y(DY_DIR), 128, 128, X(SEC_FIN), 256, 256, cf, bp);
+        gemm<32>(bt, Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, cd, nullptr);
         layer(9, 128, 283, DwSource{cf, 256, 128, splits}, DwSource{cd, 32, 128, splits}, 256, 0, bp);
     }
     auto small = [&](int L, const float* A, int lda, int n_true, const float* Xp, int K) {
@@ -442,18 +490,19 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     {   // normal_net.0 (L = 12)
         float* bp = take(128);
         float* c = take(128 * 256);
-        gemm<128>(Y(DY_NRM1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
+        gemm<128>(bt, Y(DY_NRM1), 128, 128, h8, 256, 256, c, bp);
         layer(12, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
     }
     small(13, Y(DY_NRM2), 16, 3, X(SEC_HN), 128);               // normal_net.1
     {   // is_mirror_net.0 (L = 14)
         float* bp = take(128);
         float* c = take(128 * 256);
-        gemm<128>(Y(DY_MIR1), 128, 128, h8, 256, 256, B, splits, c, bp, s);
+        gemm<128>(bt, Y(DY_MIR1), 128, 128, h8, 256, 256, c, bp);
         layer(14, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
     }
     small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
     if (p - ws > dw_workspace_floats(B)) return -1;
+    bt.flush();
     // largest layer: 256 x 319 + 256 elements
     hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
     return 0;
@@ -470,6 +519,8 @@ long long dw2_workspace_floats(long long B) {
 int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, hipStream_t s) {
     const int splits = dw_splits(B);
     const int ssplits = dw_small_splits(B);
+    DwBatch bt;
+    bt.B = B; bt.splits = splits; bt.s = s;
     float* p = ws;
     auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
     auto sec = [&](int off) { return so + (long long)off * B; };
@@ -491,17 +542,17 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
         const float* b = sec(BS_L + 256 * i);
         if (i == 0) {
             float* c = take(256 * 64);
-            gemm<64>(b, 256, 256, sec(TA_ENC), 64, 64, B, splits, c, nullptr, s);
+            gemm<64>(bt, b, 256, 256, sec(TA_ENC), 64, 64, c, nullptr);
             layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1);
         } else if (i == 4) {
             float* ce = take(256 * 64);
             float* ch = take(256 * 256);
-            gemm<64>(b, 256, 256, sec(TA_ENC), 64, 64, B, splits, ce, nullptr, s);
-            gemm<128>(b, 256, 256, sec(TA_H + 256 * 3), 256, 256, B, splits, ch, nullptr, s);
+            gemm<64>(bt, b, 256, 256, sec(TA_ENC), 64, 64, ce, nullptr);
+            gemm<128>(bt, b, 256, 256, sec(TA_H + 256 * 3), 256, 256, ch, nullptr);
             layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1);
         } else {
             float* c = take(256 * 256);
-            gemm<128>(b, 256, 256, sec(TA_H + 256 * (i - 1)), 256, 256, B, splits, c, nullptr, s);
+            gemm<128>(bt, b, 256, 256, sec(TA_H + 256 * (i - 1)), 256, 256, c, nullptr);
             layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0);
         }
     }
@@ -515,6 +566,7 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
         layer(10, 1, 256, DwSource{c, 256, 3, ssplits}, DwSource{c, 256, 3, ssplits}, 256, 0);
     }
     if (p - ws > dw2_workspace_floats(B)) return -1;
+    bt.flush();
     hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
     return 0;
 }
