@@ -184,7 +184,8 @@ int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_
                         const float* g_is_mirror, const float* rgb, const float* pred_normal,
                         const float* is_mirror, const float* save_x, const uint64_t* save_mask,
                         const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
-                        float* d_dir, void* stream);
+                        float* d_dir, unsigned flags /* 0 or MNRF_SPLIT_F16: activation gradients on the f16 pipe */,
+                        void* stream);
 
 /* Second-order term of the field backward: the gradient that reaches the trunk weights, sigma.weight
  * and xyz through `normal = l2n(-d sigma/d xyz)` (utils/func.py:10-25 with create_graph=True).

@@ -125,6 +125,7 @@ class FieldFn(torch.autograd.Function):
     def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal):
         import ctypes
         from .weights import packed_of
+        from . import mirror_nerf as _mn
         L = _lib.lib()
         xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj = ctx.saved_tensors
         B, spr = ctx.B, ctx.spr
@@ -145,7 +146,8 @@ class FieldFn(torch.autograd.Function):
         if B:
             _lib.check(L.mnrf_field_backward(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
-                p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), _lib.stream()),
+                p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir),
+                _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()),
                 "mnrf_field_backward")
             if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
                 ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))

@@ -217,7 +217,7 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
                                    const float* g_is_mirror, const float* rgb, const float* pred_normal,
                                    const float* is_mirror, const float* save_x, const uint64_t* save_mask,
                                    const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
-                                   float* d_dir, void* stream) {
+                                   float* d_dir, unsigned flags, void* stream) {
     if (!packed || !save_x || !save_mask || !save_inv || !workspace || !d_params)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: negative sample count");
@@ -229,10 +229,11 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
         if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: null gradient pointer");
     float* dY = workspace;
     float* ws = workspace + (int64_t)DY_FLOATS * B;
-    s2::FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
+    FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
                        g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, dY, d_xyz, d_dir};
     hipStream_t s = (hipStream_t)stream;
-    if (s2::launch_bwd(A, s) != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");
+    if (((flags & MNRF_SPLIT_F16) ? launch_split_bwd(A, s) : s2::launch_bwd(A, s)) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");
     int rc = mnrf_check_launch("mnrf_field_backward (activation gradients)");
     if (rc != MNRF_OK) return rc;
     if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, s) != 0)

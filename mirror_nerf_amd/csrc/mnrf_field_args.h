@@ -34,9 +34,23 @@ struct FieldArgs {
     float* save_invj;              // [B] 1/|d sigma/dx| of the density-gradient normal, same convention
 };
 
+// training backward (activation gradients): mnrf_field_bwd.inc (fp32) and mnrf_field_split_bwd.inc (split-f16)
+struct FieldBwdArgs {
+    const float* packed;
+    long long B;
+    const float* xyz; long long xyz_stride; const float* rays; const float* z_vals; int spr;
+    const float* g_sigma; const float* g_rgb; const float* g_pn; const float* g_m;   // upstream, null = 0
+    const float* rgb; const float* pn; const float* is_mirror;                        // forward outputs
+    const unsigned long long* save_mask; const float* save_inv;
+    float* dY;
+    float* d_xyz;
+    float* d_dir;
+};
+
 // split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s);
 // builds the split streams of a packed image from its fp32 streams (same stream, after pack_kernel)
 void launch_split_pack(float* packed, hipStream_t s);
+int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s);
 
 }  // namespace mnrf

@@ -28,6 +28,7 @@ constexpr int MIN_WAVES_PER_SIMD = 1;
 constexpr int CHUNK_PAIRS = 16;
 constexpr int RING_SLOTS = 3;
 #include "mnrf_field_split.inc"
+#include "mnrf_field_split_bwd.inc"
 }  // namespace h2x
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s) {
     // variant 0: measured default -- 16 KiB chunks for the forward-only kernels (17.2 vs 17.3 ms per 6.29 M full
@@ -39,6 +40,8 @@ int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hi
     return big ? h2x::launch(A, sigma_only, grad, s) : h2::launch(A, sigma_only, grad, s);
 }
 
+int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s) { return h2x::launch_bwd(A, s); }
+
 // ------------------------------------------------------------------ split-stream packer
 // One thread per f16 of the split streams.  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l
 // of the part's fp32 tile (2T + (j>>2), nb); hi = f16(w) (round to nearest), lo = f16(w - hi).
@@ -46,9 +49,11 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr long long FWD_HALVES = (long long)SPLIT_FWD_PAIRS * (PAIR_BYTES / 2);
     constexpr long long BWD_HALVES = (long long)SPLIT_BWD_PAIRS * (PAIR_BYTES / 2);
-    if (q >= FWD_HALVES + BWD_HALVES) return;
-    const bool bwd = q >= FWD_HALVES;
-    const long long r = bwd ? q - FWD_HALVES : q;
+    constexpr long long HBWD_HALVES = (long long)SPLIT_HBWD_PAIRS * (PAIR_BYTES / 2);
+    if (q >= FWD_HALVES + BWD_HALVES + HBWD_HALVES) return;
+    const int region = q >= FWD_HALVES + BWD_HALVES ? 2 : (q >= FWD_HALVES ? 1 : 0);     // forward, trunk^T, heads^T
+    const bool bwd = region != 0;
+    const long long r = q - (region == 2 ? FWD_HALVES + BWD_HALVES : (region == 1 ? FWD_HALVES : 0));
     const int pair = (int)(r / (PAIR_BYTES / 2));
     const int within = (int)(r % (PAIR_BYTES / 2));
     const bool is_lo = within >= 512;
@@ -56,12 +61,13 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     // Segments of the forward stream: the nine trunk parts (L1, L2-4, L5 encoding, L5 hidden, L6-8) are stored in two
     // HALVES of 8 row blocks each (mnrf_field_split.inc: the kernel evaluates a trunk layer half by half), L5's two
     // parts interleaved by half; the head parts and the whole backward stream are stored part by part.
-    const Part* parts = bwd ? T.bwd : T.fwd;
+    const Part* parts = region == 2 ? T.hbwd : (region == 1 ? T.bwd : T.fwd);
     int k = 0, half = -1, pair0 = 0;
     if (bwd) {
+        const int nparts = region == 2 ? N_HBWD_PARTS - 1 : N_BWD_PARTS;
         for (;;) {
-            const int np = padded_pairs(parts[k].ntq / 2 * parts[k].nb);
-            if (k + 1 >= N_BWD_PARTS || pair < pair0 + np) break;
+            const int np = padded_pairs((parts[k].ntq + 1) / 2 * parts[k].nb);
+            if (k + 1 >= nparts || pair < pair0 + np) break;
             pair0 += np;
             ++k;
         }
@@ -81,20 +87,20 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     const int rows = half >= 0 ? 8 : pt.nb;
     const int Tq = lp / rows, nb = (half >= 0 ? 8 * half : 0) + lp % rows;
     float w = 0.f;
-    if (Tq < pt.ntq / 2) {
+    if (2 * Tq + (j >> 2) < pt.ntq) {      // (an odd ntq leaves the upper half of its last step zero)
         const long long tile = pt.tile0 + (long long)(2 * Tq + (j >> 2)) * pt.nb + nb;
-        w = packed[(bwd ? OFF_BWD : OFF_FWD) + tile * TILE_FLOATS + lane * 4 + (j & 3)];
+        w = packed[(region == 2 ? OFF_HBWD : (region == 1 ? OFF_BWD : OFF_FWD)) + tile * TILE_FLOATS + lane * 4 + (j & 3)];
     }
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)(w - (float)hi);
-    _Float16* dst = (_Float16*)(packed + (bwd ? OFF_SPLIT_BWD : OFF_SPLIT_FWD));
+    _Float16* dst = (_Float16*)(packed + (region == 2 ? OFF_SPLIT_HBWD : (region == 1 ? OFF_SPLIT_BWD : OFF_SPLIT_FWD)));
     dst[r] = is_lo ? lo : hi;
 }
 
 void launch_split_pack(float* packed, hipStream_t s) {
     PartTable T;
     build_parts(T);
-    const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS) * (PAIR_BYTES / 2);
+    const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS + SPLIT_HBWD_PAIRS) * (PAIR_BYTES / 2);
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, packed, T);
 }
 

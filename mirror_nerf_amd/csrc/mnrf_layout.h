@@ -111,11 +111,14 @@ __host__ __device__ constexpr int padded_pairs(int n) { return (n + PAD_PAIRS - 
 constexpr int SPLIT_FWD_PAIRS_SIGMA = 32 + 3 * 128 + (32 + 128) + 3 * 128 + 16;                   // 976
 constexpr int SPLIT_FWD_PAIRS = SPLIT_FWD_PAIRS_SIGMA + 64 + 16 + 64 + 16 + 128 + 64 + 16 + 16;     // 1360
 constexpr int SPLIT_BWD_PAIRS = 3 * 128 + 32 + 128 + 3 * 128 + 32;                                  // 960
+// head-backward parts (training): a contraction over 16 rows (ntq = 1) fills half of a 32-wide MFMA step, the rest is zero
+constexpr int SPLIT_HBWD_PAIRS = 16 + 64 + 16 + 128 + 16 + 64 + 16 + 64;                            // 384
 constexpr int64_t OFF_SPLIT_FWD = PACKED_F32_FLOATS;
 constexpr int64_t OFF_SPLIT_BWD = OFF_SPLIT_FWD + (int64_t)SPLIT_FWD_PAIRS * (PAIR_BYTES / 4);
+constexpr int64_t OFF_SPLIT_HBWD = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4);
 // tail pad: the split kernel's static LDS-DMA schedule reads two chunks (of up to 32 KiB) past the end of a stream
 constexpr int64_t SPLIT_TAIL_FLOATS = 2 * 16 * (PAIR_BYTES / 4);
-constexpr int64_t PACKED_FLOATS = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
+constexpr int64_t PACKED_FLOATS = OFF_SPLIT_HBWD + (int64_t)SPLIT_HBWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order
 constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)
