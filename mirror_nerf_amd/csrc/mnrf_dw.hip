@@ -344,12 +344,14 @@ __global__ void dw_finish_kernel(DwFinishArgs F) {
         int col = first ? c : c - ly.split_col;
         if (first && ly.kind0 == 1) col = F.encpos[c];
         float v = 0.f;
-        for (int sp = 0; sp < s.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];
+#pragma unroll 8
+        for (int sp = 0; sp < s.splits; ++sp) v += s.part[((long long)sp * s.N + n) * s.K + col];   // unrolled: loads in flight
         ly.d_w[e] = F.accumulate ? ly.d_w[e] + v : v;
     } else if (e < nw + ly.out_f && ly.bpart) {
         const int n = e - nw;
         const int NB = ly.src[0].N;
         float v = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < ly.src[0].splits; ++sp) v += ly.bpart[(long long)sp * NB + n];
         ly.d_b[n] = F.accumulate ? ly.d_b[n] + v : v;
     }
