@@ -196,7 +196,7 @@ int64_t mnrf_train_workspace2_floats(int64_t B);
 int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                          const float* rays, const float* z_vals, int spr, const float* g_normal,
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
-                         float* workspace, float* const* d_params, float* d_xyz, void* stream);
+                         float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
 
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);

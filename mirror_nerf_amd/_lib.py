@@ -50,7 +50,7 @@ SIGNATURES = {
     "mnrf_field_forward_train": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 9 + [_u32, _str]),
     "mnrf_train_workspace2_floats": (_i64, [_i64]),
     "mnrf_field_backward2": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _c_f, _c_f, _c_f, _c_f,
-                                    ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),
+                                    ctypes.POINTER(ctypes.c_void_p), _c_f, _u32, _str]),
     "mnrf_field_backward": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 11 +
                             [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _u32, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),

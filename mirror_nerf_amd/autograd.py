@@ -153,7 +153,8 @@ class FieldFn(torch.autograd.Function):
                 ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
                 _lib.check(L.mnrf_field_backward2(
                     p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
-                    p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz), _lib.stream()), "mnrf_field_backward2")
+                    p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz),
+                    _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()), "mnrf_field_backward2")
         else:
             for t in d_params:
                 t.zero_()

@@ -246,17 +246,18 @@ extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_
 extern "C" int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                     const float* rays, const float* z_vals, int spr, const float* g_normal,
                                     const float* normal, const float* save_invj, const uint64_t* save_mask,
-                                    float* workspace, float* const* d_params, float* d_xyz, void* stream) {
+                                    float* workspace, float* const* d_params, float* d_xyz, unsigned flags, void* stream) {
     if (!packed || !g_normal || !normal || !save_invj || !save_mask || !workspace || !d_params)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: negative sample count");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: need xyz or rays+z_vals");
     float* so = workspace;
     float* ws = workspace + (int64_t)SO_FLOATS * B;
-    s2::FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
+    FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
                         (const unsigned long long*)save_mask, so, d_xyz};
     hipStream_t s = (hipStream_t)stream;
-    if (s2::launch_bwd2(A, s) != 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: too many samples for one launch");
+    if (((flags & MNRF_SPLIT_F16) ? launch_split_bwd2(A, s) : s2::launch_bwd2(A, s)) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2: too many samples for one launch");
     int rc = mnrf_check_launch("mnrf_field_backward2 (tangent pass)");
     if (rc != MNRF_OK) return rc;
     if (launch_dw2(so, (long long)B, ws, d_params, s) != 0)

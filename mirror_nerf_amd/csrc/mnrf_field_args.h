@@ -46,11 +46,24 @@ struct FieldBwdArgs {
     float* d_xyz;
     float* d_dir;
 };
+// second-order pass (gradient through the density-gradient normal)
+struct FieldBwd2Args {
+    const float* packed;
+    long long B;
+    const float* xyz; long long xyz_stride; const float* rays; const float* z_vals; int spr;
+    const float* g_normal;     // dL/d normal (B,3)
+    const float* normal;       // forward output (B,3)
+    const float* save_invj;    // 1/|J| (negative: eps clamp)
+    const unsigned long long* save_mask;
+    float* so;                 // [SO_FLOATS sections][B][width]
+    float* d_xyz;              // accumulated into (may be null)
+};
 
 // split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s);
 // builds the split streams of a packed image from its fp32 streams (same stream, after pack_kernel)
 void launch_split_pack(float* packed, hipStream_t s);
 int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s);
+int launch_split_bwd2(const FieldBwd2Args& A, hipStream_t s);
 
 }  // namespace mnrf

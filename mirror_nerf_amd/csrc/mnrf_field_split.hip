@@ -41,6 +41,7 @@ int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hi
 }
 
 int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s) { return h2x::launch_bwd(A, s); }
+int launch_split_bwd2(const FieldBwd2Args& A, hipStream_t s) { return h2x::launch_bwd2(A, s); }
 
 // ------------------------------------------------------------------ split-stream packer
 // One thread per f16 of the split streams.  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l

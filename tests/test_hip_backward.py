@@ -249,8 +249,8 @@ def test_reflect_blend_embed_backward(compact):
 
 
 def test_split_training_path_agrees_with_fp32_path(precision):
-    """The whole training path of the field -- forward with saved activations, activation gradients, weight gradients
-    -- on the split arithmetic (f16 hi/lo pairs forward and backward, one power-of-two scale per sample in the
+    """The whole training path of the field -- forward with saved activations, activation gradients, the second-order
+    pass through the density-gradient normal, weight gradients -- on the split arithmetic (f16 hi/lo pairs forward and backward, one power-of-two scale per sample in the
     backward, exact bf16 triples in the dW GEMMs) against the bit-exact fp32 kernels on the same inputs, with upstream
     gradients spread over 12 orders of magnitude (compositing weights do that).  Bound: 2e-5 of each tensor's largest
     entry (measured: printed)."""
@@ -267,7 +267,8 @@ def test_split_training_path_agrees_with_fp32_path(precision):
     de = TR.embed(rays[:, 3:6], 4)
     scale = 10.0 ** (-12 * torch.rand(N * S, device=DEV))          # per-sample magnitudes 1 .. 1e-12
     cot = [torch.randn(N * S, device=DEV) * scale, torch.randn(N * S, 3, device=DEV) * scale[:, None],
-           torch.randn(N * S, 3, device=DEV) * scale[:, None], torch.randn(N * S, device=DEV) * scale]
+           torch.randn(N * S, 3, device=DEV) * scale[:, None], torch.randn(N * S, device=DEV) * scale,
+           torch.randn(N * S, 3, device=DEV) * scale[:, None] * 1e-2]     # the density-gradient normal: second-order pass
     res = {}
     for mode in ("fp32", "split"):
         MN.set_precision(mode)
@@ -277,7 +278,7 @@ def test_split_training_path_agrees_with_fp32_path(precision):
         for p in params:
             p.grad = None
         got = FieldFn.apply(m, S, None, r, z, d, True, *params)
-        sum((o * c).sum() for o, c in zip(got[:4], cot)).backward()
+        sum((o * c).sum() for o, c in zip(got[:5], cot)).backward()
         res[mode] = [r.grad.clone(), d.grad.clone()] + [p.grad.clone() for p in params]
     worst = max(_rel(a, b) for a, b in zip(res["split"], res["fp32"]))
     print("split vs fp32 training path: worst relative gradient difference", worst)
