@@ -189,6 +189,20 @@ def main():
         MN.LAUNCH_LOG = None
         MN.set_precision(a.precision)
 
+    # PCIe-inclusive rate (never `value`): one more frame whose per-ray maps are copied to the host
+    host_maps = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hm = M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,
+                                 trace_secondary_rays=True, to_cpu="maps")
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t1
+        host_maps = {"rays_per_s": rays_per_frame / dt_h, "bytes_to_host": int(sum(v.numel() * v.element_size() for v in hm.values())),
+                     "note": "same frame with the per-ray maps (rgb, depth, opacity, mask, normals, x_surface) copied to pageable host "
+                             "memory chunk by chunk; the reference copies every dict entry incl. per-sample tensors (eval.py:735-736)"}
+        hm = None
+
     train = None
     if not a.no_train:
         from mirror_nerf_amd import training
@@ -231,6 +245,8 @@ def main():
                          "sigma_only_kernel_tflops": sig_tf,
                          "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
         }
+        if host_maps is not None:
+            res["with_host_maps"] = host_maps
         if train is not None:
             res["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:

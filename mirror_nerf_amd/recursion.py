@@ -228,7 +228,10 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     """eval.batched_inference.  kwargs: args (namespace/dict with predict_normal, only_one_field,
     only_one_field_fine_epoch, max_recursive_level, app_control_mirror_roughness, trace_ray_times),
     trace_secondary_rays, normal_noise_std, test_time, white_back (the reference reads the module
-    global `dataset.white_back`), to_cpu (default True: eval.py:735-736 moves every value to the CPU),
+    global `dataset.white_back`), to_cpu (True, the default: eval.py:735-736 moves every value to the CPU; False: keep
+    everything on the device; "maps": return only the per-ray maps -- rgb, depth, opacity, mirror mask, normals,
+    x_surface, ~100 B/ray instead of ~3 KB/ray of per-sample tensors nobody downstream of eval.py:743-894 reads -- on
+    the CPU),
     _normal_noise (iterator of pre-drawn (n,3) standard-normal tensors, for tests)."""
     args = kwargs.get("args")
     if isinstance(args, dict):
@@ -310,5 +313,11 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     for i in range(0, rays.shape[0], chunk):
         out = recurse(rays[i:i + chunk].contiguous(), 0)
         for k, v in out.items():
-            results[k] += [v.cpu() if to_cpu else v]
+            if to_cpu == "maps":
+                if v.dim() <= 2 and (v.dim() == 1 or v.shape[1] <= 3):     # per-ray maps only
+                    results[k] += [v.to("cpu", non_blocking=True)]
+            else:
+                results[k] += [v.cpu() if to_cpu else v]
+    if to_cpu == "maps" and rays.is_cuda:
+        torch.cuda.current_stream().synchronize()
     return {k: torch.cat(v, 0) for k, v in results.items()}

@@ -361,6 +361,18 @@ def test_psnr_against_oracle_render():
     assert O.psnr(got["rgb_fine"].numpy(), want["rgb_fine"]) > 90.0
     target = np.random.RandomState(0).uniform(size=want["rgb_fine"].shape).astype(np.float32)
     assert abs(O.psnr(got["rgb_fine"].numpy(), target) - O.psnr(want["rgb_fine"], target)) < 1e-3
+    # keep the frame on the device and score it there; hand only the per-ray maps to the host
+    from mirror_nerf_amd import metrics
+    dev_out = _M().batched_inference(models, _emb(), torch.from_numpy(rays_np).to(DEV), 64, 64, False, 32768, args=args,
+                                     trace_secondary_rays=True, to_cpu=False)
+    assert abs(float(metrics.psnr(dev_out["rgb_fine"], torch.from_numpy(target).to(DEV))) - O.psnr(want["rgb_fine"], target)) < 1e-3
+    maps = _M().batched_inference(models, _emb(), torch.from_numpy(rays_np).to(DEV), 64, 64, False, 32768, args=args,
+                                  trace_secondary_rays=True, to_cpu="maps")
+    assert all(not v.is_cuda and (v.dim() == 1 or v.shape[1] <= 3) for v in maps.values())
+    assert {"rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine"} <= set(maps)
+    assert not any(k.startswith(("weights_", "z_vals_", "pred_normal_")) for k in maps)
+    for k, v in maps.items():
+        assert torch.equal(v, got[k]), k
 
 
 def test_training_reduces_loss():
