@@ -36,12 +36,12 @@ class Embedding(nn.Module):
         return out
 
 
-# Arithmetic of the field kernel's Linears (inference launches):
+# Arithmetic of the field kernel's Linears:
 #   "split" -- every fp32 operand carried as a hi/lo f16 pair on the f16 matrix pipe with fp32 accumulation
 #              (MNRF_SPLIT_F16; agrees with the fp32 chain to ~3e-6, 3.2x faster; default; see
 #              csrc/mnrf_field_split.inc);
 #   "fp32"  -- v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain.
-# The training forward (saved activations) always runs the fp32 kernel.
+# The training path (forward with saved activations, activation gradients, second-order pass) follows the same switch.
 PRECISION = os.environ.get("MNRF_PRECISION", "split")
 
 
