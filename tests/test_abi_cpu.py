@@ -44,6 +44,21 @@ def test_argument_validation_without_gpu(L):
     assert L.mnrf_composite(null, 4, 64, null, null, null, null, null, null, null, 0, null, null, null, null,
                             null, null, null, null, null, null) < 0
     assert L.mnrf_embed(null, -1, 3, 4, null, null) < 0
+    # loss reductions / metric: null argument block, missing outputs, bad sizes
+    assert L.mnrf_total_loss(null, null, null) < 0
+    assert b"mnrf_total_loss" in L.mnrf_last_error()
+    from mirror_nerf_amd.losses import _Args
+    import ctypes
+    a = _Args()
+    a.n_rays = 0
+    ws = (ctypes.c_float * 64)()
+    assert L.mnrf_total_loss(ctypes.byref(a), ctypes.cast(ws, ctypes.c_void_p), null) < 0      # n_rays must be positive
+    a.n_rays = 4
+    assert L.mnrf_total_loss(ctypes.byref(a), ctypes.cast(ws, ctypes.c_void_p), null) < 0      # out / targets / rays missing
+    assert b"required" in L.mnrf_last_error()
+    assert L.mnrf_mse_psnr(null, null, null, 10, 1, null, null, null) < 0
+    assert L.mnrf_loss_workspace_floats(1024, 64, 192, 0) > 1024
+    assert L.mnrf_mse_blocks() >= 1
     # zero-sized work is a no-op, not an error
     assert L.mnrf_embed(null, 0, 3, 4, null, null) == 0
     assert L.mnrf_threshold_mask(null, 0, null, null) == 0
