@@ -420,3 +420,34 @@ def test_split_agrees_with_fp32_chain_full_chunk(precision):
         scale = max(1.0, float(a.abs().max())) if k == "sigma" else 1.0
         err = float((a - b).abs().max())
         assert err <= tol * scale, f"{k}: split vs fp32 {err:.3e} > {tol * scale:.1e}"
+
+
+def test_split_kernel_random_shapes_against_fp32(precision):
+    """Race / schedule check of the split kernels (static LDS-DMA schedule, counted waits, in-place operand overwrite):
+    eight random sizes and sample counts, forward-only and with the density-gradient pass, against the bit-exact
+    kernel.  Bound 5e-5 relative (measured 2e-6); a stale LDS slot or a half-converted operand would be O(1)."""
+    if precision != "split":
+        pytest.skip("one comparison covers both")
+    from mirror_nerf_amd import mirror_nerf as MN
+    from tests.golden import weights as GW
+    m = _module(GW.apply_tweaks(GW.make_state_dict(0, 2)[1], GW.STRADDLE))
+    e = _emb()
+    for it in range(8):
+        torch.manual_seed(100 + it)
+        n = int(torch.randint(500, 20000, (1,)))
+        S = [64, 192, 70, 33][it % 4]
+        rays = torch.randn(n, 8, device=DEV)
+        rays[:, 3:6] = torch.nn.functional.normalize(rays[:, 3:6], dim=1)
+        z = torch.sort(torch.rand(n, S, device=DEV) * 6 + 0.1, 1)[0].contiguous()
+        de = e["dir"](rays[:, 3:6].contiguous())
+        out = {}
+        for mode in ("fp32", "split"):
+            MN.set_precision(mode)
+            out[mode] = MN.field_forward(m, n * S, rays=rays, z_vals=z, spr=S, dir_emb=de, dir_stride=27,
+                                         grad_normal=(it % 2 == 0), sigma_only=(it % 4 == 3))
+        for k in out["fp32"]:
+            if k == "normal":
+                continue        # noise-dominated per sample (tests/golden/fixtures.py)
+            a, b = out["fp32"][k], out["split"][k]
+            d = float((a - b).abs().max() / max(1.0, float(a.abs().max())))
+            assert d < 5e-5, (it, k, d)
