@@ -67,7 +67,7 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     if (bwd) {
         const int nparts = region == 2 ? N_HBWD_PARTS - 1 : N_BWD_PARTS;
         for (;;) {
-            const int np = padded_pairs((parts[k].ntq + 1) / 2 * parts[k].nb);
+            const int np = (parts[k].ntq + 1) / 2 * parts[k].nb;      // parts follow each other without padding
             if (k + 1 >= nparts || pair < pair0 + np) break;
             pair0 += np;
             ++k;
@@ -78,7 +78,7 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
         for (int sg = 0;; ++sg) {
             k = seg_part[sg];
             half = seg_half[sg];
-            const int np = padded_pairs(parts[k].ntq / 2 * (half >= 0 ? 8 : parts[k].nb));
+            const int np = parts[k].ntq / 2 * (half >= 0 ? 8 : parts[k].nb);
             if (sg + 1 >= 27 || pair < pair0 + np) break;
             pair0 += np;
         }

@@ -104,15 +104,25 @@ constexpr int64_t PACKED_F32_FLOATS = OFF_HBWD + (int64_t)HBWD_TILES * TILE_FLOA
 //      One MFMA contracts 32 columns = two fp32 k-blocks: half j of lane l of "pair" (T, nb) is float
 //      (j&3) of lane l of the fp32 tile (2T + (j>>2), nb) -- the fp32 B operands 8T..8T+7 of a lane,
 //      in order, are the 8 halves of its f16 B operand, so activations still never leave their lane.
-//      A pair = [hi tile 1 KiB][lo tile 1 KiB]; parts are padded to PAD_PAIRS pairs.
+//      A pair = [hi tile 1 KiB][lo tile 1 KiB].  Parts follow each other WITHOUT padding (the kernels' LDS-DMA schedule
+//      is one piece per GEMM unit over one continuous stream, whatever the chunk size; mnrf_field_split.inc); only
+//      the end of a stream is padded to SPLIT_END_PAD pairs.  Positions of the parts (in pairs):
+//      forward  L1 0|16, L2 32|96, L3 160|224, L4 288|352, L5 416 (enc) 432 (h) | 496 (enc) 512 (h), L6 576|640, L7 704|768,
+//               L8 832|896 (each trunk layer in two halves of 8 row blocks), sigma 960, normal_net.0 968, normal_net.1 1032,
+//               is_mirror_net.0 1036, is_mirror_net.2 1100, xyz_encoding_final 1104, dir_encoding 1232 (final) 1296 (view),
+//               rgb 1304, end 1308
+//      trunk^T  L8 0, L7 128, L6 256, L5 384 (encoding rows) 416 (hidden rows), L4 544, L3 672, L2 800, L1 928, end 960
+//      heads^T  rgb 0, dir (final columns) 8, dir (view columns) 72, final 80, normal_net.1 208, normal_net.0 216,
+//               is_mirror_net.2 280, is_mirror_net.0 288, end 352
 constexpr int PAIR_BYTES = 2048;
-constexpr int PAD_PAIRS = 16;
-__host__ __device__ constexpr int padded_pairs(int n) { return (n + PAD_PAIRS - 1) / PAD_PAIRS * PAD_PAIRS; }
-constexpr int SPLIT_FWD_PAIRS_SIGMA = 32 + 3 * 128 + (32 + 128) + 3 * 128 + 16;                   // 976
-constexpr int SPLIT_FWD_PAIRS = SPLIT_FWD_PAIRS_SIGMA + 64 + 16 + 64 + 16 + 128 + 64 + 16 + 16;     // 1360
+constexpr int SPLIT_END_PAD = 16;
+__host__ __device__ constexpr int padded_pairs(int n) { return (n + SPLIT_END_PAD - 1) / SPLIT_END_PAD * SPLIT_END_PAD; }
+constexpr int SPLIT_FWD_USED_SIGMA = 960 + 8;
+constexpr int SPLIT_FWD_USED = SPLIT_FWD_USED_SIGMA + 64 + 4 + 64 + 4 + 128 + 64 + 8 + 4;            // 1308
+constexpr int SPLIT_FWD_PAIRS = padded_pairs(SPLIT_FWD_USED);                                        // 1312
 constexpr int SPLIT_BWD_PAIRS = 3 * 128 + 32 + 128 + 3 * 128 + 32;                                  // 960
 // head-backward parts (training): a contraction over 16 rows (ntq = 1) fills half of a 32-wide MFMA step, the rest is zero
-constexpr int SPLIT_HBWD_PAIRS = 16 + 64 + 16 + 128 + 16 + 64 + 16 + 64;                            // 384
+constexpr int SPLIT_HBWD_PAIRS = padded_pairs(8 + 64 + 8 + 128 + 8 + 64 + 8 + 64);                  // 352
 constexpr int64_t OFF_SPLIT_FWD = PACKED_F32_FLOATS;
 constexpr int64_t OFF_SPLIT_BWD = OFF_SPLIT_FWD + (int64_t)SPLIT_FWD_PAIRS * (PAIR_BYTES / 4);
 constexpr int64_t OFF_SPLIT_HBWD = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4);
