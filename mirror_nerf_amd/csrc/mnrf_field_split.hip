@@ -30,7 +30,23 @@ constexpr int RING_SLOTS = 3;
 #include "mnrf_field_split.inc"
 #include "mnrf_field_split_bwd.inc"
 }  // namespace h2x
+#ifdef MNRF_EXP_H1
+// experiment: 16 samples per wave, <= 256 registers, two workgroups per CU (two waves share each SIMD's matrix pipe)
+namespace h1 {
+constexpr int S = 1;
+constexpr int MIN_WAVES_PER_SIMD = 2;
+constexpr int CHUNK_PAIRS = 8;
+constexpr int RING_SLOTS = 3;
+#define MNRF_SPLIT_NO_GRAD
+#include "mnrf_field_split.inc"
+#undef MNRF_SPLIT_NO_GRAD
+}  // namespace h1
+#endif
+
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s) {
+#ifdef MNRF_EXP_H1
+    if (variant == 3 && !grad) return h1::launch(A, sigma_only, grad, s);
+#endif
     // variant 0: measured default -- 16 KiB chunks for the forward-only kernels (17.2 vs 17.3 ms per 6.29 M full
     // samples), 32 KiB chunks when the density-gradient pass is on (32.1 vs 34.1 ms); 1 / 2 force h2 / h2x.
     // A 16-samples-per-wave tuning with two workgroups per CU (as s1 of the fp32 kernel) was tried and dropped:

@@ -48,7 +48,7 @@ PRECISION = os.environ.get("MNRF_PRECISION", "split")
 def set_precision(mode):
     """Select the arithmetic of the inference field kernel: "fp32" or "split"."""
     global PRECISION
-    if mode not in ("fp32", "split", "split_h2", "split_h2x"):
+    if mode not in ("fp32", "split", "split_h2", "split_h2x", "split_h1"):
         raise ValueError("precision must be 'fp32' or 'split'")
     PRECISION = mode
 
@@ -87,6 +87,8 @@ def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, 
         flags |= _lib.MNRF_SPLIT_F16 | 8
     elif PRECISION == "split_h2x":   # experiments only: force 32 KiB chunks
         flags |= _lib.MNRF_SPLIT_F16 | 16
+    elif PRECISION == "split_h1":    # experiments only (library built with -DMNRF_EXP_H1)
+        flags |= _lib.MNRF_SPLIT_F16 | 24
     p = _lib.ptr
     if LAUNCH_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
