@@ -53,6 +53,28 @@ def set_precision(mode):
     PRECISION = mode
 
 
+def verify_split(module, n=8192, bound=4.0, seed=0):
+    """Evaluate `module` on n random positions of [-bound, bound]^3 with both arithmetics and return the largest
+    difference of each output relative to max(1, |fp32 output|).  ~3e-6 is normal; a large value means some activation
+    left the range the f16 hi/lo pairs carry (> 1.3e5) -- use set_precision("fp32") for that model."""
+    global PRECISION
+    dev = next(module.parameters()).device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = (torch.rand(n, 3, device=dev, generator=g) * 2 - 1) * bound
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=1)
+    de = Embedding(4)(d)
+    old, out = PRECISION, {}
+    try:
+        for mode in ("fp32", "split"):
+            PRECISION = mode
+            out[mode] = field_forward(module, n, xyz=x.contiguous(), xyz_stride=3, spr=1, dir_emb=de, dir_stride=27)
+    finally:
+        PRECISION = old
+    return {k: float((out["fp32"][k] - out["split"][k]).abs().max() / max(1.0, float(out["fp32"][k].abs().max())))
+            for k in out["fp32"]}
+
+
 # When a list is installed here, every field-kernel launch is bracketed by two events on the
 # launching stream and (flags, B, start, end) is appended -- bench.py reads kernel time from it.
 LAUNCH_LOG = None

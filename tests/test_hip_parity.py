@@ -451,3 +451,21 @@ def test_split_kernel_random_shapes_against_fp32(precision):
             a, b = out["fp32"][k], out["split"][k]
             d = float((a - b).abs().max() / max(1.0, float(a.abs().max())))
             assert d < 5e-5, (it, k, d)
+
+
+def test_verify_split_reports_range_problems(precision):
+    """mirror_nerf.verify_split: ~1e-6 on a normal model; a model whose activations leave the range of the f16 hi/lo
+    pairs (weights of the first layer scaled until h1 ~ 1e6) is reported as such -- the documented limit of the split."""
+    if precision != "split":
+        pytest.skip("one check covers both")
+    from mirror_nerf_amd import mirror_nerf as MN
+    from tests.golden import weights as GW
+    sd = GW.make_state_dict(0, 1)[0]
+    m = _module(sd)
+    rep = MN.verify_split(m)
+    assert max(rep.values()) < 2e-5, rep
+    big = {k: v.copy() for k, v in sd.items()}
+    big["xyz_encoding_1.0.weight"] *= 3e6
+    rep = MN.verify_split(_module(big))
+    assert max(rep.values()) > 1e-3, rep
+    assert MN.PRECISION == "split"
