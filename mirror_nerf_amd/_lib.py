@@ -74,7 +74,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile csrc/*.hip for gfx950 into libmnrf_hip.so (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j4", "-C", CSRC], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout + r.stderr)
     if r.returncode != 0:
