@@ -28,14 +28,15 @@ def _f(dev, *s):
     return torch.empty(*s, dtype=torch.float32, device=dev)
 
 
-def _threshold_(mask):
-    """In place m[m>0.5]=1, m[m<0.5]=0 (exactly 0.5 untouched); returns any(m != 0) as a bool."""
+def _threshold_(mask, want_any=True):
+    """In place m[m>0.5]=1, m[m<0.5]=0 (exactly 0.5 untouched); returns any(m != 0) as a bool.
+    want_any=False skips the device->host read of the flag (a stream sync) when the caller does not branch on it."""
     n = mask.shape[0]
     flag = torch.zeros(1, dtype=torch.int32, device=mask.device)
     if n:
         _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), n, _lib.ptr(flag), _lib.stream()),
                    "mnrf_threshold_mask")
-    return bool(flag.item())
+    return bool(flag.item()) if want_any else False
 
 
 def _reflect(rays, x_surface, normal, mask, compact, normal_noise=None, noise_std=0.0, want_dir=True):
@@ -271,7 +272,10 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
             if key in r:
                 mask = r[key]
                 break
-        any_mirror = _threshold_(mask) if mask is not None else False     # in place (eval.py:303-307)
+        # in place (eval.py:303-307); at the last level nothing branches on "any mirror pixel": no host read, so the next
+        # chunk's launches queue behind this pass without a stream sync
+        last = level >= args.max_recursive_level or not trace_flag
+        any_mirror = _threshold_(mask, want_any=not last) if mask is not None else False
         trace = bool(mask is not None and any_mirror and trace_flag)
         if level >= args.max_recursive_level:
             trace = False
