@@ -114,6 +114,8 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     # -- mirror mask (train.py:153-168)
     gt = extra_chunk["mirror_mask"].float()
     any_mirror = None
+    # nothing branches on "any mirror pixel" when this level cannot trace: no device->host reads (stream syncs) then
+    can_trace = bool(hp.trace_secondary_rays and (not train_geometry_stage) and recur_level < hp.max_recursive_level)
     if recur_level > 0 or bool((gt < 0).any().item()):
         # the reference thresholds `results[...].detach()` in place: the returned predicted
         # mask is the hard one
@@ -123,7 +125,7 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
             mask = r["mirror_mask_coarse"]
         else:
             mask = torch.zeros(N, device=dev)
-        any_mirror = _threshold_(mask.detach())   # in place on the shared storage, like the reference
+        any_mirror = _threshold_(mask.detach(), want_any=can_trace)   # in place on the shared storage, like the reference
         mask = mask.detach()
     else:
         mask = gt.clone().contiguous()
@@ -132,7 +134,7 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
         mask = mask * mirror_mask_prev.float()
         any_mirror = None
     if any_mirror is None:
-        any_mirror = bool((mask != 0).any().item()) if N else False
+        any_mirror = bool((mask != 0).any().item()) if (N and can_trace) else False
 
     # -- trace decision (train.py:170-178)
     trace = bool(hp.trace_secondary_rays and (not train_geometry_stage) and (any_mirror or hp.for_vis))
