@@ -173,19 +173,23 @@ def main():
     ms_sig = sum(t for _, t in sig)
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
 
-    # the other arithmetic on one fine-pass launch of the same chunk size, for the record
+    # the other arithmetic on ONE whole frame of the same workload (rank 0), for the record: rays/s and the dominant
+    # kernel's rate under it
     other = "fp32" if a.precision == "split" else "split"
-    other_tf = None
+    other_tf = other_rays = other_ms = None
     if rank == 0:
         MN.set_precision(other)
-        MN.LAUNCH_LOG = []
-        with torch.no_grad():
-            for _ in range(3):
-                M.render_rays(models, emb, rays[:CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, test_time=True,
-                              compute_normal=False)
+        frame()                      # warm-up (first launches of the other kernels)
         torch.cuda.synchronize()
-        t_o = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG[2:] if not (flags & 1)]
+        MN.LAUNCH_LOG = []
+        t1 = time.perf_counter()
+        frame()
+        torch.cuda.synchronize()
+        dt_o = time.perf_counter() - t1
+        t_o = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG if not (flags & 1)]
         other_tf = sum(B for B, _ in t_o) * MN.FLOP_FULL / (sum(t for _, t in t_o) * 1e-3) / 1e12
+        other_rays = (H * W * 2) / dt_o
+        other_ms = sum(t for _, t in t_o) / max(1, len(t_o))
         MN.LAUNCH_LOG = None
         MN.set_precision(a.precision)
 
@@ -239,7 +243,10 @@ def main():
                          "kernel": ("mnrf::h2::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>")
                                    + " (full 4-head evaluation, fine pass)",
                          "other_precision": {"precision": other, "achieved": other_tf,
-                                             "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS},
+                                             "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
+                                             "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
+                                             "avg_launch_ms": other_ms, "rays_per_s": other_rays,
+                                             "note": "one frame of the same workload with the other arithmetic"},
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
                          "flop_per_sample": MN.FLOP_FULL,
                          "sigma_only_kernel_tflops": sig_tf,
