@@ -40,8 +40,8 @@ def main():
               f"{len(smem)} scalar loads inside, {len(scratch)} scratch ops inside")
         if smem or (scratch and not grad) or counted < 100:
             ok = False
-    # split-f16 kernels: same rule for their counted lgkmcnt waits; M0 is written by hand for the LDS-DMA pieces,
-    # so nothing else may touch it; and nothing may spill
+    # split-f16 kernels: same rule for their counted lgkmcnt waits (the LDS-DMA pieces go through the compiler's builtin,
+    # which owns M0 and the VMEM hazards); and nothing may spill
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "split.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-S",
@@ -55,12 +55,11 @@ def main():
         smem = [l for l in inner if re.search(r"\bs_(buffer_)?load_", l)]
         scratch = [l for l in body if "scratch_" in l]
         counted = sum(bool(re.search(r"s_waitcnt lgkmcnt\([24]\)", l)) for l in inner)
-        other_m0 = [l for l in body if re.search(r"\bm0\b", l) and "s_mov_b32 m0" not in l]
         dma = sum("global_load_lds_dwordx4" in l for l in body)
         print(f"{name}: {len(mf)} MFMA, {dma} LDS-DMA pieces, {counted} counted waits, {len(smem)} scalar loads inside, "
-              f"{len(scratch)} scratch ops, {len(other_m0)} other M0 uses")
+              f"{len(scratch)} scratch ops")
         n += 1
-        if smem or scratch or other_m0 or counted < 100:
+        if smem or scratch or counted < 100:
             ok = False
     if n != 8:
         print(f"expected 8 split kernels, found {n}")
