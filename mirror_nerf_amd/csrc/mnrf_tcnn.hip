@@ -294,6 +294,460 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
 }
 #undef VEC
 
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the hash-grid field (training of config 5; autograd equivalent of loss.backward() through
+// models/mirror_nerf_tcnn.py:220-259, models/gridencoder/src/gridencoder.cu:275-380 [kernel_grid_backward: atomicAdd of
+// w * dL/dout into the table gradient] and models/shencoder/src/shencoder.cu:81-160 [dL/d direction]).
+//
+// One thread per sample, 256-sample tiles, persistent workgroups (one per CU).  Nothing is saved by the forward: the tile is
+// re-evaluated head by head and every head is differentiated as soon as it has been evaluated, so that at most one layer's
+// input X (<= 64 features) and half a layer's pre-activation gradient G (32 features) sit in LDS, feature-major
+// [feature][sample] -- which is exactly the operand layout of the weight-gradient product dW[n][k] = sum_s G[n][s] X[k][s]:
+// each wave keeps its share of the 52 16x16 gradient tiles in registers across ALL tiles of the workgroup and feeds them
+// with v_mfma_f32_16x16x4_f32 (exact fp32; the four k slots of a step are four consecutive samples of one ds_read_b128 --
+// the sum over samples does not care about their order).  Row stride 260 floats: the (16 rows x 4 sample quads) of a
+// ds_read_b128 pass hit 16 different bank quads.  Activation gradients go through the same rows: dX = W^T G is a loop over
+// the rows of G (wave-uniform weight rows from LDS, as in the forward).  At the end every workgroup adds its tiles to the
+// gradient blob (<= 256 atomic adds per weight); the table gradient is scattered with global_atomic_add_f32 like the
+// reference does.  First-order only: the density-gradient normal is a constant of the graph here.
+constexpr int BT = 256;                         // samples per tile = threads
+constexpr int RS = BT + 4;                      // row stride (floats)
+constexpr int XO = VEC_OFF;                     // X rows: 64
+constexpr int GO = XO + 64 * RS;                // G rows: 32
+constexpr int BWD_LDS_FLOATS = GO + 32 * RS;
+#define XR(k) wlds[XO + (k) * RS + threadIdx.x]
+#define GR(k) wlds[GO + (k) * RS + threadIdx.x]
+
+struct TcnnBwdArgs {
+    TcnnArgs f;                                  // inputs as in the forward (outputs unused)
+    const float* g_sigma; const float* g_rgb; const float* g_pn; const float* g_m;   // dL/d outputs, any may be null
+    float* d_table;                              // (entries, 2), zero-initialised by the caller; accumulated
+    float* d_weights;                            // W_TOTAL floats, zero-initialised by the caller; accumulated
+    float* d_xyz;                                // (B,3) or null
+    float* d_dir;                                // (B,3) or null
+};
+
+__device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// acc[r] += sum over the tile's samples of G[g0 + 4*(lane>>4) + r][s] * X[x0 + (lane&15)][s]
+__device__ __forceinline__ void dw_tile(f32x4& acc, int g0, int x0) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
+    const float* gp = wlds + GO + (g0 + i) * RS + 4 * q;
+    const float* xp = wlds + XO + (x0 + i) * RS + 4 * q;
+#pragma unroll 4
+    for (int s = 0; s < BT; s += 16) {
+        const f32x4 a = *(const f32x4*)(gp + s);
+        const f32x4 b = *(const f32x4*)(xp + s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+    }
+}
+
+// acc[i] += sum_r G[r] * W[woff + r*K + i]   (this thread's column of the G rows; wave-uniform weight rows)
+template <int K>
+__device__ __forceinline__ void back_rows(int nrows, int woff, float (&acc)[K]) {
+#pragma unroll 1
+    for (int r = 0; r < nrows; ++r) {
+        const float s = GR(r);
+#pragma unroll
+        for (int i = 0; i < K; i += 4) {
+            const f32x4 w = *(const f32x4*)(wlds + woff + r * K + i);
+            acc[i] = fmaf(s, w[0], acc[i]); acc[i + 1] = fmaf(s, w[1], acc[i + 1]);
+            acc[i + 2] = fmaf(s, w[2], acc[i + 2]); acc[i + 3] = fmaf(s, w[3], acc[i + 3]);
+        }
+    }
+}
+
+// add a register tile to the gradient blob: rows n < nmax of a (N x K) matrix at woff; column `bias_col` (>= 0) of the
+// tile is the bias gradient and goes to boff + n
+__device__ __forceinline__ void flush_tile(float* dst, const f32x4& acc, int woff, int K, int n0, int k0, int nmax,
+                                           int kmax, int bias_col, int boff) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * q + r, k = k0 + i;
+        if (n >= nmax) continue;
+        if (k < kmax) fadd(dst + woff + n * K + k, acc[r]);
+        else if (k == bias_col) fadd(dst + boff + n, acc[r]);
+    }
+}
+
+__device__ __forceinline__ void sh4(const float (&d)[3], float* in) {
+    const float X = d[0], Y = d[1], Z = d[2];
+    const float xy = X * Y, xz = X * Z, yz = Y * Z, x2 = X * X, y2 = Y * Y, z2 = Z * Z;
+    in[0] = 0.28209479177387814f;
+    in[1] = -0.48860251190291987f * Y;
+    in[2] = 0.48860251190291987f * Z;
+    in[3] = -0.48860251190291987f * X;
+    in[4] = 1.0925484305920792f * xy;
+    in[5] = -1.0925484305920792f * yz;
+    in[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    in[7] = -1.0925484305920792f * xz;
+    in[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    in[9] = 0.59004358992664352f * Y * (-3.0f * x2 + y2);
+    in[10] = 2.8906114426405538f * xy * Z;
+    in[11] = 0.45704579946446572f * Y * (1.0f - 5.0f * z2);
+    in[12] = 0.3731763325901154f * Z * (5.0f * z2 - 3.0f);
+    in[13] = 0.45704579946446572f * X * (1.0f - 5.0f * z2);
+    in[14] = 1.4453057213202769f * Z * (x2 - y2);
+    in[15] = 0.59004358992664352f * X * (-x2 + 3.0f * y2);
+}
+
+// dL/d direction from dL/d SH (the derivative polynomials of the 16 basis functions above)
+__device__ __forceinline__ void sh4_backward(const float (&d)[3], const float* g, float (&gd)[3]) {
+    const float X = d[0], Y = d[1], Z = d[2];
+    const float x2 = X * X, y2 = Y * Y, z2 = Z * Z;
+    const float a = 0.48860251190291987f, b = 1.0925484305920792f, c = 0.94617469575755997f, e = 0.54627421529603959f;
+    const float f = 0.59004358992664352f, gg = 2.8906114426405538f, h = 0.45704579946446572f, k = 0.3731763325901154f;
+    const float m = 1.4453057213202769f;
+    gd[0] = -a * g[3] + b * Y * g[4] - b * Z * g[7] + 2.f * e * X * g[8] - 6.f * f * X * Y * g[9] + gg * Y * Z * g[10]
+            + h * (1.f - 5.f * z2) * g[13] + 2.f * m * X * Z * g[14] + 3.f * f * (y2 - x2) * g[15];
+    gd[1] = -a * g[1] + b * X * g[4] - b * Z * g[5] - 2.f * e * Y * g[8] + 3.f * f * (y2 - x2) * g[9] + gg * X * Z * g[10]
+            + h * (1.f - 5.f * z2) * g[11] - 2.f * m * Y * Z * g[14] + 6.f * f * X * Y * g[15];
+    gd[2] = a * g[2] - b * Y * g[5] + 2.f * c * Z * g[6] - b * X * g[7] + gg * X * Y * g[10] - 10.f * h * Y * Z * g[11]
+            + k * (15.f * z2 - 3.f) * g[12] - 10.f * h * X * Z * g[13] + m * (x2 - y2) * g[14];
+}
+
+__global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
+    const TcnnArgs& A = P.f;
+    for (int k = threadIdx.x; k < W_TOTAL; k += BT) wlds[k] = A.weights[k];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's gradient tiles (see the tile maps at their dw_tile calls)
+    f32x4 t_s0[2] = {z4, z4}, t_s1 = z4, t_c0[2] = {z4, z4}, t_c1[2][2] = {{z4, z4}, {z4, z4}}, t_c2 = z4;
+    f32x4 t_n0[2] = {z4, z4}, t_n1 = z4, t_m0 = z4, t_m1 = z4;
+    float db_m1 = 0.f;
+    const long long ntiles = (A.B + BT - 1) / BT;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        long long i = tile * BT + threadIdx.x;
+        const bool live = i < A.B;
+        if (!live) i = A.B - 1;
+        float x[3], d[3];
+        if (A.xyz) {
+            const float* p = A.xyz + i * A.xyz_stride;
+            x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+            d[0] = p[3]; d[1] = p[4]; d[2] = p[5];
+        } else {
+            const long long ray = i / A.spr;
+            const float* r = A.rays + ray * 8;
+            const float z = A.z_vals[i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) x[a] = r[a] + r[3 + a] * z;
+            const float* dp = A.dirs ? A.dirs + ray * A.dir_stride : r + 3;
+            d[0] = dp[0]; d[1] = dp[1]; d[2] = dp[2];
+        }
+        const float g_sigma = (live && P.g_sigma) ? P.g_sigma[i] : 0.f;
+        float g_rgb[3], g_pn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            g_rgb[a] = (live && P.g_rgb) ? P.g_rgb[i * 3 + a] : 0.f;
+            g_pn[a] = (live && P.g_pn) ? P.g_pn[i * 3 + a] : 0.f;
+        }
+        const float g_m = (live && P.g_m) ? P.g_m[i] : 0.f;
+        float u[3];
+        bool oob = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            u[a] = (x[a] + A.bound) / (2.f * A.bound);
+            oob |= u[a] < 0.f || u[a] > 1.f;
+        }
+        // ---- forward trunk: encoding -> h1 -> (sigma, geo)
+        unsigned long long bits_h1 = 0;
+        float geo[16];
+        {
+#pragma unroll 1
+            for (int lv = 0; lv < NL; ++lv) {
+                float a0, a1, g0[3], g1[3];
+                encode_level<false>(A, lv, u, oob, a0, a1, g0, g1);
+                XR(2 * lv) = a0;
+                XR(2 * lv + 1) = a1;
+            }
+            float in[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) in[k] = XR(k);
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) {
+                const float pre = dot_row(in, W_S0 + o * 32);
+                bits_h1 |= (unsigned long long)(pre > 0.f) << o;
+                XR(o) = fmaxf(pre, 0.f);
+            }
+            float h1[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) h1[k] = XR(k);
+#pragma unroll 1
+            for (int o = 1; o < 16; ++o) GR(o) = dot_row(h1, W_S1 + o * 64);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) geo[k] = GR(1 + k);
+            geo[15] = 0.f;
+        }
+        float g_geo[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) g_geo[k] = 0.f;
+
+        // ---- predicted-normal head: geo -> hn (ReLU) -> v -> l2-normalise
+        if (P.g_pn) {
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(geo, W_N0 + o * 16), 0.f);
+            float hn[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) hn[k] = XR(k);
+            float v[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) v[o] = dot_row(hn, W_N1 + o * 64);
+            const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            const float inv = 1.f / sqrtf(fmaxf(n2, EPS32));
+            float g_v[3];
+            {   // y = v * inv:  dL/dv = inv * (g - y (y.g)) above the clamp, inv * g below it
+                const float y0 = v[0] * inv, y1 = v[1] * inv, y2 = v[2] * inv;
+                const float dotp = n2 > EPS32 ? y0 * g_pn[0] + y1 * g_pn[1] + y2 * g_pn[2] : 0.f;
+                g_v[0] = inv * (g_pn[0] - y0 * dotp); g_v[1] = inv * (g_pn[1] - y1 * dotp); g_v[2] = inv * (g_pn[2] - y2 * dotp);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) GR(k) = k < 3 ? g_v[k] : 0.f;
+            __syncthreads();
+            dw_tile(t_n1, 0, 16 * wave);                       // normal_net.1 (3 x 64): k block = wave
+            // dL/dhn, masked by the ReLU
+#pragma unroll
+            for (int o = 0; o < 64; ++o) {
+                const float gh = fmaf(wlds[W_N1 + o], g_v[0], fmaf(wlds[W_N1 + 64 + o], g_v[1], wlds[W_N1 + 128 + o] * g_v[2]));
+                hn[o] = hn[o] > 0.f ? gh : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) XR(k) = geo[k];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) GR(k) = hn[32 * h + k];
+                __syncthreads();
+                if (wave < 2) dw_tile(t_n0[h], 16 * wave, 0);   // normal_net.0 (64 x 16): row block 2h + wave
+                back_rows<16>(32, W_N0 + 32 * h * 16, g_geo);
+                __syncthreads();
+            }
+        }
+        // ---- mirror head: geo -> hm (LeakyReLU, bias) -> sigmoid (bias)
+        if (P.g_m) {
+            unsigned bits_m = 0;
+#pragma unroll 1
+            for (int o = 0; o < 32; ++o) {
+                const float v = dot_row(geo, W_M0 + o * 16) + wlds[B_M0 + o];
+                bits_m |= (unsigned)(v > 0.f) << o;
+                XR(o) = v > 0.f ? v : 0.01f * v;
+            }
+            float hm[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) hm[k] = XR(k);
+            const float m = 1.f / (1.f + expf(-(dot_row(hm, W_M1) + wlds[B_M1])));
+            const float g_z = g_m * m * (1.f - m);
+            db_m1 += g_z;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) GR(k) = k == 0 ? g_z : 0.f;
+            __syncthreads();
+            if (wave < 2) dw_tile(t_m1, 0, 16 * wave);          // is_mirror_net.2 (1 x 32): k block = wave
+#pragma unroll
+            for (int o = 0; o < 32; ++o) hm[o] = wlds[W_M1 + o] * g_z * (((bits_m >> o) & 1u) ? 1.f : 0.01f);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) XR(k) = k < 15 ? geo[k] : 1.f;      // feature 15 = 1: its column is the bias gradient
+#pragma unroll
+            for (int k = 0; k < 32; ++k) GR(k) = hm[k];
+            __syncthreads();
+            if (wave < 2) dw_tile(t_m0, 16 * wave, 0);          // is_mirror_net.0 (32 x 16): row block = wave
+            back_rows<16>(32, W_M0, g_geo);                     // (column 15 of the padded weights is zero)
+            __syncthreads();
+        }
+        // ---- colour head: [SH4(d), geo] -> c1 (ReLU) -> c2 (ReLU) -> sigmoid
+        float g_dir[3] = {0.f, 0.f, 0.f};
+        if (P.g_rgb) {
+            float in[32];
+            sh4(d, in);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) in[16 + k] = geo[k];
+            in[31] = 0.f;
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(in, W_C0 + o * 32), 0.f);
+            float c1[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) c1[k] = XR(k);
+            unsigned long long bits_c1 = 0, bits_c2 = 0;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) bits_c1 |= (unsigned long long)(c1[k] > 0.f) << k;
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) {
+                const float pre = dot_row(c1, W_C1 + o * 64);
+                bits_c2 |= (unsigned long long)(pre > 0.f) << o;
+                XR(o) = fmaxf(pre, 0.f);
+            }
+            float g_z[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) a = fmaf(wlds[W_C2 + k * 64 + j], XR(j), a);
+                const float c = 1.f / (1.f + expf(-a));
+                g_z[k] = g_rgb[k] * c * (1.f - c);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) GR(k) = k < 3 ? g_z[k] : 0.f;
+            __syncthreads();
+            dw_tile(t_c2, 0, 16 * wave);                        // color_net.2 (3 x 64): k block = wave
+            float g_c2[64];
+#pragma unroll
+            for (int o = 0; o < 64; ++o) {
+                const float gh = fmaf(wlds[W_C2 + o], g_z[0], fmaf(wlds[W_C2 + 64 + o], g_z[1], wlds[W_C2 + 128 + o] * g_z[2]));
+                g_c2[o] = ((bits_c2 >> o) & 1ull) ? gh : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 64; ++k) XR(k) = c1[k];
+            float g_c1[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g_c1[k] = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) GR(k) = g_c2[32 * h + k];
+                __syncthreads();
+                dw_tile(t_c1[h][0], 0, 16 * wave);              // color_net.1 (64 x 64): row blocks 2h, 2h+1; k block = wave
+                dw_tile(t_c1[h][1], 16, 16 * wave);
+                back_rows<64>(32, W_C1 + 32 * h * 64, g_c1);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g_c1[k] = ((bits_c1 >> k) & 1ull) ? g_c1[k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) XR(k) = in[k];
+            float g_in[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) g_in[k] = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) GR(k) = g_c1[32 * h + k];
+                __syncthreads();
+                dw_tile(t_c0[h], 16 * (wave >> 1), 16 * (wave & 1));   // color_net.0 (64 x 32): row block 2h + wave/2, k block wave%2
+                back_rows<32>(32, W_C0 + 32 * h * 32, g_in);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 15; ++k) g_geo[k] += g_in[16 + k];
+            if (P.d_dir) sh4_backward(d, g_in, g_dir);
+        }
+        if (P.d_dir && live) { P.d_dir[i * 3] = g_dir[0]; P.d_dir[i * 3 + 1] = g_dir[1]; P.d_dir[i * 3 + 2] = g_dir[2]; }
+
+        // ---- trunk: (g_sigma, g_geo) -> sigma_net.1 -> h1 (ReLU) -> sigma_net.0 -> encoding -> table
+        float enc[32];
+        {
+#pragma unroll 1
+            for (int lv = 0; lv < NL; ++lv) {
+                float a0, a1, g0[3], g1[3];
+                encode_level<false>(A, lv, u, oob, a0, a1, g0, g1);
+                XR(2 * lv) = a0;
+                XR(2 * lv + 1) = a1;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) enc[k] = XR(k);
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(enc, W_S0 + o * 32), 0.f);
+        }
+        GR(0) = g_sigma;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) GR(1 + k) = g_geo[k];
+        __syncthreads();
+        dw_tile(t_s1, 0, 16 * wave);                            // sigma_net.1 (16 x 64): k block = wave
+        float g_h1[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) g_h1[k] = 0.f;
+        back_rows<64>(16, W_S1, g_h1);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) g_h1[k] = ((bits_h1 >> k) & 1ull) ? g_h1[k] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) XR(k) = enc[k];
+        float g_enc[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) g_enc[k] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) GR(k) = g_h1[32 * h + k];
+            __syncthreads();
+            dw_tile(t_s0[h], 16 * (wave >> 1), 16 * (wave & 1));       // sigma_net.0 (64 x 32)
+            back_rows<32>(32, W_S0 + 32 * h * 32, g_enc);
+            __syncthreads();
+        }
+        // ---- encoding backward: table gradient (gridencoder.cu:275-380) and dL/dx through the interpolation weights
+#pragma unroll
+        for (int k = 0; k < 32; ++k) GR(k) = g_enc[k];           // (own column; indexed by level below)
+        float gx[3] = {0.f, 0.f, 0.f};
+        if (live && !oob) {
+#pragma unroll 1
+            for (int lv = 0; lv < NL; ++lv) {
+                const float e0 = GR(2 * lv), e1 = GR(2 * lv + 1);
+                const float scale = A.scale[lv];
+                const unsigned res = A.res[lv];
+                const unsigned hsize = A.off[lv + 1] - A.off[lv];
+                const float2* tab = (const float2*)A.table + A.off[lv];
+                float* dtab = P.d_table + 2ll * A.off[lv];
+                unsigned pg[3];
+                float fr[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float pos = u[a] * scale + 0.5f;
+                    const float fl = floorf(pos);
+                    pg[a] = (unsigned)fl;
+                    fr[a] = pos - fl;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
+                    const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
+                    const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
+                    const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res);
+                    const float w = wx * wy * wz;
+                    fadd(dtab + 2ll * idx, w * e0);
+                    fadd(dtab + 2ll * idx + 1, w * e1);
+                    if (P.d_xyz) {
+                        const float2 v = tab[idx];
+                        const float ev = e0 * v.x + e1 * v.y;
+                        gx[0] += ((c & 1) ? scale : -scale) * wy * wz * ev;
+                        gx[1] += ((c & 2) ? scale : -scale) * wx * wz * ev;
+                        gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
+                    }
+                }
+            }
+        }
+        if (P.d_xyz && live) {
+            const float s = 1.f / (2.f * A.bound);
+            P.d_xyz[i * 3] = gx[0] * s; P.d_xyz[i * 3 + 1] = gx[1] * s; P.d_xyz[i * 3 + 2] = gx[2] * s;
+        }
+    }
+    // ---- this workgroup's share of the weight gradients
+    float* D = P.d_weights;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        flush_tile(D, t_s0[h], W_S0, 32, 32 * h + 16 * (wave >> 1), 16 * (wave & 1), 64, 32, -1, 0);
+        flush_tile(D, t_c0[h], W_C0, 32, 32 * h + 16 * (wave >> 1), 16 * (wave & 1), 64, 32, -1, 0);
+        flush_tile(D, t_c1[h][0], W_C1, 64, 32 * h, 16 * wave, 64, 64, -1, 0);
+        flush_tile(D, t_c1[h][1], W_C1, 64, 32 * h + 16, 16 * wave, 64, 64, -1, 0);
+        if (wave < 2) flush_tile(D, t_n0[h], W_N0, 16, 32 * h + 16 * wave, 0, 64, 16, -1, 0);
+    }
+    flush_tile(D, t_s1, W_S1, 64, 0, 16 * wave, 16, 64, -1, 0);
+    flush_tile(D, t_c2, W_C2, 64, 0, 16 * wave, 3, 64, -1, 0);
+    flush_tile(D, t_n1, W_N1, 64, 0, 16 * wave, 3, 64, -1, 0);
+    if (wave < 2) {
+        flush_tile(D, t_m0, W_M0, 16, 16 * wave, 0, 32, 15, 15, B_M0);
+        flush_tile(D, t_m1, W_M1, 32, 0, 16 * wave, 1, 32, -1, 0);
+    }
+    // bias of is_mirror_net.2: sum of g_z over the workgroup's samples
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) db_m1 += __shfl_xor(db_m1, o);
+    if (lane == 0) fadd(D + B_M1, db_m1);
+}
+#undef XR
+#undef GR
+
 }  // namespace
 
 extern "C" int mnrf_tcnn_weight_floats(void) { return W_TOTAL; }
@@ -332,4 +786,38 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     else if (!grad) hipLaunchKernelGGL((tcnn_kernel<false, false>), grid, block, lds, s, A);
     else hipLaunchKernelGGL((tcnn_kernel<false, true>), grid, block, lds, s, A);
     return mnrf_check_launch("mnrf_tcnn_forward");
+}
+
+extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                  int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
+                                  int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
+                                  int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                  const float* g_is_mirror, float* d_table, float* d_weights, float* d_xyz, float* d_dir,
+                                  void* stream) {
+    if (!table || !offsets17_host || !weights || !d_table || !d_weights)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: null pointer");
+    if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: negative sample count");
+    if (B == 0) return MNRF_OK;
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: need xyz or rays+z_vals");
+    if (xyz && xyz_stride < 6) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: xyz_stride too small");
+    if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: samples per ray must be >= 1");
+    if (bound <= 0.f) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: bound must be positive");
+    TcnnBwdArgs P;
+    TcnnArgs& A = P.f;
+    A.table = table; A.weights = weights; A.B = B; A.xyz = xyz; A.xyz_stride = xyz_stride; A.rays = rays;
+    A.z_vals = z_vals; A.spr = spr; A.dirs = dirs; A.dir_stride = dir_stride; A.bound = bound;
+    for (int l = 0; l < NL; ++l) {
+        A.scale[l] = (float)(exp2((double)l * log2_per_level_scale) * (double)base_resolution - 1.0);
+        A.res[l] = (unsigned)ceilf(A.scale[l]) + 1u;
+        A.off[l] = (unsigned)offsets17_host[l];
+    }
+    A.off[NL] = (unsigned)offsets17_host[NL];
+    A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
+    P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror;
+    P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
+    const long long ntiles = (B + BT - 1) / BT;
+    const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256)), block(BT);      // persistent: one workgroup per CU of the MI355X
+    const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
+    return mnrf_check_launch("mnrf_tcnn_backward");
 }

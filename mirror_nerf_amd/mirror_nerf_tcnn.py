@@ -7,7 +7,11 @@ ordinary parameter `encoder.embeddings` of shape (entries, 2) fp32 laid out leve
 the sizing of models/gridencoder/grid.py:181-194.  tinycudann's private parameter layout is not
 reproduced, so tcnn checkpoints do not interchange (and parity against tcnn is unpinned, SURVEY 8c);
 the small MLPs keep the reference's names (`sigma_net.N.weight`, `color_net.N.weight`,
-`normal_net.N.weight`, `is_mirror_net.{0,2}.{weight,bias}`).  Forward / inference only this round.
+`normal_net.N.weight`, `is_mirror_net.{0,2}.{weight,bias}`).
+
+Training: `TcnnFieldFn` chains the forward kernel with `mnrf_tcnn_backward` (table gradient by atomic scatter, MLP
+weight gradients by in-kernel fp32 MFMA products, dL/d position and dL/d direction).  First order only: the
+density-gradient normal (`normal`) is a constant of the graph.
 """
 import ctypes
 
@@ -30,6 +34,88 @@ def hashgrid_config(bound=1.0, n_levels=16, level_dim=2, base_resolution=16, log
     offsets.append(off)
     return dict(offsets=np.array(offsets, dtype=np.int64), S=float(np.log2(per_level_scale)), H=base_resolution,
                 n_levels=n_levels, level_dim=level_dim, bound=float(bound))
+
+
+# (name, rows, used columns, padded columns) of the weight blob, in blob order; biases follow their matrix
+_BLOB = (("sigma_net.0.weight", 64, 32, 32), ("sigma_net.1.weight", 16, 64, 64), ("color_net.0.weight", 64, 31, 32),
+         ("color_net.1.weight", 64, 64, 64), ("color_net.2.weight", 3, 64, 64), ("normal_net.0.weight", 64, 15, 16),
+         ("normal_net.1.weight", 3, 64, 64), ("is_mirror_net.0.weight", 32, 15, 16), ("is_mirror_net.0.bias", 32, 0, 0),
+         ("is_mirror_net.2.weight", 1, 32, 32), ("is_mirror_net.2.bias", 1, 0, 0))
+
+
+def _offsets17(cfg):
+    return (ctypes.c_int64 * 17)(*[int(v) for v in cfg["offsets"]])
+
+
+class TcnnFieldFn(torch.autograd.Function):
+    """mnrf_tcnn_forward / mnrf_tcnn_backward.
+    apply(module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *mlp_params) ->
+        sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty; not differentiable)
+    Positions/directions come from `xyz6` (B,6) or from rays (N,8) + z_vals (N,spr) with per-ray raw directions
+    `dirs` (N,3; None: the ray direction).  `mlp_params`: the 11 tensors of _BLOB in that order."""
+
+    @staticmethod
+    def forward(ctx, module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *params):
+        B = xyz6.shape[0] if xyz6 is not None else rays.shape[0] * spr
+        c = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+        xyz6, rays, z_vals, dirs = c(xyz6), c(rays), c(z_vals), c(dirs)
+        o = module.field(B, xyz=xyz6, xyz_stride=6, rays=rays, z_vals=z_vals, spr=spr, dirs=dirs,
+                         grad_normal=bool(want_normal))
+        ctx.module, ctx.spr, ctx.B = module, spr, B
+        ctx.save_for_backward(xyz6, rays, z_vals, dirs)
+        ctx.set_materialize_grads(False)
+        normal = o.get("normal")
+        if normal is None:
+            normal = torch.empty(0, 3, dtype=torch.float32, device=o["sigma"].device)
+        ctx.mark_non_differentiable(normal)
+        return o["sigma"], o["rgb"], o["pred_normal"], o["is_mirror"], normal
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, _g_normal):
+        xyz6, rays, z_vals, dirs = ctx.saved_tensors
+        m, B, spr = ctx.module, ctx.B, ctx.spr
+        table = m.encoder.embeddings.detach().contiguous()
+        dev = table.device
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g_sigma, g_rgb, g_pn, g_m = c(g_sigma), c(g_rgb), c(g_pn), c(g_m)
+        need = ctx.needs_input_grad
+        d_table = torch.zeros_like(table)
+        d_blob = torch.zeros(_lib.lib().mnrf_tcnn_weight_floats(), dtype=torch.float32, device=dev)
+        want_x = (xyz6 is not None and need[2]) or (rays is not None and need[3])
+        want_d = (xyz6 is not None and need[2]) or (dirs is not None and need[5]) or (dirs is None and rays is not None and need[3])
+        d_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_x else None
+        d_dir = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_d else None
+        p = _lib.ptr
+        if B:
+            _lib.check(_lib.lib().mnrf_tcnn_backward(
+                p(table), _offsets17(m.cfg), m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
+                p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
+                p(g_m), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
+        grads, off = [], 0
+        for _name, rows, used, padded in _BLOB:
+            if padded:
+                grads.append(d_blob[off:off + rows * padded].view(rows, padded)[:, :used].contiguous())
+                off += rows * padded
+            else:
+                grads.append(d_blob[off:off + rows].clone())
+                off += rows
+        g_xyz6 = g_rays = g_dirs = None
+        if xyz6 is not None and need[2]:
+            g_xyz6 = torch.cat([d_xyz, d_dir], 1)
+        elif rays is not None:
+            N = rays.shape[0]
+            per_ray_dir = d_dir.view(N, spr, 3).sum(1) if d_dir is not None else None
+            if need[3]:   # x = o + d*z  (rendering.py:302)
+                dx = d_xyz.view(N, spr, 3)
+                g_rays = torch.zeros_like(rays)
+                g_rays[:, 0:3] = dx.sum(1)
+                g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
+                if dirs is None:
+                    g_rays[:, 3:6] += per_ray_dir
+            if dirs is not None and need[5]:
+                g_dirs = torch.zeros_like(dirs)
+                g_dirs[:, :3] = per_ray_dir
+        return (None, None, g_xyz6, g_rays, None, g_dirs, None, d_table, *grads)
 
 
 class _Encoder(nn.Module):
@@ -63,11 +149,15 @@ class MirrorNeRFTcnn(nn.Module):
         self._blob = None
         self._blob_key = None
 
+    def mlp_params(self):
+        """The 11 tensors of the weight blob, in blob order (include/mnrf.h)."""
+        return [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight, self.color_net[1].weight,
+                self.color_net[2].weight, self.normal_net[0].weight, self.normal_net[1].weight, self.is_mirror_net[0].weight,
+                self.is_mirror_net[0].bias, self.is_mirror_net[2].weight, self.is_mirror_net[2].bias]
+
     # ---- weight blob of the small MLPs in the order include/mnrf.h documents
     def _weights(self):
-        ps = [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight, self.color_net[1].weight,
-              self.color_net[2].weight, self.normal_net[0].weight, self.normal_net[1].weight, self.is_mirror_net[0].weight,
-              self.is_mirror_net[0].bias, self.is_mirror_net[2].weight, self.is_mirror_net[2].bias]
+        ps = self.mlp_params()
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if key != self._blob_key:
             def pad(w, cols):
@@ -96,7 +186,7 @@ class MirrorNeRFTcnn(nn.Module):
         if want_geo:
             out["geo_feat"] = f(B, 15)
         flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
-        offs = (ctypes.c_int64 * 17)(*[int(v) for v in self.cfg["offsets"]])
+        offs = _offsets17(self.cfg)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_forward(
@@ -113,6 +203,14 @@ class MirrorNeRFTcnn(nn.Module):
         `sigma` has shape (B,) here, as in the reference (235)."""
         x = x.float().contiguous()
         B = x.shape[0]
+        if (not sigma_only and x.shape[1] == 6 and torch.is_grad_enabled()
+                and (x.requires_grad or any(q.requires_grad for q in self.parameters()))):
+            # training: geo_feat is not part of this route (nothing downstream of render_rays reads it)
+            sigma, rgb, pn, mir, normal = TcnnFieldFn.apply(self, 1, x, None, None, None, bool(compute_normal),
+                                                            self.encoder.embeddings, *self.mlp_params())
+            out = {"normal": normal} if compute_normal else {}
+            out.update(sigma=sigma, pred_normal=pn, rgb=rgb, is_mirror=mir.view(B, 1))
+            return out
         o = self.field(B, xyz=x, xyz_stride=x.shape[1], sigma_only=sigma_only, grad_normal=compute_normal, want_geo=True)
         out = {}
         if compute_normal:

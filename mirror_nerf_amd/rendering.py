@@ -89,12 +89,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         raise NotImplementedError("the HIP field kernel is built for Embedding(10)/Embedding(4)")
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
 
-    train = (not hashgrid) and torch.is_grad_enabled() and (rays.requires_grad or any(
+    train = torch.is_grad_enabled() and (rays.requires_grad or any(
         q.requires_grad for mdl in models.values() for q in mdl.parameters()))
 
     # rendering.py:275-277 -- view encoding once per ray
     view = kwargs.get("view_dir", rays[:, 3:6])
-    dir_emb = EmbedFn.apply(view, n_fd) if (train and view.requires_grad) else _embed(view.detach(), n_fd)
+    if hashgrid:
+        dir_emb = view.float().contiguous()          # Embedding(0): the raw direction (train.py:69-70)
+    else:
+        dir_emb = EmbedFn.apply(view, n_fd) if (train and view.requires_grad) else _embed(view.detach(), n_fd)
 
     # rendering.py:283-300 -- coarse depths
     z_steps = kwargs.get("_z_steps")
@@ -171,8 +174,13 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     def inference_train(model, typ, z, noise_key):
         """The same pass with autograd-aware kernels (training)."""
         S = z.shape[1]
-        sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
-                                                    *list(model.parameters()))
+        if hashgrid:
+            from .mirror_nerf_tcnn import TcnnFieldFn
+            sigma, rgb, pn, mir, normal = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
+                                                            model.encoder.embeddings, *model.mlp_params())
+        else:
+            sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
+                                                        *list(model.parameters()))
         noise = kwargs.get(noise_key)
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()

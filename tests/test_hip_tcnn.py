@@ -84,3 +84,102 @@ def test_tcnn_render_rays_matches_oracle_compositing():
     # self-consistency tolerance 5e-4: the fine depths of the two sides differ by ~1e-5 and this field is steep
     assert np.max(np.abs(got["rgb_fine"].cpu().numpy() - rgb)) <= 5e-4
     assert np.max(np.abs(got["mirror_mask_fine"].cpu().numpy() - (wfi * o["is_mirror"].reshape(N, 128)).sum(1))) <= 5e-4
+
+
+# ----------------------------------------------------------------------------------------------------- training
+def _grads_of(model, x6, seeds, which):
+    """Gradients of sum_k <seed_k, out_k> from the HIP path: dict name -> tensor (+ 'x6')."""
+    model.zero_grad()
+    x = x6.clone().requires_grad_(True)
+    out = model(x, compute_normal=False)
+    outs = {"sigma": out["sigma"], "rgb": out["rgb"], "pred_normal": out["pred_normal"], "is_mirror": out["is_mirror"][:, 0]}
+    loss = sum((outs[k] * seeds[k]).sum() for k in which)
+    loss.backward()
+    g = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in model.named_parameters()}
+    g["x6"] = x.grad.clone()
+    return g, outs
+
+
+def _ref_grads(model, x6, seeds, which, cfg, double=False):
+    from tests import torch_ref as R
+    dt = torch.float64 if double else torch.float32
+    w = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    x = x6.detach().to(dt).clone().requires_grad_(True)
+    sigma, rgb, pn, m = R.tcnn_field(w, x, cfg)
+    outs = {"sigma": sigma, "rgb": rgb, "pred_normal": pn, "is_mirror": m}
+    loss = sum((outs[k] * seeds[k].to(dt)).sum() for k in which)
+    loss.backward()
+    g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).float() for k, v in w.items()}
+    g["x6"] = x.grad.float()
+    return g, outs
+
+
+@pytest.mark.parametrize("bound,B,which", [
+    (1.0, 700, ("sigma", "rgb", "pred_normal", "is_mirror")),     # ragged tile (700 = 2*256 + 188)
+    (6.0, 1500, ("sigma", "rgb", "pred_normal", "is_mirror")),
+    (1.0, 300, ("sigma",)), (1.0, 300, ("rgb",)), (1.0, 300, ("pred_normal",)), (1.0, 300, ("is_mirror",)),
+])
+def test_tcnn_backward_matches_torch_autograd(bound, B, which):
+    """mnrf_tcnn_backward against torch.autograd through a plain-torch restatement of the field (tests/torch_ref.py;
+    fp64 for the reference gradients, so the tolerance measures the kernel): table, MLP weights, positions, directions."""
+    m, _w, cfg = _model(bound, seed=3, table_scale=0.3)
+    g = torch.Generator().manual_seed(B)
+    xyz = (torch.rand(B, 3, generator=g) * 2 - 1) * bound
+    xyz[:4] *= 1.4                                         # outside the box: no encoding gradient
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    x6 = torch.cat([xyz, d], 1).to(DEV)
+    seeds = {"sigma": torch.randn(B, generator=g).to(DEV), "rgb": torch.randn(B, 3, generator=g).to(DEV),
+             "pred_normal": torch.randn(B, 3, generator=g).to(DEV), "is_mirror": torch.randn(B, generator=g).to(DEV)}
+    got, outs = _grads_of(m, x6, seeds, which)
+    want, routs = _ref_grads(m, x6, seeds, which, cfg, double=True)
+    for k in ("sigma", "rgb", "is_mirror"):
+        assert float((outs[k] - routs[k].float()).abs().max()) <= 2e-5, k
+    for k, wv in want.items():
+        gv = got[k]
+        assert gv.shape == wv.shape, (k, gv.shape, wv.shape)
+        scale = float(wv.abs().max()) + 1e-12
+        err = float((gv - wv).abs().max())
+        if k == "x6":
+            # d/dx jumps across cell faces and the l2-normalised head amplifies: compare where well conditioned
+            rel = ((gv - wv).abs().max(-1).values / (wv.abs().max(-1).values + 1e-3 * scale))
+            assert float(rel.median()) <= 1e-4 and float((rel < 1e-2).float().mean()) > 0.97, (k, float(rel.median()))
+        else:
+            assert err <= 2e-5 * scale + 1e-7, (k, err, scale)
+    # untouched table entries stay exactly zero
+    assert int((got["encoder.embeddings"] != 0).sum()) <= B * 16 * 8 * 2
+
+
+def test_tcnn_training_step_through_render_rays():
+    """render_rays with hash-grid models under autograd: gradients reach the table and every MLP of both models and
+    agree with torch.autograd through the restated field + compositing on the same sample positions."""
+    import mirror_nerf_amd as M
+    from tests import torch_ref as R
+    mc, _wc, cfg = _model(2.0, 5, table_scale=0.05)
+    mf, _wf, _ = _model(2.0, 6, table_scale=0.05)
+    rays = torch.from_numpy(O.synthetic_rays(6, 6)).to(DEV)
+    rays[:, 6], rays[:, 7] = 2.5, 5.5
+    N = rays.shape[0]
+    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    res = M.render_rays({"coarse": mc, "fine": mf}, emb, rays, 16, False, 0, 0, 16, compute_normal=False)
+    loss = ((res["rgb_coarse"] - target) ** 2).mean() + ((res["rgb_fine"] - target) ** 2).mean() \
+        + 0.1 * res["mirror_mask_fine"].mean() + 0.01 * res["surface_normal_fine"].sum()
+    loss.backward()
+    for mdl, typ in ((mc, "coarse"), (mf, "fine")):
+        z = res[f"z_vals_{typ}"].detach()
+        S = z.shape[1]
+        w = {k: v.detach().double().clone().requires_grad_(True) for k, v in mdl.state_dict().items()}
+        xyz = (rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        x6 = torch.cat([xyz, rays[:, None, 3:6].expand(N, S, 3).reshape(-1, 3)], 1).double()
+        sigma, rgb, pn, mir = R.tcnn_field(w, x6, cfg)
+        comp = R.composite(rays.double(), sigma.view(N, S), z.double(), None, rgb.view(N, S, 3), mir.view(N, S),
+                           pn.view(N, S, 3), None)
+        ref = ((comp["rgb"] - target.double()) ** 2).mean()
+        if typ == "fine":
+            ref = ref + 0.1 * comp["mask"].mean() + 0.01 * comp["sn"].sum()
+        ref.backward()
+        for k, p in mdl.named_parameters():
+            assert p.grad is not None, (typ, k)
+            wv = w[k].grad.float()
+            scale = float(wv.abs().max()) + 1e-12
+            assert float((p.grad - wv).abs().max()) <= 1e-4 * scale + 1e-8, (typ, k, float((p.grad - wv).abs().max()), scale)

@@ -84,3 +84,58 @@ def blend(base, sec, mask, compact):
         part = sec
     m = mask[:, None]
     return m * part + (1 - m) * base
+
+
+def tcnn_field(w, x6, cfg):
+    """MirrorNeRFTcnn.forward (models/mirror_nerf_tcnn.py:220-259) with torch ops: the hash-grid cells and interpolation
+    weights follow the oracle (`hashgrid_encode` / `_grid_index`), the table look-up is a differentiable gather.
+    w: dict of torch tensors (state_dict names), x6 (B,6) = [xyz, raw direction].  Returns sigma (B), rgb, pred_normal,
+    is_mirror (B)."""
+    import numpy as np
+    from oracle import mirror_nerf_oracle as O
+    xyz, d = x6[:, :3], x6[:, 3:6]
+    bound = cfg["bound"]
+    # cell coordinates in fp32 like the kernel (a cell of the finest level is 2e-4 of the box: fp64 coordinates would
+    # differ from the kernel's by 1e-4 of a cell); everything after the interpolation weights runs in the dtype of w
+    x01 = (xyz.float() + bound) / (2 * bound)
+    oob = ((x01 < 0) | (x01 > 1)).any(-1)
+    table = w["encoder.embeddings"]
+    feats = []
+    for lv in range(cfg["n_levels"]):
+        off0, off1 = int(cfg["offsets"][lv]), int(cfg["offsets"][lv + 1])
+        scale = float(np.float32(np.exp2(np.float64(lv) * np.float64(cfg["S"])) * np.float64(cfg["H"]) - 1.0))
+        res = int(np.ceil(np.float32(scale))) + 1
+        pos = x01 * scale + 0.5
+        pg = torch.floor(pos).detach()
+        fr = (pos - pg).to(table.dtype)
+        pgi = pg.cpu().numpy().astype(np.int64).clip(0).astype(np.uint32)
+        acc = 0
+        for c in range(8):
+            wgt = 1
+            loc = np.empty_like(pgi)
+            for a in range(3):
+                bit = (c >> a) & 1
+                wgt = wgt * (fr[:, a] if bit else 1 - fr[:, a])
+                loc[:, a] = pgi[:, a] + np.uint32(bit)
+            idx = torch.from_numpy(O._grid_index(loc, off1 - off0, res)).to(x6.device) + off0
+            acc = acc + wgt[:, None] * table[idx]
+        feats.append(torch.where(oob[:, None], torch.zeros_like(acc), acc))
+    enc = torch.cat(feats, -1)
+    h = torch.relu(enc @ w["sigma_net.0.weight"].T) @ w["sigma_net.1.weight"].T
+    sigma, geo = h[:, 0], h[:, 1:]
+    pn = l2n(torch.relu(geo @ w["normal_net.0.weight"].T) @ w["normal_net.1.weight"].T)
+    X, Y, Z = d[:, 0], d[:, 1], d[:, 2]
+    xy, xz, yz, x2, y2, z2 = X * Y, X * Z, Y * Z, X * X, Y * Y, Z * Z
+    sh = torch.stack([
+        torch.full_like(X, 0.28209479177387814), -0.48860251190291987 * Y, 0.48860251190291987 * Z, -0.48860251190291987 * X,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * Y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * Z, 0.45704579946446572 * Y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * Z * (5.0 * z2 - 3.0), 0.45704579946446572 * X * (1.0 - 5.0 * z2),
+        1.4453057213202769 * Z * (x2 - y2), 0.59004358992664352 * X * (-x2 + 3.0 * y2)], -1)
+    hc = torch.relu(torch.cat([sh, geo], -1) @ w["color_net.0.weight"].T)
+    hc = torch.relu(hc @ w["color_net.1.weight"].T)
+    rgb = torch.sigmoid(hc @ w["color_net.2.weight"].T)
+    hm = torch.nn.functional.leaky_relu(geo @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
+    m = torch.sigmoid(hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"])[:, 0]
+    return sigma, rgb, pn, m
