@@ -50,7 +50,8 @@ def _offsets17(cfg):
 class TcnnFieldFn(torch.autograd.Function):
     """mnrf_tcnn_forward / mnrf_tcnn_backward.
     apply(module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *mlp_params) ->
-        sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty; not differentiable)
+        sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty), geo_feat (B,15)
+        [the last two are not differentiable]
     Positions/directions come from `xyz6` (B,6) or from rays (N,8) + z_vals (N,spr) with per-ray raw directions
     `dirs` (N,3; None: the ray direction).  `mlp_params`: the 11 tensors of _BLOB in that order."""
 
@@ -60,18 +61,18 @@ class TcnnFieldFn(torch.autograd.Function):
         c = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
         xyz6, rays, z_vals, dirs = c(xyz6), c(rays), c(z_vals), c(dirs)
         o = module.field(B, xyz=xyz6, xyz_stride=6, rays=rays, z_vals=z_vals, spr=spr, dirs=dirs,
-                         grad_normal=bool(want_normal))
+                         grad_normal=bool(want_normal), want_geo=True)
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.save_for_backward(xyz6, rays, z_vals, dirs)
         ctx.set_materialize_grads(False)
         normal = o.get("normal")
         if normal is None:
             normal = torch.empty(0, 3, dtype=torch.float32, device=o["sigma"].device)
-        ctx.mark_non_differentiable(normal)
-        return o["sigma"], o["rgb"], o["pred_normal"], o["is_mirror"], normal
+        ctx.mark_non_differentiable(normal, o["geo_feat"])
+        return o["sigma"], o["rgb"], o["pred_normal"], o["is_mirror"], normal, o["geo_feat"]
 
     @staticmethod
-    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, _g_normal):
+    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, _g_normal, _g_geo):
         xyz6, rays, z_vals, dirs = ctx.saved_tensors
         m, B, spr = ctx.module, ctx.B, ctx.spr
         table = m.encoder.embeddings.detach().contiguous()
@@ -205,11 +206,11 @@ class MirrorNeRFTcnn(nn.Module):
         B = x.shape[0]
         if (not sigma_only and x.shape[1] == 6 and torch.is_grad_enabled()
                 and (x.requires_grad or any(q.requires_grad for q in self.parameters()))):
-            # training: geo_feat is not part of this route (nothing downstream of render_rays reads it)
-            sigma, rgb, pn, mir, normal = TcnnFieldFn.apply(self, 1, x, None, None, None, bool(compute_normal),
-                                                            self.encoder.embeddings, *self.mlp_params())
+            # training route (geo_feat and the density-gradient normal are constants of the graph)
+            sigma, rgb, pn, mir, normal, geo = TcnnFieldFn.apply(self, 1, x, None, None, None, bool(compute_normal),
+                                                                 self.encoder.embeddings, *self.mlp_params())
             out = {"normal": normal} if compute_normal else {}
-            out.update(sigma=sigma, pred_normal=pn, rgb=rgb, is_mirror=mir.view(B, 1))
+            out.update(sigma=sigma, geo_feat=geo, pred_normal=pn, rgb=rgb, is_mirror=mir.view(B, 1))
             return out
         o = self.field(B, xyz=x, xyz_stride=x.shape[1], sigma_only=sigma_only, grad_normal=compute_normal, want_geo=True)
         out = {}

@@ -176,8 +176,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         S = z.shape[1]
         if hashgrid:
             from .mirror_nerf_tcnn import TcnnFieldFn
-            sigma, rgb, pn, mir, normal = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
-                                                            model.encoder.embeddings, *model.mlp_params())
+            sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
+                                                                  model.encoder.embeddings, *model.mlp_params())
         else:
             sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
                                                         *list(model.parameters()))

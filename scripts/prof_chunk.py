@@ -32,7 +32,8 @@ if a.tcnn:
     for it in range(a.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+        with torch.no_grad():
+            M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"tcnn chunk: {dt * 1e3:.2f} ms  {a.rays * 256 / dt / 1e6:.1f} M samples/s  {a.rays / dt / 1e3:.1f} k rays/s")

@@ -97,7 +97,8 @@ def tcnn_field(w, x6, cfg):
     bound = cfg["bound"]
     # cell coordinates in fp32 like the kernel (a cell of the finest level is 2e-4 of the box: fp64 coordinates would
     # differ from the kernel's by 1e-4 of a cell); everything after the interpolation weights runs in the dtype of w
-    x01 = (xyz.float() + bound) / (2 * bound)
+    xf = xyz.float()
+    x01 = (xf + bound) / torch.full_like(xf, 2 * bound)     # a tensor divisor: torch turns "/ scalar" into "* (1/scalar)" on the GPU
     oob = ((x01 < 0) | (x01 > 1)).any(-1)
     table = w["encoder.embeddings"]
     feats = []
