@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
@@ -325,6 +326,14 @@ struct TcnnBwdArgs {
     float* d_weights;                            // W_TOTAL floats, zero-initialised by the caller; accumulated
     float* d_xyz;                                // (B,3) or null
     float* d_dir;                                // (B,3) or null
+    // Coarse levels are hit by every sample (level 0 of a 1 M-sample batch: 1 700 adds per entry): their gradient goes
+    // to PRIVATE COPIES selected by the workgroup index (copy = blockIdx % copies; workgroups are dealt to the 8 XCDs
+    // round robin, so a copy is only ever touched from one XCD and its lines stay in that XCD's L2 instead of
+    // bouncing between the eight), summed into d_table by tcnn_fold_kernel.  Measured at 1 M samples: the scatter of
+    // levels 0-3 straight into d_table took 19 ms of a 33 ms step.
+    float* copies;                               // workspace (zero-initialised) or null
+    int cp_n[NL];                                // copies of level lv (0: straight into d_table)
+    long long cp_off[NL];                        // float offset of the level's first copy in `copies`
 };
 
 __device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
@@ -681,40 +690,72 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) GR(k) = g_enc[k];           // (own column; indexed by level below)
         float gx[3] = {0.f, 0.f, 0.f};
-        if (live && !oob) {
+        const bool active = live && !oob;
 #pragma unroll 1
-            for (int lv = 0; lv < NL; ++lv) {
-                const float e0 = GR(2 * lv), e1 = GR(2 * lv + 1);
-                const float scale = A.scale[lv];
-                const unsigned res = A.res[lv];
-                const unsigned hsize = A.off[lv + 1] - A.off[lv];
-                const float2* tab = (const float2*)A.table + A.off[lv];
-                float* dtab = P.d_table + 2ll * A.off[lv];
-                unsigned pg[3];
-                float fr[3];
+        for (int lv = 0; lv < NL; ++lv) {
+            const float e0 = active ? GR(2 * lv) : 0.f, e1 = active ? GR(2 * lv + 1) : 0.f;
+            const float scale = A.scale[lv];
+            const unsigned res = A.res[lv];
+            const unsigned hsize = A.off[lv + 1] - A.off[lv];
+            const float2* tab = (const float2*)A.table + A.off[lv];
+            const bool coarse = P.cp_n[lv] != 0;                          // (wave-uniform)
+            float* dtab = coarse ? P.copies + P.cp_off[lv] + 2ll * hsize * (blockIdx.x % (unsigned)P.cp_n[lv])
+                                 : P.d_table + 2ll * A.off[lv];
+            unsigned pg[3];
+            float fr[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float pos = u[a] * scale + 0.5f;
-                    const float fl = floorf(pos);
-                    pg[a] = (unsigned)fl;
-                    fr[a] = pos - fl;
+            for (int a = 0; a < 3; ++a) {
+                const float pos = u[a] * scale + 0.5f;
+                const float fl = floorf(pos);
+                pg[a] = active ? (unsigned)fl : 0u;
+                fr[a] = pos - fl;
+            }
+            float v0[8], v1[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
+                const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
+                const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
+                const float w = wx * wy * wz;
+                v0[c] = w * e0;
+                v1[c] = w * e1;
+                if (P.d_xyz && active) {
+                    const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res)];
+                    const float ev = e0 * v.x + e1 * v.y;
+                    gx[0] += ((c & 1) ? scale : -scale) * wy * wz * ev;
+                    gx[1] += ((c & 2) ? scale : -scale) * wx * wz * ev;
+                    gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
                 }
+            }
+            bool head = true;
+            if (coarse) {
+                // Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): sum each
+                // run of lanes with equal cell into its first lane (segmented suffix sum, 6 shuffle steps) and let only
+                // that lane scatter.
+                const unsigned key = pg[0] | (pg[1] << 10) | (pg[2] << 20);          // coarse levels: res < 1024
+                const unsigned prev = __shfl_up(key, 1);
+                const int prev_active = __shfl_up((int)active, 1);
+                head = !(lane > 0 && active && prev_active && prev == key);
+                const unsigned long long heads = __ballot(head);
+                const int run = __popcll(heads & (~0ull >> (63 - lane)));
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const int run_d = __shfl_down(run, dlt);          // (every lane executes the shuffle: no short circuit)
+                    const bool ok = (lane + dlt < 64) & (run_d == run);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float t0 = __shfl_down(v0[c], dlt), t1 = __shfl_down(v1[c], dlt);
+                        v0[c] += ok ? t0 : 0.f;
+                        v1[c] += ok ? t1 : 0.f;
+                    }
+                }
+            }
+            if (active && head) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
-                    const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
-                    const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
                     const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res);
-                    const float w = wx * wy * wz;
-                    fadd(dtab + 2ll * idx, w * e0);
-                    fadd(dtab + 2ll * idx + 1, w * e1);
-                    if (P.d_xyz) {
-                        const float2 v = tab[idx];
-                        const float ev = e0 * v.x + e1 * v.y;
-                        gx[0] += ((c & 1) ? scale : -scale) * wy * wz * ev;
-                        gx[1] += ((c & 2) ? scale : -scale) * wx * wz * ev;
-                        gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
-                    }
+                    fadd(dtab + 2ll * idx, v0[c]);
+                    fadd(dtab + 2ll * idx + 1, v1[c]);
                 }
             }
         }
@@ -747,6 +788,40 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 }
 #undef XR
 #undef GR
+
+// d_table[level entries] += sum of the level's private copies
+__global__ void tcnn_fold_kernel(TcnnBwdArgs P) {
+    const TcnnArgs& A = P.f;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long base = 0;
+    for (int lv = 0; lv < NL; ++lv) {
+        if (!P.cp_n[lv]) continue;
+        const long long n = 2ll * (A.off[lv + 1] - A.off[lv]);
+        if (q < base + n) {
+            const long long e = q - base;
+            float a = 0.f;
+            for (int c = 0; c < P.cp_n[lv]; ++c) a += P.copies[P.cp_off[lv] + c * n + e];
+            P.d_table[2ll * A.off[lv] + e] += a;
+            return;
+        }
+        base += n;
+    }
+}
+
+// copies per level: 32 for levels of <= 32 Ki entries, 8 (one per XCD) up to 256 Ki entries, none above (the hashed levels:
+// random addresses, little contention).  Returns the workspace size in floats.
+long long plan_copies(const int64_t* off17, int* cp_n, long long* cp_off, long long* folded_floats) {
+    long long total = 0, folded = 0;
+    for (int lv = 0; lv < NL; ++lv) {
+        const long long n = off17[lv + 1] - off17[lv];
+        cp_n[lv] = n <= 32768 ? 32 : (n <= 262144 ? 8 : 0);
+        cp_off[lv] = total;
+        total += 2 * n * cp_n[lv];
+        if (cp_n[lv]) folded += 2 * n;
+    }
+    if (folded_floats) *folded_floats = folded;
+    return total;
+}
 
 }  // namespace
 
@@ -788,12 +863,18 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     return mnrf_check_launch("mnrf_tcnn_forward");
 }
 
+extern "C" int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host) {
+    int n[NL];
+    long long o[NL];
+    return offsets17_host ? plan_copies(offsets17_host, n, o, nullptr) : 0;
+}
+
 extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                                   int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
                                   int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
-                                  const float* g_is_mirror, float* d_table, float* d_weights, float* d_xyz, float* d_dir,
-                                  void* stream) {
+                                  const float* g_is_mirror, float* workspace, float* d_table, float* d_weights, float* d_xyz,
+                                  float* d_dir, void* stream) {
     if (!table || !offsets17_host || !weights || !d_table || !d_weights)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: null pointer");
     if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: negative sample count");
@@ -815,9 +896,17 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
     P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
+    P.copies = workspace;
+    long long folded = 0;
+    plan_copies(offsets17_host, P.cp_n, P.cp_off, &folded);
+    if (!workspace || getenv("MNRF_TCNN_NO_COPIES")) {         // (null workspace: every level straight into d_table)
+        for (int l = 0; l < NL; ++l) P.cp_n[l] = 0;
+        folded = 0;
+    }
     const long long ntiles = (B + BT - 1) / BT;
     const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256)), block(BT);      // persistent: one workgroup per CU of the MI355X
     const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
+    if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     return mnrf_check_launch("mnrf_tcnn_backward");
 }

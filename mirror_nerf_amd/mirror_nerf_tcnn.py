@@ -86,12 +86,14 @@ class TcnnFieldFn(torch.autograd.Function):
         want_d = (xyz6 is not None and need[2]) or (dirs is not None and need[5]) or (dirs is None and rays is not None and need[3])
         d_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_x else None
         d_dir = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_d else None
+        offs = _offsets17(m.cfg)
+        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats(offs)), dtype=torch.float32, device=dev)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(
-                p(table), _offsets17(m.cfg), m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
+                p(table), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
-                p(g_m), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
+                p(g_m), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
         grads, off = [], 0
         for _name, rows, used, padded in _BLOB:
             if padded:
