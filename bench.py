@@ -94,6 +94,54 @@ def cpu_baseline(sds, n_rays=1024):
                       f"({threads} threads), {dt:.1f} s"}
 
 
+def hash_grid_leg(dev, rays):
+    """BASELINE config 5 for the record (not `value`): the hash-grid field (MirrorNeRFTcnn, bound 6, 2^19 x 16 x 2 table)
+    on the same 800x800 rays -- one frame of primary rays through render_rays (64 sigma-only + 192 full samples), and the
+    1024-ray training step (forward + hand-written backward + Adam)."""
+    import torch
+    import mirror_nerf_amd as M
+    torch.manual_seed(0)
+    models = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev)
+              for k in ("coarse", "fine")}
+    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+
+    def frame():
+        with torch.no_grad():
+            for c in range(0, rays.shape[0], CHUNK):
+                M.render_rays(models, emb, rays[c:c + CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, CHUNK, test_time=True,
+                              compute_normal=False)
+    frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame()
+    torch.cuda.synchronize()
+    dt_f = time.perf_counter() - t0
+    opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4)
+    target = torch.rand(1024, 3, device=dev)
+
+    def step():
+        idx = torch.randint(0, rays.shape[0], (1024,), device=dev)
+        res = M.render_rays(models, emb, rays[idx], N_SAMPLES, False, 1, 1, N_IMPORTANCE, compute_normal=False)
+        loss = ((res["rgb_coarse"] - target) ** 2).mean() + ((res["rgb_fine"] - target) ** 2).mean() \
+            + 0.1 * ((res["mirror_mask_fine"] - 0.5) ** 2).mean() + 1e-4 * res["surface_normal_fine"].pow(2).sum(-1).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    dt_t = (time.perf_counter() - t0) / 10
+    n = rays.shape[0]
+    return {"rays_per_s": n / dt_f, "samples_per_s": n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
+            "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": 1024 / dt_t,
+            "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
+                    "against tinycudann unpinned (DESIGN.md 4.3); bound = gather / scatter traffic, not MFMA"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +262,8 @@ def main():
         train_total = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
         train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn")}
 
+    hash_grid = hash_grid_leg(dev, rays) if (rank == 0 and world == 1 and not a.no_train) else None
+
     if rank == 0:
         split = a.precision == "split"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
@@ -256,6 +306,8 @@ def main():
             res["with_host_maps"] = host_maps
         if train is not None:
             res["train_step"] = train
+        if hash_grid is not None:
+            res["hash_grid_variant"] = hash_grid
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, a.cpu_rays)
         print(json.dumps(res))
