@@ -220,3 +220,77 @@ def test_tcnn_backward_run_aggregation_is_order_independent():
     for k in a:
         scale = float(a[k].abs().max()) + 1e-12
         assert float((a[k] - b[k]).abs().max()) <= 2e-5 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+
+
+def test_tcnn_train_recursion_matches_torch_field(monkeypatch):
+    """NeRFSystem.forward (train semantics, GT mirror mask, compacted reflected rays, blend) with hash-grid models:
+    gradients with the HIP field backward against the same pipeline with the field replaced by torch ops (autograd
+    through tests/torch_ref.tcnn_field; every other node is the HIP autograd function in both runs).  Exercises
+    dL/d position and dL/d direction: the reflected rays start at x_surface and point along the reflected normal."""
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf_tcnn as T
+    from tests import torch_ref as R
+    hp = SimpleNamespace(model_type="nerf_tcnn", bound=2.0, predict_normal=True, predict_mirror_mask=True, N_samples=24,
+                         N_importance=24, use_disp=False, perturb=0, noise_std=0, chunk=4096, only_one_field=False,
+                         trace_secondary_rays=True, max_recursive_level=1, only_trace_rays_in_mirrors=True, for_vis=False)
+    torch.manual_seed(4)
+    system = M.NeRFSystem(hp)
+    with torch.no_grad():
+        for mdl in (system.nerf_coarse, system.nerf_fine):
+            mdl.encoder.embeddings.uniform_(-0.05, 0.05)
+            # a random table is white noise at the fine levels: d(output)/d(position) ~ 1e4 and a reflected ray that moves
+            # by one ulp changes its gradient by O(1) -- keep the five coarsest levels only, so that the comparison of two
+            # fp32 implementations is well conditioned
+            mdl.encoder.embeddings[int(mdl.cfg["offsets"][5]):] = 0
+            # x10: opaque enough for surfaces (and reflected rays) to matter.  (Measured while writing this test: at x40
+            # a 1e-7 relative change of the ray origins moves these gradients by 3-7 % in BOTH implementations and they
+            # differ by as much; at x10 the two agree to 7e-5.)
+            mdl.sigma_net[1].weight[0] *= 10.0
+    system.to(DEV)
+    rays = torch.from_numpy(O.synthetic_rays(8, 8)).to(DEV)
+    rays[:, 6], rays[:, 7] = 2.5, 5.5
+    N = rays.shape[0]
+    gt = (torch.arange(N, device=DEV) % 3 != 0).float()
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run():
+        system.zero_grad()
+        res = system(rays, {"mirror_mask": gt, "is_eval": False, "train_geometry_stage": False})
+        loss = ((res["rgb_fine"] - target) ** 2).mean() + ((res["rgb_coarse"] - target) ** 2).mean() \
+            + 0.05 * ((res["mirror_mask_fine"] - gt) ** 2).mean()
+        loss.backward()
+        return float(loss.detach()), {k: v.grad.clone() for k, v in system.named_parameters()}
+
+    loss_hip, g_hip = run()
+
+    class TorchField:
+        @staticmethod
+        def apply(module, spr, xyz6, rays_, z, dirs, want_normal, table, *params):
+            n = rays_.shape[0]
+            xyz = (rays_[:, None, :3] + rays_[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+            dd = (dirs if dirs is not None else rays_[:, 3:6])[:, None, :3].expand(n, spr, 3).reshape(-1, 3)
+            w = dict(module.named_parameters())
+            sigma, rgb, pn, mir = R.tcnn_field(w, torch.cat([xyz, dd], 1), module.cfg)
+            # the density-gradient normal is a constant of the graph in both runs: take it from the kernel
+            nrm = module.field(n * spr, rays=rays_.detach().contiguous(), z_vals=z.contiguous(), spr=spr,
+                               dirs=None if dirs is None else dirs.detach().contiguous(), grad_normal=True)["normal"] \
+                if want_normal else torch.empty(0, 3, device=rays_.device)
+            return sigma, rgb, pn, mir, nrm, None
+
+    monkeypatch.setattr(T, "TcnnFieldFn", TorchField)
+    loss_ref, g_ref = run()
+    assert abs(loss_hip - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))     # (fp32 torch GEMMs vs the kernel's fma chains, sigma x40)
+    touched, bad = 0, []
+    for k, wv in g_ref.items():
+        scale = float(wv.abs().max())
+        if scale == 0:
+            assert float(g_hip[k].abs().max()) == 0, k
+            continue
+        touched += 1
+        err = float((g_hip[k] - wv).abs().max())
+        print(f"{k:45s} err {err:.3e} scale {scale:.3e}")
+        if err > 2e-3 * scale:
+            bad.append((k, err, scale))
+    assert not bad, bad
+    assert touched == 18       # every tensor but the coarse normal and mirror heads (no loss reads them)
