@@ -119,5 +119,11 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The current torch stream of the current device as a hipStream_t (every kernel is launched on it)."""
+    if _raw_stream is not None:      # ~1 us; torch.cuda.current_stream() builds a Stream object (~13 us, 20 launches per step)
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -22,6 +22,7 @@ import torch
 from . import _lib
 from .autograd import CompositeFn, EmbedFn, FieldFn
 from .mirror_nerf import field_forward
+from .weights import params_of
 
 __all__ = ["render_rays", "sample_pdf"]
 
@@ -90,7 +91,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
 
     train = torch.is_grad_enabled() and (rays.requires_grad or any(
-        q.requires_grad for mdl in models.values() for q in mdl.parameters()))
+        q.requires_grad for mdl in models.values() for q in params_of(mdl)))
 
     # rendering.py:275-277 -- view encoding once per ray
     view = kwargs.get("view_dir", rays[:, 3:6])
@@ -180,7 +181,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:
             sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
-                                                        *list(model.parameters()))
+                                                        *params_of(model))
         noise = kwargs.get(noise_key)
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()

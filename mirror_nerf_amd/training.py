@@ -10,6 +10,7 @@ import torch
 
 from . import dist as D
 from .recursion import NeRFSystem
+from .weights import params_of
 
 
 def default_hparams(**over):
@@ -49,7 +50,7 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    D.allreduce_gradients([p for p in system.parameters()])   # RCCL over xGMI when world_size > 1
+    D.allreduce_gradients(params_of(system))                  # RCCL over xGMI when world_size > 1
     optimizer.step()
     return loss
 
@@ -63,7 +64,10 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
         for m in (system.nerf_coarse, system.nerf_fine):
             m.sigma.weight.mul_(20.0)
             m.sigma.bias.fill_(1.0)
-    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4)
+    import os
+    # fused Adam: one kernel per step instead of the foreach kernels, same arithmetic; measured 8.0 vs 8.9 ms per step on the
+    # same box (the step is host-bound: 4 ms of kernels).  MNRF_ADAM_FUSED=0 selects the foreach implementation.
+    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=os.environ.get("MNRF_ADAM_FUSED", "1") == "1")
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
     loss_fn = total_loss_fn() if loss_name == "total" else color_mask_loss

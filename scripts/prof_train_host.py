@@ -1,0 +1,24 @@
+"""Host-side profile of the training step (cProfile): where the Python/launch time of a step goes."""
+import cProfile
+import os
+import pstats
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mirror_nerf_amd import training  # noqa: E402
+from oracle import mirror_nerf_oracle as O  # noqa: E402
+
+dev = torch.device("cuda", 0)
+rays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
+training.synthetic_train_bench(dev, rays, 3, 3, 1024)
+pr = cProfile.Profile()
+pr.enable()
+r = training.synthetic_train_bench(dev, rays, 20, 3, 1024)
+pr.disable()
+print(r["ms_per_step"])
+st = pstats.Stats(pr).sort_stats("cumulative")
+st.print_stats(45)
+st.print_callers("named_parameters")
+st.print_callers("parameters")
