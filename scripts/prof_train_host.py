@@ -18,7 +18,5 @@ pr.enable()
 r = training.synthetic_train_bench(dev, rays, 20, 3, 1024)
 pr.disable()
 print(r["ms_per_step"])
-st = pstats.Stats(pr).sort_stats("cumulative")
-st.print_stats(45)
-st.print_callers("named_parameters")
-st.print_callers("parameters")
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
