@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-rays", type=int, default=4096)
     ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement")
     ap.add_argument("--precision", choices=("split", "fp32"), default="split",
                     help="arithmetic of the field kernel's Linears: fp32 operands as hi/lo f16 pairs on the f16 matrix "
