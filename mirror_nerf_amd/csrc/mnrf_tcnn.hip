@@ -55,24 +55,95 @@ struct TcnnArgs {
 
 extern __shared__ __attribute__((aligned(16))) float wlds[];
 
-constexpr int TPB = 384;                        // threads (= samples) per workgroup: 141 KB of LDS, 6 waves per CU (256: 8.98 ms per
+constexpr int TPB = 512;                        // threads (= samples) per workgroup: 141 KB of LDS, 6 waves per CU (256: 8.98 ms per
                                                 // 32768-ray chunk, 384: 8.50 ms; 512 would need 173 KB)
-constexpr int VEC_OFF = (W_TOTAL + 3) / 4 * 4;  // per-thread vector buffer vec[64][TPB] behind the weights
+constexpr int VEC_OFF = 0;                      // per-thread vector buffer vec[64][TPB] (the forward keeps no weights in LDS)
+constexpr int BWD_W_FLOATS = (W_TOTAL + 3) / 4 * 4;   // the backward kernel keeps them at wlds[0 ..)
 #define VEC(k) wlds[VEC_OFF + (k) * TPB + threadIdx.x]
 
 // Layers run as "inputs in registers, loop over outputs": the output loop is NOT unrolled (a fully
 // unrolled 11 k-FMA body makes hipcc hoist thousands of LDS reads and spill 2-4 KB per lane); each
 // output goes to the thread's column of an LDS vector buffer and is re-loaded as the next input.
+// Weight rows are wave-uniform: read through the CONSTANT address space they become s_load_dwordx4/8/16 into SGPRs and the
+// FMAs take them as scalar operands -- no LDS traffic (a broadcast ds_read_b128 still moves 64 x 16 B through the LDS port
+// for four FMAs per lane, which bounded this kernel).  The weights are not written while a kernel runs.
+typedef const __attribute__((address_space(4))) float* cptr;
+typedef const __attribute__((address_space(4))) f32x4* cptr4;
+__device__ __forceinline__ cptr as_const(const float* p) { return (cptr)(unsigned long long)p; }
+
 template <int NI>
-__device__ __forceinline__ float dot_row(const float (&in)[NI], int woff) {
-    float a = 0.f;
+__device__ __forceinline__ float dot_row(cptr W, const float (&in)[NI], int woff) {
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;       // four independent chains: one chain of NI dependent v_fmac runs at the
+                                                    // VALU latency, not at its rate (measured: 6.97 -> see DESIGN 4.3)
+#pragma unroll
+    for (int i = 0; i < NI; i += 4) {
+        const f32x4 w = *(cptr4)(W + woff + i);
+        a = fmaf(w[0], in[i], a); b = fmaf(w[1], in[i + 1], b);
+        c = fmaf(w[2], in[i + 2], c); d = fmaf(w[3], in[i + 3], d);
+    }
+    return (a + b) + (c + d);
+}
+
+// One Linear of the forward kernel: out[o] = <W[o, :], in>, o < n_out, handed to `store(o, value)`.  The weights are
+// consumed in chunks of 32 floats (= half a 64-wide row, one 32-wide row, two 16-wide rows) and chunk j+1 is requested
+// BEFORE chunk j is used: an s_load issued when its data are needed costs its whole latency per row (scalar loads return
+// out of order, so the wait is always lgkmcnt(0)), and one or two waves per SIMD do not hide it.  The body handles two
+// chunks per iteration so that both buffers and every register-array index are static.
+__device__ __forceinline__ void load_chunk(cptr W, int off, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = *(cptr4)(W + off + 4 * q);
+}
+// Explicit 2-wide FMAs: (w[q].xy, w[q].zw) are even-aligned SGPR pairs of the s_load destination and `in` is kept as
+// float2s, so every v_pk_fma_f32 takes its operands where they are.  (Left to the SLP vectoriser, the scalar FMAs were
+// paired across odd SGPR boundaries and each pair cost three s_mov_b32: the CU's one scalar unit ran 93 % busy
+// -- SQ_ACTIVE_INST_SCA, profiles/r01s_pmc_tcnn -- and bounded the kernel.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N4>
+__device__ __forceinline__ float dot_chunk(const f32x4* w, const f32x2* in2) {      // N4 float4s of weights
+    f32x2 a = {0.f, 0.f}, b = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < N4; ++q) {
+        a = __builtin_elementwise_fma(w[q].xy, in2[2 * q], a);
+        b = __builtin_elementwise_fma(w[q].zw, in2[2 * q + 1], b);
+    }
+    a += b;
+    return a.x + a.y;
+}
+template <int NI, class Store>
+__device__ __forceinline__ void mlp_layer(cptr W, int woff, int n_out, const float (&in)[NI], Store store) {
+    static_assert(NI == 16 || NI == 32 || NI == 64, "row widths of the weight blob");
+    const int nchunks = n_out * NI / 32;           // even for every layer routed here
+    f32x2 in2[NI / 2];
+#pragma unroll
+    for (int k = 0; k < NI / 2; ++k) in2[k] = f32x2{in[2 * k], in[2 * k + 1]};
+    f32x4 A[8], B[8];
+    load_chunk(W, woff, A);
+    float half = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < nchunks; j += 2) {
+        load_chunk(W, woff + 32 * (j + 1), B);
+        if constexpr (NI == 64) half = dot_chunk<8>(A, in2);
+        else if constexpr (NI == 32) store(j, dot_chunk<8>(A, in2));
+        else { store(2 * j, dot_chunk<4>(A, in2)); store(2 * j + 1, dot_chunk<4>(A + 4, in2)); }
+        load_chunk(W, woff + 32 * (j + 2 < nchunks ? j + 2 : j), A);
+        if constexpr (NI == 64) store(j >> 1, half + dot_chunk<8>(B, in2 + 16));
+        else if constexpr (NI == 32) store(j + 1, dot_chunk<8>(B, in2));
+        else { store(2 * j + 2, dot_chunk<4>(B, in2)); store(2 * j + 3, dot_chunk<4>(B + 4, in2)); }
+    }
+}
+
+// the same with the weights in LDS at wlds[0 ..) (backward kernel: its transposed passes read them from LDS anyway, and the
+// scalar variant measured slower there, 4.68 vs 4.38 ms per training step)
+template <int NI>
+__device__ __forceinline__ float dot_row_lds(const float (&in)[NI], int woff) {
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; i += 4) {
         const f32x4 w = *(const f32x4*)(wlds + woff + i);
-        a = fmaf(w[0], in[i], a); a = fmaf(w[1], in[i + 1], a);
-        a = fmaf(w[2], in[i + 2], a); a = fmaf(w[3], in[i + 3], a);
+        a = fmaf(w[0], in[i], a); b = fmaf(w[1], in[i + 1], b);
+        c = fmaf(w[2], in[i + 2], c); d = fmaf(w[3], in[i + 3], d);
     }
-    return a;
+    return (a + b) + (c + d);
 }
 
 template <int N>
@@ -138,8 +209,7 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
 
 template <bool SIGMA_ONLY, bool GRAD>
 __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
-    for (int k = threadIdx.x; k < W_TOTAL; k += TPB) wlds[k] = A.weights[k];
-    __syncthreads();
+    const cptr WC = as_const(A.weights);
     long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     const bool live = i < A.B;
     if (!live) i = A.B - 1;
@@ -179,19 +249,16 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
     {
         float in[32];
         load_vec(in);
-#pragma unroll 1
-        for (int o = 0; o < 64; ++o) {
-            const float pre = dot_row(in, W_S0 + o * 32);
+        mlp_layer(WC, W_S0, 64, in, [&](int o, float pre) {
             relu_bits |= (unsigned long long)(pre > 0.f) << o;
             VEC(o) = fmaxf(pre, 0.f);
-        }
+        });
     }
     float geo[16];
     {
         float in[64];
         load_vec(in);
-#pragma unroll 1
-        for (int o = 0; o < 16; ++o) VEC(o) = dot_row(in, W_S1 + o * 64);
+        mlp_layer(WC, W_S1, 16, in, [&](int o, float v) { VEC(o) = v; });
         if (A.sigma && live) A.sigma[i] = VEC(0);
 #pragma unroll
         for (int k = 0; k < 15; ++k) geo[k] = VEC(1 + k);
@@ -209,10 +276,10 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
         for (int e = 0; e < 32; ++e) genc[e] = 0.f;
 #pragma unroll 1
         for (int k = 0; k < 64; ++k) {
-            const float s = ((relu_bits >> k) & 1ull) ? wlds[W_S1 + k] : 0.f;
+            const float s = ((relu_bits >> k) & 1ull) ? WC[W_S1 + k] : 0.f;
 #pragma unroll
             for (int e = 0; e < 32; e += 4) {
-                const f32x4 w = *(const f32x4*)(wlds + W_S0 + k * 32 + e);
+                const f32x4 w = *(cptr4)(WC + W_S0 + k * 32 + e);
                 genc[e] = fmaf(s, w[0], genc[e]); genc[e + 1] = fmaf(s, w[1], genc[e + 1]);
                 genc[e + 2] = fmaf(s, w[2], genc[e + 2]); genc[e + 3] = fmaf(s, w[3], genc[e + 3]);
             }
@@ -235,13 +302,12 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
     }
     // ---- predicted normal: 15 -> 64 (ReLU) -> 3, l2-normalised (249-255, 185-192)
     if (A.pred_normal) {
-#pragma unroll 1
-        for (int o = 0; o < 64; ++o) VEC(o) = fmaxf(dot_row(geo, W_N0 + o * 16), 0.f);
+        mlp_layer(WC, W_N0, 64, geo, [&](int o, float v) { VEC(o) = fmaxf(v, 0.f); });
         float hn[64];
         load_vec(hn);
         float v[3];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) v[o] = dot_row(hn, W_N1 + o * 64);
+        for (int o = 0; o < 3; ++o) v[o] = dot_row(WC, hn, W_N1 + o * 64);
         const float inv = 1.f / sqrtf(fmaxf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], EPS32));
         if (live) { A.pred_normal[i * 3] = v[0] * inv; A.pred_normal[i * 3 + 1] = v[1] * inv; A.pred_normal[i * 3 + 2] = v[2] * inv; }
     }
@@ -270,28 +336,25 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
 #pragma unroll
         for (int k = 0; k < 15; ++k) in[16 + k] = geo[k];
         in[31] = 0.f;
-#pragma unroll 1
-        for (int o = 0; o < 64; ++o) VEC(o) = fmaxf(dot_row(in, W_C0 + o * 32), 0.f);
+        mlp_layer(WC, W_C0, 64, in, [&](int o, float v) { VEC(o) = fmaxf(v, 0.f); });
         float c1[64];
         load_vec(c1);
-#pragma unroll 1
-        for (int o = 0; o < 64; ++o) VEC(o) = fmaxf(dot_row(c1, W_C1 + o * 64), 0.f);
+        mlp_layer(WC, W_C1, 64, c1, [&](int o, float v) { VEC(o) = fmaxf(v, 0.f); });
         load_vec(c1);
         if (A.rgb && live) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) A.rgb[i * 3 + k] = 1.f / (1.f + expf(-dot_row(c1, W_C2 + k * 64)));
+            for (int k = 0; k < 3; ++k) A.rgb[i * 3 + k] = 1.f / (1.f + expf(-dot_row(WC, c1, W_C2 + k * 64)));
         }
     }
     // ---- mirror probability: 15 -> 32 LeakyReLU(0.01) -> 1 sigmoid, with biases (141-149)
     if (A.is_mirror) {
-#pragma unroll 1
-        for (int o = 0; o < 32; ++o) {
-            const float v = dot_row(geo, W_M0 + o * 16) + wlds[B_M0 + o];
+        mlp_layer(WC, W_M0, 32, geo, [&](int o, float dotv) {
+            const float v = dotv + WC[B_M0 + o];
             VEC(o) = v > 0.f ? v : 0.01f * v;
-        }
+        });
         float hm[32];
         load_vec(hm);
-        if (live) A.is_mirror[i] = 1.f / (1.f + expf(-(dot_row(hm, W_M1) + wlds[B_M1])));
+        if (live) A.is_mirror[i] = 1.f / (1.f + expf(-(dot_row(WC, hm, W_M1) + WC[B_M1])));
     }
 }
 #undef VEC
@@ -314,7 +377,7 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
 // reference does.  First-order only: the density-gradient normal is a constant of the graph here.
 constexpr int BT = 256;                         // samples per tile = threads
 constexpr int RS = BT + 4;                      // row stride (floats)
-constexpr int XO = VEC_OFF;                     // X rows: 64
+constexpr int XO = BWD_W_FLOATS;                     // X rows: 64
 constexpr int GO = XO + 64 * RS;                // G rows: 32
 constexpr int BWD_LDS_FLOATS = GO + 32 * RS;
 #define XR(k) wlds[XO + (k) * RS + threadIdx.x]
@@ -479,7 +542,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             for (int k = 0; k < 32; ++k) in[k] = XR(k);
 #pragma unroll 1
             for (int o = 0; o < 64; ++o) {
-                const float pre = dot_row(in, W_S0 + o * 32);
+                const float pre = dot_row_lds(in, W_S0 + o * 32);
                 bits_h1 |= (unsigned long long)(pre > 0.f) << o;
                 XR(o) = fmaxf(pre, 0.f);
             }
@@ -487,7 +550,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 #pragma unroll
             for (int k = 0; k < 64; ++k) h1[k] = XR(k);
 #pragma unroll 1
-            for (int o = 1; o < 16; ++o) GR(o) = dot_row(h1, W_S1 + o * 64);
+            for (int o = 1; o < 16; ++o) GR(o) = dot_row_lds(h1, W_S1 + o * 64);
 #pragma unroll
             for (int k = 0; k < 15; ++k) geo[k] = GR(1 + k);
             geo[15] = 0.f;
@@ -499,13 +562,13 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
         // ---- predicted-normal head: geo -> hn (ReLU) -> v -> l2-normalise
         if (P.g_pn) {
 #pragma unroll 1
-            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(geo, W_N0 + o * 16), 0.f);
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row_lds(geo, W_N0 + o * 16), 0.f);
             float hn[64];
 #pragma unroll
             for (int k = 0; k < 64; ++k) hn[k] = XR(k);
             float v[3];
 #pragma unroll
-            for (int o = 0; o < 3; ++o) v[o] = dot_row(hn, W_N1 + o * 64);
+            for (int o = 0; o < 3; ++o) v[o] = dot_row_lds(hn, W_N1 + o * 64);
             const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
             const float inv = 1.f / sqrtf(fmaxf(n2, EPS32));
             float g_v[3];
@@ -542,14 +605,14 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             unsigned bits_m = 0;
 #pragma unroll 1
             for (int o = 0; o < 32; ++o) {
-                const float v = dot_row(geo, W_M0 + o * 16) + wlds[B_M0 + o];
+                const float v = dot_row_lds(geo, W_M0 + o * 16) + wlds[B_M0 + o];
                 bits_m |= (unsigned)(v > 0.f) << o;
                 XR(o) = v > 0.f ? v : 0.01f * v;
             }
             float hm[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) hm[k] = XR(k);
-            const float m = 1.f / (1.f + expf(-(dot_row(hm, W_M1) + wlds[B_M1])));
+            const float m = 1.f / (1.f + expf(-(dot_row_lds(hm, W_M1) + wlds[B_M1])));
             const float g_z = g_m * m * (1.f - m);
             db_m1 += g_z;
 #pragma unroll
@@ -577,7 +640,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             for (int k = 0; k < 15; ++k) in[16 + k] = geo[k];
             in[31] = 0.f;
 #pragma unroll 1
-            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(in, W_C0 + o * 32), 0.f);
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row_lds(in, W_C0 + o * 32), 0.f);
             float c1[64];
 #pragma unroll
             for (int k = 0; k < 64; ++k) c1[k] = XR(k);
@@ -586,7 +649,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             for (int k = 0; k < 64; ++k) bits_c1 |= (unsigned long long)(c1[k] > 0.f) << k;
 #pragma unroll 1
             for (int o = 0; o < 64; ++o) {
-                const float pre = dot_row(c1, W_C1 + o * 64);
+                const float pre = dot_row_lds(c1, W_C1 + o * 64);
                 bits_c2 |= (unsigned long long)(pre > 0.f) << o;
                 XR(o) = fmaxf(pre, 0.f);
             }
@@ -660,7 +723,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) enc[k] = XR(k);
 #pragma unroll 1
-            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row(enc, W_S0 + o * 32), 0.f);
+            for (int o = 0; o < 64; ++o) XR(o) = fmaxf(dot_row_lds(enc, W_S0 + o * 32), 0.f);
         }
         GR(0) = g_sigma;
 #pragma unroll
