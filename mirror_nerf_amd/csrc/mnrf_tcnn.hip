@@ -50,6 +50,7 @@ struct TcnnArgs {
     float scale[NL];              // exp2(level*S)*H - 1
     unsigned res[NL];             // ceil(scale) + 1
     unsigned off[NL + 1];         // level offsets in entries
+    unsigned mode[NL];            // 0: dense level, 1: hashed, power-of-two size (mask), 2: hashed, any size (modulo)
     float* sigma; float* rgb; float* pred_normal; float* is_mirror; float* normal; float* geo_feat;
 };
 
@@ -152,19 +153,14 @@ __device__ __forceinline__ void load_vec(float (&v)[N]) {
     for (int k = 0; k < N; ++k) v[k] = VEC(k);
 }
 
-__device__ __forceinline__ unsigned grid_index(unsigned x, unsigned y, unsigned z, unsigned hsize, unsigned res) {
-    // get_grid_index (gridencoder.cu:68-89): dense while the running stride fits, else the spatial hash
-    unsigned stride = 1, index = 0;
-    const unsigned p[3] = {x, y, z};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (stride <= hsize) {
-            index += p[d] * stride;
-            stride *= res + 1;
-        }
-    }
-    if (stride > hsize) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
-    return index % hsize;
+__device__ __forceinline__ unsigned grid_index(unsigned x, unsigned y, unsigned z, unsigned hsize, unsigned res, unsigned mode) {
+    // get_grid_index (gridencoder.cu:68-89): dense while the running stride fits, else the spatial hash, then `% hsize`.
+    // Which of the two a LEVEL takes is fixed on the host (level_mode below: dense iff (res+1)^3 <= hsize, and then the
+    // index is already < hsize), so the per-corner code has no branch and no integer division: hashed levels of the
+    // reference configuration hold 2^19 entries (a mask); any other size keeps the modulo.
+    if (mode == 0) return x + (res + 1) * (y + (res + 1) * z);
+    const unsigned h = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return mode == 1 ? (h & (hsize - 1)) : (h % hsize);
 }
 
 // one level of the encoding: the two features and (GRAD) their derivatives w.r.t. the [0,1] coordinates
@@ -179,11 +175,12 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
     float fr[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float pos = u[a] * scale + 0.5f;
+        const float pos = (oob ? 0.5f : u[a]) * scale + 0.5f;     // (outside the box: a valid cell, weight 0 below)
         const float fl = floorf(pos);
         pg[a] = (unsigned)fl;
         fr[a] = pos - fl;
     }
+    const float in_box = oob ? 0.f : 1.f;
     a0 = 0.f; a1 = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { g0[a] = 0.f; g1[a] = 0.f; }
@@ -192,14 +189,14 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
         const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
         const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
         const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
-        float2 v = make_float2(0.f, 0.f);
-        if (!oob) v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res)];
-        const float w = wx * wy * wz;
+        // unconditional loads: the eight gathers of a level (and of the next levels, the loop is unrolled) go out together
+        const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
+        const float w = wx * wy * wz * in_box;
         a0 += w * v.x; a1 += w * v.y;
         if (GRAD) {
-            const float sx = ((c & 1) ? scale : -scale) * wy * wz;
-            const float sy = ((c & 2) ? scale : -scale) * wx * wz;
-            const float sz = ((c & 4) ? scale : -scale) * wx * wy;
+            const float sx = ((c & 1) ? scale : -scale) * wy * wz * in_box;
+            const float sy = ((c & 2) ? scale : -scale) * wx * wz * in_box;
+            const float sz = ((c & 4) ? scale : -scale) * wx * wy * in_box;
             g0[0] += sx * v.x; g1[0] += sx * v.y;
             g0[1] += sy * v.x; g1[1] += sy * v.y;
             g0[2] += sz * v.x; g1[2] += sz * v.y;
@@ -237,7 +234,7 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
         u[a] = (x[a] + A.bound) / (2.f * A.bound);
         oob |= u[a] < 0.f || u[a] > 1.f;
     }
-#pragma unroll 1
+#pragma unroll 4
     for (int lv = 0; lv < NL; ++lv) {
         float a0, a1, g0[3], g1[3];
         encode_level<false>(A, lv, u, oob, a0, a1, g0, g1);
@@ -785,7 +782,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                 v0[c] = w * e0;
                 v1[c] = w * e1;
                 if (P.d_xyz && active) {
-                    const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res)];
+                    const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
                     const float ev = e0 * v.x + e1 * v.y;
                     gx[0] += ((c & 1) ? scale : -scale) * wy * wz * ev;
                     gx[1] += ((c & 2) ? scale : -scale) * wx * wz * ev;
@@ -818,7 +815,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             if (active && head) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res);
+                    const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
                     fadd(dtab + 2ll * idx, v0[c]);
                     fadd(dtab + 2ll * idx + 1, v1[c]);
                 }
@@ -890,6 +887,15 @@ long long plan_copies(const int64_t* off17, int* cp_n, long long* cp_off, long l
 
 }  // namespace
 
+static void level_modes(TcnnArgs& A) {
+    for (int l = 0; l < NL; ++l) {
+        const unsigned long long hsize = A.off[l + 1] - A.off[l], r1 = (unsigned long long)A.res[l] + 1;
+        // the running stride of get_grid_index stays <= hsize through all three axes iff (res+1)^3 <= hsize
+        const bool dense = r1 <= hsize && r1 * r1 <= hsize && r1 * r1 * r1 <= hsize;
+        A.mode[l] = dense ? 0u : ((hsize & (hsize - 1)) == 0 ? 1u : 2u);
+    }
+}
+
 extern "C" int mnrf_tcnn_weight_floats(void) { return W_TOTAL; }
 
 extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
@@ -917,6 +923,7 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
         A.off[l] = (unsigned)offsets17_host[l];
     }
     A.off[NL] = (unsigned)offsets17_host[NL];
+    level_modes(A);
     A.sigma = sigma; A.rgb = rgb; A.pred_normal = pred_normal; A.is_mirror = is_mirror; A.normal = normal; A.geo_feat = geo_feat;
     const dim3 grid((unsigned)((B + TPB - 1) / TPB)), block(TPB);
     const size_t lds = (VEC_OFF + 64 * TPB) * sizeof(float);
@@ -958,6 +965,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
         A.off[l] = (unsigned)offsets17_host[l];
     }
     A.off[NL] = (unsigned)offsets17_host[NL];
+    level_modes(A);
     A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
     P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
