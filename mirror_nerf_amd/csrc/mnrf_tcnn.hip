@@ -101,13 +101,15 @@ __device__ __forceinline__ void load_chunk(cptr W, int off, f32x4 (&dst)[8]) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N4>
 __device__ __forceinline__ float dot_chunk(const f32x4* w, const f32x2* in2) {      // N4 float4s of weights
-    f32x2 a = {0.f, 0.f}, b = {0.f, 0.f};
+    f32x2 a = {0.f, 0.f}, b = {0.f, 0.f}, c = {0.f, 0.f}, d = {0.f, 0.f};     // four independent chains of packed FMAs
 #pragma unroll
-    for (int q = 0; q < N4; ++q) {
+    for (int q = 0; q < N4; q += 2) {
         a = __builtin_elementwise_fma(w[q].xy, in2[2 * q], a);
         b = __builtin_elementwise_fma(w[q].zw, in2[2 * q + 1], b);
+        c = __builtin_elementwise_fma(w[q + 1].xy, in2[2 * q + 2], c);
+        d = __builtin_elementwise_fma(w[q + 1].zw, in2[2 * q + 3], d);
     }
-    a += b;
+    a = (a + b) + (c + d);
     return a.x + a.y;
 }
 template <int NI, class Store>
