@@ -9,8 +9,8 @@
 // against this repository's own CPU restatement (oracle `tcnn_field_forward`).
 //
 // Regime: 22 kFLOP and 128 random 8-byte gathers per sample -> gather/L2 bound, not MFMA bound.
-// One thread per sample; the 11 k weights sit in LDS and are read as wave-uniform (broadcast)
-// ds_read_b128; the table (53 MB fp32 at bound 6) lives in the 256 MB Infinity Cache.
+// One thread per sample; the 11 k weights are wave-uniform and arrive as scalar loads through the
+// constant address space (mlp_layer below); the table (53 MB fp32 at bound 6) lives in the 256 MB Infinity Cache.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -56,8 +56,9 @@ struct TcnnArgs {
 
 extern __shared__ __attribute__((aligned(16))) float wlds[];
 
-constexpr int TPB = 512;                        // threads (= samples) per workgroup: 141 KB of LDS, 6 waves per CU (256: 8.98 ms per
-                                                // 32768-ray chunk, 384: 8.50 ms; 512 would need 173 KB)
+constexpr int TPB = 512;                        // threads (= samples) per workgroup: 128 KB of LDS for the vector buffer, 8 waves
+                                                // per CU (with the weights in LDS too: 256 threads 8.98 ms per 32768-ray chunk,
+                                                // 384 threads 8.50 ms; now 6.7 ms)
 constexpr int VEC_OFF = 0;                      // per-thread vector buffer vec[64][TPB] (the forward keeps no weights in LDS)
 constexpr int BWD_W_FLOATS = (W_TOTAL + 3) / 4 * 4;   // the backward kernel keeps them at wlds[0 ..)
 #define VEC(k) wlds[VEC_OFF + (k) * TPB + threadIdx.x]
