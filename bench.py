@@ -139,7 +139,7 @@ def hash_grid_leg(dev, rays):
     return {"rays_per_s": n / dt_f, "samples_per_s": n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": 1024 / dt_t,
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
-                    "against tinycudann unpinned (DESIGN.md 4.3); bound = gather / scatter traffic, not MFMA"}
+                    "against tinycudann unpinned (DESIGN.md 4.3); VALU + gather kernels, the MLPs are not on MFMA yet"}
 
 
 def main():
