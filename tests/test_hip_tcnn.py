@@ -294,3 +294,27 @@ def test_tcnn_train_recursion_matches_torch_field(monkeypatch):
             bad.append((k, err, scale))
     assert not bad, bad
     assert touched == 18       # every tensor but the coarse normal and mirror heads (no loss reads them)
+
+
+def test_tcnn_forward_sees_updated_weights():
+    """The kernel reads the MLP weights through the scalar cache (constant address space): a changed blob at the SAME
+    address (optimiser step, in-place edit) must be seen by the next launch."""
+    m, w, cfg = _model(1.0, seed=9)
+    rs = np.random.RandomState(5)
+    x6 = np.concatenate([rs.uniform(-1, 1, (513, 3)), rs.normal(size=(513, 3))], 1).astype(np.float32)
+    xt = torch.from_numpy(x6).to(DEV)
+    with torch.no_grad():
+        first = m(xt, compute_normal=False)["rgb"].cpu().numpy()
+        ptrs = {m._weights().data_ptr()}
+        for _ in range(4):
+            for name in ("sigma_net.0.weight", "color_net.1.weight", "is_mirror_net.0.bias"):
+                p = dict(m.named_parameters())[name]
+                p.mul_(1.25).add_(0.01)
+                w[name] = p.detach().cpu().numpy().copy()
+            ptrs.add(m._weights().data_ptr())     # (the caching allocator alternates between two blocks: addresses repeat)
+            got = {k: v.cpu().numpy() for k, v in m(xt, compute_normal=False).items()}
+            want = O.tcnn_field_forward(w, x6, cfg, False, False)
+            for k in ("sigma", "rgb", "is_mirror"):
+                assert float(np.max(np.abs(got[k] - want[k]))) <= 5e-5, k
+    assert float(np.max(np.abs(first - got["rgb"]))) > 1e-3      # (the edits did change the output)
+    assert len(ptrs) < 5                                          # (at least one address was reused)
