@@ -283,10 +283,19 @@ __global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(DwJobs J, long long B
     }
 }
 
-// dW for Linears with <= 3 output rows: Cpart[split][3][K], bpart[split][3]
-__global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__ A, int lda, int n_true,
-                                                       const float* __restrict__ X, int ldx, int K, long long B,
-                                                       int splits, float* __restrict__ Cpart, float* __restrict__ bpart) {
+// dW for Linears with <= 3 output rows: Cpart[split][3][K], bpart[split][3]; up to four of them per launch (blockIdx.y)
+struct DwSmallJob {
+    const float* A; int lda, n_true;
+    const float* X; int ldx, K;
+    float* Cpart; float* bpart;
+};
+struct DwSmallJobs { DwSmallJob job[4]; };
+
+__global__ __launch_bounds__(256) void dw_small_kernel(DwSmallJobs J, long long B, int splits) {
+    const DwSmallJob& j = J.job[blockIdx.y];
+    const float* __restrict__ A = j.A;
+    const float* __restrict__ X = j.X;
+    const int lda = j.lda, n_true = j.n_true, ldx = j.ldx, K = j.K;
     const int k = threadIdx.x;
     const int split = blockIdx.x;
     const long long per = (B + splits - 1) / splits;
@@ -305,9 +314,9 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__
     }
     if (k < K) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) Cpart[((long long)split * 3 + n) * K + k] = acc[n];
+        for (int n = 0; n < 3; ++n) j.Cpart[((long long)split * 3 + n) * K + k] = acc[n];
     }
-    if (k < 3) bpart[(long long)split * 3 + k] = bs[k];
+    if (k < 3) j.bpart[(long long)split * 3 + k] = bs[k];
 }
 
 // ---- assemble parameter gradients
@@ -481,10 +490,12 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         gemm<32>(bt, Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, cd, nullptr);
         layer(9, 128, 283, DwSource{cf, 256, 128, splits}, DwSource{cd, 32, 128, splits}, 256, 0, bp);
     }
+    DwSmallJobs SJ;
+    int n_small = 0;
     auto small = [&](int L, const float* A, int lda, int n_true, const float* Xp, int K) {
         float* bp = take_small(3);
         float* c = take_small(3 * K);
-        hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits), dim3(256), 0, s, A, lda, n_true, Xp, K, K, B, ssplits, c, bp);
+        SJ.job[n_small++] = DwSmallJob{A, lda, n_true, Xp, K, K, c, bp};       // one launch for the four of them below
         layer(L, n_true, K, DwSource{c, K, 3, ssplits}, DwSource{c, K, 3, ssplits}, K, 0, bp);
     };
     small(10, g_sigma, 1, 1, h8, 256);                          // sigma
@@ -504,6 +515,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     }
     small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
     if (p - ws > dw_workspace_floats(B)) return -1;
+    hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits, n_small), dim3(256), 0, s, SJ, B, ssplits);
     bt.flush();
     // largest layer: 256 x 319 + 256 elements
     hipLaunchKernelGGL(dw_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
@@ -564,7 +576,9 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
         float* c = p; p += 3LL * 256 * ssplits;
         static const float h1 = 1.f;
         (void)hipMemcpyAsync(one, &h1, sizeof(float), hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits), dim3(256), 0, s, one, 0, 1, sec(TA_H + 256 * 7), 256, 256, B, ssplits, c, bp);
+        DwSmallJobs SJ;
+        SJ.job[0] = DwSmallJob{one, 0, 1, sec(TA_H + 256 * 7), 256, 256, c, bp};
+        hipLaunchKernelGGL(dw_small_kernel, dim3(ssplits, 1), dim3(256), 0, s, SJ, B, ssplits);
         layer(10, 1, 256, DwSource{c, 256, 3, ssplits}, DwSource{c, 256, 3, ssplits}, 256, 0);
     }
     if (p - ws > dw2_workspace_floats(B)) return -1;
