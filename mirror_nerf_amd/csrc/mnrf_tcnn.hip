@@ -399,6 +399,7 @@ struct TcnnBwdArgs {
     int cp_n[NL];                                // copies of level lv (0: straight into d_table)
     long long cp_off[NL];                        // float offset of the level's first copy in `copies`
     int agg_levels;                              // levels [0, agg_levels) sum runs of equal cells inside the wave first
+    int exp_noscatter;                           // experiment (MNRF_EXP_TCNN_NOSCATTER): skip the table atomics
 };
 
 __device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                     }
                 }
             }
-            if (active && head) {
+            if (active && head && !P.exp_noscatter) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
@@ -973,6 +974,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
     P.copies = workspace;
+    P.exp_noscatter = getenv("MNRF_EXP_TCNN_NOSCATTER") != nullptr;
     P.agg_levels = 0;
     // measured (1 M samples, bound 6): 15.96 / 15.00 / 14.12 / 13.77 / 13.70 ms per step with runs summed up to resolution
     // 64 / 128 / 256 / 512 / 1000 -- the shuffles are cheap next to an atomic, so every level the key can hold takes part
