@@ -11,9 +11,14 @@ A "step" is one frame.  Inputs (rays, packed weights) are resident in HBM when t
 result maps stay on the GPU (`to_cpu=False`; the reference's per-chunk D2H of every dict entry
 is caller-side data movement).
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): frames are independent units; every
-rank renders its own frame (weak scaling), no collective on the data path, barrier + max-over-ranks
-timing.  value = rays of all ranks / slowest rank's time.
+Multi-GPU (`--gpus N`): one process per GPU over RCCL.  Launched by `python -m torch.distributed.run ...
+bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) -- or plainly as `python bench.py
+--gpus N`, in which case it re-executes itself under torch.distributed.run on 127.0.0.1.  Frames are
+independent units: every rank renders its own frame (weak scaling), no collective on the data path,
+barrier + max-over-ranks timing; value = rays of all ranks / slowest rank's time.  With more than one
+rank the line also carries `strong_scaling` (ONE frame dealt to the ranks in interleaved 4096-ray tiles,
+dist.render_sharded, + the optional gather of the maps to rank 0) and `train_step` (the 1024-ray
+training step per rank with one flat RCCL all-reduce of the 5.3 MB gradient, train.py:577-584).
 """
 import argparse
 import json
@@ -33,65 +38,75 @@ PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide, dense f16/bf16: 256 CU x 4 SIMD 
 # MFMA FLOPs the split kernel EXECUTES per full sample: 1308 hi/lo tile pairs x 3 products x 2 groups x 4 waves x
 # 16384 FLOP per v_mfma_f32_16x16x32_f16 / 128 samples (= 3 x the padded fp32 count; algorithmic: MN.FLOP_FULL)
 SPLIT_EXECUTED_FLOP_FULL = 1308 * 3 * 2 * 4 * 16384 // 128
-# HBM bytes per full-kernel sample from the PMC passes (profiles/r01_pmc for the fp32 kernel, profiles/r01e_pmc_split
-# for the split kernel: the same traffic; FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE):
-# (2 x 33758 + 196608) KiB / 6291456 samples
-PMC_HBM_BYTES_PER_FULL_SAMPLE = (2 * 33758 + 196608) * 1024 / 6291456
+# roofline.traffic: HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of THIS command
+# (scripts/pmc_passes.sh -> profiles/traffic.json, keyed by kernel name; FETCH_SIZE doubled per the guide's gfx950
+# correction + WRITE_SIZE).  PMC counters cannot be read from inside the run: a kernel without an entry reports null.
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def build_models(dev):
-    import torch
     import mirror_nerf_amd as M
-    from tests.golden import weights as GW
-    sds = [GW.apply_tweaks(sd, GW.ALL_MIRROR) for sd in GW.make_state_dict(0, 2)]
-    models = {}
-    for name, sd in zip(("coarse", "fine"), sds):
-        m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-        models[name] = m.to(dev)
+    from mirror_nerf_amd import synthetic as SY
+    models, sds = SY.build_models(dev, SY.ALL_MIRROR, seed=0)
     return models, sds, {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
 
 
 ARGS = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
 
 
-def cpu_baseline(sds, n_rays=1024):
-    """The oracle (numpy port of the reference path) on a bounded sample of the same workload:
-    `n_rays` primary rays of the frame + their reflected rays.  The fp32 GEMM backend is whichever
-    of numpy/OpenBLAS and torch's CPU sgemm (what the reference's CPU path runs on) is faster on
-    this host in a short trial; threads = min(host cores, 64)."""
+def cpu_baseline(sds, budget_s=20.0):
+    """The reference's path on the host cores, on a bounded sample of the same workload (primary rays spread over
+    the frame + their reflected rays), two ways:
+      * `value`: oracle/torch_port.py -- plain torch CPU ops in the reference's own op structure (cat + linear per
+        layer, chunk 32768, cumprod, searchsorted, sort), torch.set_num_threads(threads): what the reference's CPU
+        path costs here;
+      * `numpy_oracle`: oracle/mirror_nerf_oracle.py, the bit-careful checker the parity tests use, for the record.
+    The sample is sized from a short trial so that each leg takes about `budget_s`/2 seconds."""
     import torch
     from threadpoolctl import threadpool_limits
     from oracle import mirror_nerf_oracle as O
+    from oracle import torch_port as TP
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     rays = O.synthetic_rays(H, W)
-    idx = np.linspace(0, rays.shape[0] - 1, n_rays).astype(np.int64)
-    sub = rays[idx]
-    models = {"coarse": sds[0], "fine": sds[1]}
 
-    def torch_sgemm(x, w):
-        return torch.mm(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(w).t()).numpy()
+    def sample(n):
+        return rays[np.linspace(0, rays.shape[0] - 1, n).astype(np.int64)]
 
-    def run(r):
+    mt = {k: {n: torch.from_numpy(v) for n, v in sd.items()} for k, sd in zip(("coarse", "fine"), sds)}
+
+    def run_torch(r):
         t0 = time.perf_counter()
-        out = O.render_eval(models, {"xyz": 10, "dir": 4}, r, N_SAMPLES, N_IMPORTANCE, False, CHUNK, ARGS)
-        return time.perf_counter() - t0, out
+        out = TP.render_eval(mt, torch.from_numpy(np.ascontiguousarray(r)), N_SAMPLES, N_IMPORTANCE, CHUNK, 1)
+        return time.perf_counter() - t0, int((out["mirror_mask_fine"] != 0).any()) * r.shape[0]
+
+    def run_numpy(r):
+        t0 = time.perf_counter()
+        out = O.render_eval({"coarse": sds[0], "fine": sds[1]}, {"xyz": 10, "dir": 4}, r, N_SAMPLES, N_IMPORTANCE, False,
+                            CHUNK, ARGS)
+        return time.perf_counter() - t0, int((out["mirror_mask_fine"] != 0).any()) * r.shape[0]
+
+    def sized(run, trial_n=256):
+        run(sample(64))                                   # warm-up (thread pools, allocator)
+        dt, _ = run(sample(trial_n))
+        n = int(min(16384, max(trial_n, 0.5 * budget_s / dt * trial_n)))
+        n -= n % 64
+        dt, traced = run(sample(n))
+        return n, traced, dt
 
     with threadpool_limits(limits=threads):
-        trial = {}
-        for name, fn in (("numpy-openblas", None), ("torch-cpu-sgemm", torch_sgemm)):
-            O.set_sgemm(fn)
-            run(sub[:32])                        # warm-up
-            trial[name] = run(sub[:128])[0]
-        best = min(trial, key=trial.get)
-        O.set_sgemm(torch_sgemm if best == "torch-cpu-sgemm" else None)
-        dt, r = run(sub)
-        O.set_sgemm(None)
-    traced = int((r["mirror_mask_fine"] != 0).any()) * n_rays
-    return {"value": (n_rays + traced) / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{n_rays} primary + {traced} reflected rays of the same frame, oracle with {best} "
-                      f"({threads} threads), {dt:.1f} s"}
+        n_t, tr_t, dt_t = sized(run_torch)
+        O.set_sgemm(lambda x, w: torch.mm(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(w).t()).numpy())
+        try:
+            n_n, tr_n, dt_n = sized(run_numpy)
+        finally:
+            O.set_sgemm(None)
+    return {"value": (n_t + tr_t) / dt_t, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{n_t} primary + {tr_t} reflected rays of the same frame, oracle/torch_port.py (plain torch CPU ops in "
+                      f"the reference's op structure, chunk {CHUNK}, {threads} threads), {dt_t:.1f} s",
+            "numpy_oracle": {"value": (n_n + tr_n) / dt_n, "unit": "rays/s", "cores": threads,
+                             "sample": f"{n_n} primary + {tr_n} reflected rays, oracle/mirror_nerf_oracle.py with torch's CPU "
+                                       f"sgemm as its GEMM backend ({threads} threads), {dt_n:.1f} s"}}
 
 
 def hash_grid_leg(dev, rays):
@@ -142,68 +157,87 @@ def hash_grid_leg(dev, rays):
                     "against tinycudann unpinned (DESIGN.md 4.3); VALU + gather kernels, the MLPs are not on MFMA yet"}
 
 
+def _respawn(a):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def _traffic(kernel):
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        e = t.get(kernel)
+        return (e["hbm_bytes_per_launch"], e.get("source")) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=4096)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement")
     ap.add_argument("--precision", choices=("split", "fp32"), default="split",
                     help="arithmetic of the field kernel's Linears: fp32 operands as hi/lo f16 pairs on the f16 matrix "
                          "pipe (default, ~1e-6 of fp32) or the bit-exact fp32 MFMA chain")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("MNRF_BENCH_SPAWN") == "1"):
+        _respawn(a)          # MNRF_BENCH_SPAWN=1: take the launcher path at N = 1 too (tests on a 1-GPU box)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}, or plain "
+                 f"python bench.py --gpus {a.gpus})")
+
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
     import mirror_nerf_amd as M
+    from mirror_nerf_amd import dist as D
     from mirror_nerf_amd import mirror_nerf as MN
-    from oracle import mirror_nerf_oracle as O
+    from mirror_nerf_amd import synthetic as SY
+
+    rank, world, dev = D.init_from_env()
+    if dist.is_initialized() and dist.get_world_size() != a.gpus:
+        sys.exit(f"bench.py: RCCL group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+    multi = dist.is_initialized()
 
     MN.set_precision(a.precision)
     models, sds, emb = build_models(dev)
     # every rank renders its own view: same camera model, pose rotated about z by the rank index
-    pose = O.look_at_pose(eye=(4.0 * np.sin(0.3 * rank), -4.0 * np.cos(0.3 * rank), 1.5))
-    focal = 0.5 * W / np.tan(0.5 * 0.6911112)
-    rays = torch.empty(H * W, 8, device=dev)
-    import ctypes
-    c2w = (ctypes.c_float * 12)(*pose.reshape(-1).tolist())
-    M._lib.check(M._lib.lib().mnrf_generate_rays(H, W, float(focal), c2w, 0.05, 8.0, M._lib.ptr(rays),
-                                                 M._lib.stream()), "mnrf_generate_rays")
+    rays = SY.device_rays(H, W, dev, SY.look_at_pose(eye=(4.0 * np.sin(0.3 * rank), -4.0 * np.cos(0.3 * rank), 1.5)))
 
-    def frame():
-        return M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,
-                                   trace_secondary_rays=True, to_cpu=False)
+    def render(r, to_cpu=False):
+        return M.batched_inference(models, emb, r, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,
+                                   trace_secondary_rays=True, to_cpu=to_cpu)
 
     def sync():
-        if dist.is_initialized():
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        out = frame()
+        out = render(rays)
     sync()
     MN.LAUNCH_LOG = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = frame()
+        out = render(rays)
     sync()
-    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
-    if dist.is_initialized():
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     n_mirror = int((out["mirror_mask_fine"] != 0).sum().item())
     out = None
@@ -221,17 +255,41 @@ def main():
     ms_sig = sum(t for _, t in sig)
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
 
-    # the other arithmetic on ONE whole frame of the same workload (rank 0), for the record: rays/s and the dominant
-    # kernel's rate under it
+    # strong scaling: ONE frame (rank 0's view) dealt to the ranks in interleaved 4096-ray tiles; no collective while
+    # rendering; then the optional assembly of the 20 B/ray maps on rank 0
+    strong = None
+    if multi:
+        common = SY.device_rays(H, W, dev)
+        keys = ("rgb_fine", "depth_fine", "mirror_mask_fine")
+        idx, res = D.render_sharded(render, common)                       # warm-up
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            idx, res = D.render_sharded(render, common)
+        sync()
+        dt_s = D.max_over_ranks(time.perf_counter() - t1, dev)
+        t1 = time.perf_counter()
+        frame = D.gather_frame(idx, res, H * W, keys=keys)
+        sync()
+        dt_g = D.max_over_ranks(time.perf_counter() - t1, dev)
+        strong = {"rays_per_s": 2 * H * W * a.steps / dt_s, "ms_per_frame": dt_s / a.steps * 1e3, "tile": D.TILE,
+                  "rays_of_rank0": int(idx.numel()), "gather_ms": dt_g * 1e3,
+                  "gathered_bytes": int(sum(v.numel() * 4 for v in frame.values())) if rank == 0 else None,
+                  "note": "one 800x800 frame + its reflected rays over all ranks (interleaved 4096-ray tiles, no data-path "
+                          "collective); gather = all_gather of rgb/depth/mask maps, outside ms_per_frame"}
+        res = frame = None
+
+    # the other arithmetic on ONE whole frame of the same workload, for the record: rays/s and the dominant kernel's rate
     other = "fp32" if a.precision == "split" else "split"
     other_tf = other_rays = other_ms = None
-    if rank == 0:
+    host_maps = None
+    if world == 1:
         MN.set_precision(other)
-        frame()                      # warm-up (first launches of the other kernels)
+        render(rays)                 # warm-up (first launches of the other kernels)
         torch.cuda.synchronize()
         MN.LAUNCH_LOG = []
         t1 = time.perf_counter()
-        frame()
+        render(rays)
         torch.cuda.synchronize()
         dt_o = time.perf_counter() - t1
         t_o = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG if not (flags & 1)]
@@ -241,13 +299,10 @@ def main():
         MN.LAUNCH_LOG = None
         MN.set_precision(a.precision)
 
-    # PCIe-inclusive rate (never `value`): one more frame whose per-ray maps are copied to the host
-    host_maps = None
-    if rank == 0:
+        # PCIe-inclusive rate (never `value`): one more frame whose per-ray maps are copied to the host
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        hm = M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,
-                                 trace_secondary_rays=True, to_cpu="maps")
+        hm = render(rays, to_cpu="maps")
         torch.cuda.synchronize()
         dt_h = time.perf_counter() - t1
         host_maps = {"rays_per_s": rays_per_frame / dt_h, "bytes_to_host": int(sum(v.numel() * v.element_size() for v in hm.values())),
@@ -260,13 +315,16 @@ def main():
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
         train_total = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
-        train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn")}
+        train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline")
+                                    if k in train_total}
 
-    hash_grid = hash_grid_leg(dev, rays) if (rank == 0 and world == 1 and not a.no_train) else None
+    hash_grid = hash_grid_leg(dev, rays) if (world == 1 and not a.no_train) else None
 
     if rank == 0:
         split = a.precision == "split"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        kernel = "mnrf::h2::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>"
+        traffic, traffic_src = _traffic(kernel)
         res = {
             "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -277,7 +335,9 @@ def main():
             "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
                                    "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
                                    "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
-                       "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames"},
+                       "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames",
+                       "collective_backend": (dist.get_backend() + " (RCCL)") if multi else None,
+                       "rccl_world_size": dist.get_world_size() if multi else None},
             "samples_per_s": value * evals_per_ray,
             "field_evals_per_ray": evals_per_ray,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -287,21 +347,23 @@ def main():
                          "executed_tflops": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL),
                          "executed_frac": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL) / peak,
                          "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": PMC_HBM_BYTES_PER_FULL_SAMPLE * (sum(B for B, _ in full) / max(1, len(full))),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/), "
-                                         "not re-measured in this run; algorithmic bytes are 36 B/sample",
-                         "kernel": ("mnrf::h2::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>")
-                                   + " (full 4-head evaluation, fine pass)",
-                         "other_precision": {"precision": other, "achieved": other_tf,
-                                             "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
-                                             "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
-                                             "avg_launch_ms": other_ms, "rays_per_s": other_rays,
-                                             "note": "one frame of the same workload with the other arithmetic"},
+                         "traffic": traffic,
+                         "traffic_note": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this "
+                                          f"command: {traffic_src}; algorithmic bytes are 36 B/sample") if traffic is not None
+                                         else "no PMC pass on record for this kernel (profiles/traffic.json)",
+                         "kernel": kernel + " (full 4-head evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
                          "flop_per_sample": MN.FLOP_FULL,
                          "sigma_only_kernel_tflops": sig_tf,
                          "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
         }
+        if other_tf is not None:
+            res["roofline"]["other_precision"] = {
+                "precision": other, "achieved": other_tf, "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
+                "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
+                "avg_launch_ms": other_ms, "rays_per_s": other_rays, "note": "one frame of the same workload with the other arithmetic"}
+        if strong is not None:
+            res["strong_scaling"] = strong
         if host_maps is not None:
             res["with_host_maps"] = host_maps
         if train is not None:
@@ -309,9 +371,10 @@ def main():
         if hash_grid is not None:
             res["hash_grid_variant"] = hash_grid
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sds, a.cpu_rays)
-        print(json.dumps(res))
-    if dist.is_initialized():
+            res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if multi:
+        dist.barrier()
         dist.destroy_process_group()
 
 

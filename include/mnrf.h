@@ -46,6 +46,12 @@ extern "C" {
                                   hi/lo f16 pair (3 MFMAs per product block, fp32 accumulation; ~2^-20 relative per
                                   product instead of the bit-exact fp32 fmaf chain of the default) */
 
+/* gradient steering of the training backward (the reference's --detach_density_* options; values are unaffected) */
+#define MNRF_CUT_NORMAL_HEAD 32u   /* mnrf_field_backward: normal_net sees geo_feat.detach() (mirror_nerf.py:154-158) */
+#define MNRF_CUT_MIRROR_HEAD 64u   /* mnrf_field_backward: is_mirror_net sees geo_feat.detach() (mirror_nerf.py:169-170) */
+#define MNRF_DETACH_W_MASK 1       /* mnrf_composite_backward: mirror mask = sum(weights.detach() * is_mirror) (rendering.py:223-226) */
+#define MNRF_DETACH_W_NORMAL 2     /* mnrf_composite_backward: the normal outputs use weights.detach() (rendering.py:244-264) */
+
 const char* mnrf_last_error(void);
 int mnrf_version(void);
 
@@ -143,7 +149,10 @@ int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const floa
                             const float* g_depth, const float* g_mirror_mask, const float* g_surf_normal,
                             const float* g_surf_normal_grad, const float* g_normal_dif, const float* g_x_surface,
                             float* d_sigma, float* d_rgb, float* d_is_mirror, float* d_pred_normal,
-                            float* d_normal, float* d_rays, void* stream);
+                            float* d_normal, float* d_rays,
+                            int detach /* MNRF_DETACH_W_* : models/rendering.py:223-247 */,
+                            const float* keep_mirror /* (n_rays) or null: 0 = this ray's mirror mask sees weights.detach() */,
+                            void* stream);
 
 /* ---- backward of the per-ray glue (training; autograd through train.py:217-296, mirror_nerf.py:20-38)
  * reflect: g_sec (n_sec,8) = dL/d secondary rays -> dL/dx_surface (n_rays,3), dL/d normal (n_rays,3),
@@ -184,7 +193,11 @@ int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_
                         const float* g_is_mirror, const float* rgb, const float* pred_normal,
                         const float* is_mirror, const float* save_x, const uint64_t* save_mask,
                         const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
-                        float* d_dir, unsigned flags /* 0 or MNRF_SPLIT_F16: activation gradients on the f16 pipe */,
+                        float* d_dir,
+                        const float* keep_mirror /* (B/spr) per ray [(B) with xyz] or null: 0 = the mirror head of this ray's
+                                                    samples sees geo_feat.detach() (models/mirror_nerf.py:172-183) */,
+                        unsigned flags /* MNRF_SPLIT_F16: activation gradients on the f16 pipe; MNRF_CUT_NORMAL_HEAD /
+                                          MNRF_CUT_MIRROR_HEAD: that head sees geo_feat.detach() (mirror_nerf.py:157, 169-170) */,
                         void* stream);
 
 /* Second-order term of the field backward: the gradient that reaches the trunk weights, sigma.weight

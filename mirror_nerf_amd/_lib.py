@@ -26,6 +26,10 @@ _str = ctypes.c_void_p      # hipStream_t
 MNRF_SIGMA_ONLY = 1
 MNRF_GRAD_NORMAL = 2
 MNRF_SPLIT_F16 = 4
+MNRF_CUT_NORMAL_HEAD = 32
+MNRF_CUT_MIRROR_HEAD = 64
+MNRF_DETACH_W_MASK = 1
+MNRF_DETACH_W_NORMAL = 2
 N_PARAMS = 32
 
 # name -> (restype, argtypes): exactly the prototypes of include/mnrf.h
@@ -40,7 +44,7 @@ SIGNATURES = {
     "mnrf_sample_coarse": (_int, [_c_f, _i64, _c_f, _int, _int, _flt, _c_f, _c_f, _str]),
     "mnrf_composite": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
                               _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
-    "mnrf_composite_backward": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_str]),
+    "mnrf_composite_backward": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_int, _c_f, _str]),
     "mnrf_reflect_backward": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _str]),
     "mnrf_blend_backward": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _str]),
     "mnrf_embed_backward": (_int, [_c_f, _c_f, _i64, _int, _int, _c_f, _str]),
@@ -52,7 +56,7 @@ SIGNATURES = {
     "mnrf_field_backward2": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _c_f, _c_f, _c_f, _c_f,
                                     ctypes.POINTER(ctypes.c_void_p), _c_f, _u32, _str]),
     "mnrf_field_backward": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 11 +
-                            [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _u32, _str]),
+                            [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f, _u32, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
@@ -116,10 +120,16 @@ def ptr(t):
         raise RuntimeError("mirror_nerf_amd runs on the GPU only (tensor is on %s)" % t.device)
     if not t.is_contiguous():
         raise RuntimeError("tensor must be contiguous")
+    if t.device.index != _cur_device():
+        # kernels are launched on the CURRENT device's current stream (stream()): one process per GPU binds it once with
+        # torch.cuda.set_device(LOCAL_RANK) (dist.init_from_env); anything else must wrap calls in torch.cuda.device(...)
+        raise RuntimeError(f"tensor lives on cuda:{t.device.index} but the current device is cuda:{_cur_device()}; "
+                           "call torch.cuda.set_device / use `with torch.cuda.device(t.device)`")
     return ctypes.c_void_p(t.data_ptr())
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream():

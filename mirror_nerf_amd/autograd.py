@@ -14,7 +14,9 @@ class CompositeFn(torch.autograd.Function):
     Differentiable inputs: rays (through x_surface), sigma, rgb, is_mirror, pred_normal, normal."""
 
     @staticmethod
-    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back):
+    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back, detach=0, keep_mirror=None):
+        """detach: MNRF_DETACH_W_MASK | MNRF_DETACH_W_NORMAL; keep_mirror: (N,) float, 0 = that ray's mirror mask sees
+        weights.detach() (models/rendering.py:223-247: the --detach_density_* options; values are unaffected)."""
         N, S = z.shape
         dev = z.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -37,6 +39,7 @@ class CompositeFn(torch.autograd.Function):
                 p(xs), _lib.stream()), "mnrf_composite")
         ctx.save_for_backward(rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, depth)
         ctx.white_back = bool(white_back)
+        ctx.detach, ctx.keep_mirror = int(detach), _c(keep_mirror)
         ctx.set_materialize_grads(False)
         ctx.present = (rgb_map is not None, depth is not None, mask is not None, sn is not None, sng is not None,
                        nd is not None, xs is not None)
@@ -65,15 +68,15 @@ class CompositeFn(torch.autograd.Function):
             _lib.check(_lib.lib().mnrf_composite_backward(
                 p(rays), N, S, p(sigma), p(z), p(noise), p(rgb), p(is_mirror), p(pred_normal), p(normal),
                 int(ctx.white_back), None, p(depth), p(g[0]), p(g[1]), p(g[2]), p(g[3]), p(g[4]), p(g[5]), p(g[6]),
-                p(g[7]), p(g[8]), p(d_sigma), p(d_rgb), p(d_m), p(d_pn), p(d_n), p(d_rays), _lib.stream()),
-                "mnrf_composite_backward")
+                p(g[7]), p(g[8]), p(d_sigma), p(d_rgb), p(d_m), p(d_pn), p(d_n), p(d_rays), ctx.detach, p(ctx.keep_mirror),
+                _lib.stream()), "mnrf_composite_backward")
 
         def like(d, ref):
             return None if d is None else d.view(ref.shape)
         return (d_rays, like(d_sigma, sigma), None, None, like(d_rgb, rgb) if rgb is not None else None,
                 like(d_m, is_mirror) if is_mirror is not None else None,
                 like(d_pn, pred_normal) if pred_normal is not None else None,
-                like(d_n, normal) if normal is not None else None, None)
+                like(d_n, normal) if normal is not None else None, None, None, None)
 
 
 class FieldFn(torch.autograd.Function):
@@ -83,6 +86,9 @@ class FieldFn(torch.autograd.Function):
 
     apply(module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params) ->
         sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty)
+    `want_normal` may also be a tuple (want_normal, cut_flags, keep_mirror): cut_flags = MNRF_CUT_NORMAL_HEAD |
+    MNRF_CUT_MIRROR_HEAD and keep_mirror (per ray / per row of xyz; 0 = cut the mirror head there) make those heads see
+    geo_feat.detach() (models/mirror_nerf.py:154-183, the --detach_density_* options).
     Positions come from `xyz` (B,>=3 columns, row stride = its row length) or from rays (N,8) and
     z_vals (N,spr).  `dir_emb`: (B/spr, 27) view encoding.  `params`: the module's 32 parameters in
     state_dict order (so that autograd routes their gradients).
@@ -94,6 +100,9 @@ class FieldFn(torch.autograd.Function):
         from .weights import packed_of
         from . import mirror_nerf as _mn
         L = _lib.lib()
+        ctx.cut, ctx.keep_mirror = 0, None
+        if isinstance(want_normal, tuple):
+            want_normal, ctx.cut, ctx.keep_mirror = want_normal[0], int(want_normal[1]), _c(want_normal[2])
         packed = packed_of(module)
         dev = packed.device
         B = xyz.shape[0] if xyz is not None else rays.shape[0] * spr
@@ -146,8 +155,8 @@ class FieldFn(torch.autograd.Function):
         if B:
             _lib.check(L.mnrf_field_backward(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
-                p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir),
-                _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()),
+                p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), p(ctx.keep_mirror),
+                (_lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0) | ctx.cut, _lib.stream()),
                 "mnrf_field_backward")
             if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
                 ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
@@ -246,7 +255,8 @@ class BlendFn(torch.autograd.Function):
     scattered through index (rows without a source keep base.detach()).  `index` None/empty + M == N: direct."""
 
     @staticmethod
-    def forward(ctx, base, sec, index, mask, compact):
+    def forward(ctx, base, sec, index, mask, compact, detach_sec=False):
+        """detach_sec: the reflected colour is a constant of the blend (train.py:284-289, --detach_ref_color_for_blend)."""
         base, sec, mask = _c(base.float()), _c(sec.float()), _c(mask.float())
         N = base.shape[0]
         c = base.shape[1] if base.dim() == 2 else 1
@@ -256,7 +266,7 @@ class BlendFn(torch.autograd.Function):
         _lib.check(_lib.lib().mnrf_blend_scatter(p(base), p(sec), p(idx), sec.shape[0], p(mask), N, c, p(out), None,
                                                  _lib.stream()), "mnrf_blend_scatter")
         ctx.save_for_backward(mask, index)
-        ctx.compact, ctx.c, ctx.m = bool(compact), c, sec.shape[0]
+        ctx.compact, ctx.c, ctx.m, ctx.detach_sec = bool(compact), c, sec.shape[0], bool(detach_sec)
         return out
 
     @staticmethod
@@ -265,8 +275,8 @@ class BlendFn(torch.autograd.Function):
         N = mask.shape[0]
         g_out = g_out.contiguous().float()
         g_base = torch.empty_like(g_out)
-        g_sec = torch.empty((ctx.m,) + tuple(g_out.shape[1:]), dtype=torch.float32, device=g_out.device)
+        g_sec = None if ctx.detach_sec else torch.empty((ctx.m,) + tuple(g_out.shape[1:]), dtype=torch.float32, device=g_out.device)
         p = _lib.ptr
         _lib.check(_lib.lib().mnrf_blend_backward(p(g_out), p(mask), p(index) if ctx.compact else None, ctx.m, N, ctx.c,
                                                   p(g_base), p(g_sec), _lib.stream()), "mnrf_blend_backward")
-        return g_base, g_sec, None, None, None
+        return g_base, g_sec, None, None, None, None

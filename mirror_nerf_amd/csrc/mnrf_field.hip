@@ -217,7 +217,7 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
                                    const float* g_is_mirror, const float* rgb, const float* pred_normal,
                                    const float* is_mirror, const float* save_x, const uint64_t* save_mask,
                                    const float* save_inv, float* workspace, float* const* d_params, float* d_xyz,
-                                   float* d_dir, unsigned flags, void* stream) {
+                                   float* d_dir, const float* keep_mirror, unsigned flags, void* stream) {
     if (!packed || !save_x || !save_mask || !save_inv || !workspace || !d_params)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: negative sample count");
@@ -230,7 +230,8 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
     float* dY = workspace;
     float* ws = workspace + (int64_t)DY_FLOATS * B;
     FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
-                       g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, dY, d_xyz, d_dir};
+                       g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, dY, d_xyz, d_dir,
+                       flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror};
     hipStream_t s = (hipStream_t)stream;
     if (((flags & MNRF_SPLIT_F16) ? launch_split_bwd(A, s) : s2::launch_bwd(A, s)) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");

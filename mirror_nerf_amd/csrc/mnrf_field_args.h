@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mnrf.h"
 #include "mnrf_layout.h"
 
 namespace mnrf {
@@ -45,6 +46,10 @@ struct FieldBwdArgs {
     float* dY;
     float* d_xyz;
     float* d_dir;
+    // gradient steering (models/mirror_nerf.py:154-183): heads that see geo_feat.detach() still get their own weight
+    // gradients, but add nothing to dL/dh8
+    unsigned cut;               // MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD
+    const float* keep_mirror;   // per ray (per sample with xyz) or null: 0 = cut the mirror head for this ray's samples
 };
 // second-order pass (gradient through the density-gradient normal)
 struct FieldBwd2Args {

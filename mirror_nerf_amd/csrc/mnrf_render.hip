@@ -191,6 +191,9 @@ struct CompBwdArgs {
     const float* g_w; const float* g_op; const float* g_rgb; const float* g_depth; const float* g_mask;
     const float* g_sn; const float* g_sng; const float* g_nd; const float* g_xs;
     float* d_sigma; float* d_rgb; float* d_mirror; float* d_pn; float* d_n; float* d_rays;
+    // gradient steering (models/rendering.py:222-264): which composited outputs see the weights as constants
+    int detach;                 // MNRF_DETACH_W_MASK: mirror mask of every ray; MNRF_DETACH_W_NORMAL: the three normal outputs
+    const float* keep_mirror;   // (n_rays) or null: rays whose entry is 0 see detached weights in the mirror mask
 };
 constexpr int CB_MAXB = 4;
 
@@ -209,6 +212,13 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompBwdArgs A) 
     float gd = A.g_depth ? A.g_depth[ray] : 0.f;
     const float gm = A.g_mask ? A.g_mask[ray] : 0.f;
     const float gnd = A.g_nd ? A.g_nd[ray] : 0.f;
+    // the same cotangents as seen by the WEIGHTS (zero where the reference multiplies weights.detach())
+    const bool w_mask = !(A.detach & MNRF_DETACH_W_MASK) && !(A.keep_mirror && A.keep_mirror[ray] == 0.f);
+    const bool w_nrm = !(A.detach & MNRF_DETACH_W_NORMAL);
+    const float gm_w = w_mask ? gm : 0.f;
+    const float gnd_w = w_nrm ? gnd : 0.f;
+    float gsn_w[3], gsg_w[3];
+    for (int k = 0; k < 3; ++k) { gsn_w[k] = w_nrm ? gsn[k] : 0.f; gsg_w[k] = w_nrm ? gsg[k] : 0.f; }
     if (A.g_xs && r8) gd += gxs[0] * r8[3] + gxs[1] * r8[4] + gxs[2] * r8[5];   // x_surface = o + d * depth
     if (A.white_back) gop -= gc[0] + gc[1] + gc[2];                            // rgb_map += 1 - opacity
     if (A.d_rays && lane == 0) {
@@ -237,12 +247,12 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompBwdArgs A) 
             alpha = 1.f - expf(-delta * fmaxf(sv, 0.f));
             G = (A.g_w ? A.g_w[i1] : 0.f) + gop + gd * zv;
             if (A.rgb) G += gc[0] * A.rgb[i3] + gc[1] * A.rgb[i3 + 1] + gc[2] * A.rgb[i3 + 2];
-            if (A.is_mirror) G += gm * A.is_mirror[i1];
-            if (A.pred_normal) { for (int k = 0; k < 3; ++k) { pn[k] = A.pred_normal[i3 + k]; G += gsn[k] * pn[k]; } }
-            if (A.normal) { for (int k = 0; k < 3; ++k) { gn[k] = A.normal[i3 + k]; G += gsg[k] * gn[k]; } }
+            if (A.is_mirror) G += gm_w * A.is_mirror[i1];
+            if (A.pred_normal) { for (int k = 0; k < 3; ++k) { pn[k] = A.pred_normal[i3 + k]; G += gsn_w[k] * pn[k]; } }
+            if (A.normal) { for (int k = 0; k < 3; ++k) { gn[k] = A.normal[i3 + k]; G += gsg_w[k] * gn[k]; } }
             if (A.pred_normal && A.normal) {
                 const float d0 = gn[0] - pn[0], d1 = gn[1] - pn[1], d2 = gn[2] - pn[2];
-                G += gnd * (d0 * d0 + d1 * d1 + d2 * d2);
+                G += gnd_w * (d0 * d0 + d1 * d1 + d2 * d2);
             }
         }
         const float t = in ? (1.f - alpha) + 1e-10f : 1.f;
@@ -617,7 +627,8 @@ extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S,
                                        const float* g_mirror_mask, const float* g_surf_normal,
                                        const float* g_surf_normal_grad, const float* g_normal_dif,
                                        const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
-                                       float* d_pred_normal, float* d_normal, float* d_rays, void* stream) {
+                                       float* d_pred_normal, float* d_normal, float* d_rays, int detach,
+                                       const float* keep_mirror, void* stream) {
     (void)weights;   // recomputed in-kernel from sigma and z (cheaper than reading them back)
     if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: bad size");
     if (S > 64 * CB_MAXB) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_composite_backward: needs S <= 256");
@@ -632,7 +643,7 @@ extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S,
     if (d_rays && !depth) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: d_rays needs the forward depth");
     CompBwdArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
                   depth, g_weights, g_opacity, g_rgb_map, g_depth, g_mirror_mask, g_surf_normal, g_surf_normal_grad,
-                  g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays};
+                  g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays, detach, keep_mirror};
     hipLaunchKernelGGL(composite_backward_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_composite_backward");
 }

@@ -14,9 +14,37 @@ import torch
 import torch.distributed as dist
 
 TILE = 4096
-# MNRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box
-# exercise the RCCL code path that the 8-GPU run uses).
-FORCE = os.environ.get("MNRF_FORCE_COLLECTIVES", "0") == "1"
+
+
+def forced():
+    """MNRF_FORCE_COLLECTIVES=1: issue the collectives even in a 1-rank group (lets a single-GPU box exercise the
+    RCCL code path that the 8-GPU run uses)."""
+    return os.environ.get("MNRF_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
+def init_from_env(device=None):
+    """One process per GPU (train.py:577-584 gets the same from Lightning DDP): reads RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as set by torch.distributed.run, binds this process to GPU LOCAL_RANK and brings up the RCCL group
+    (backend "nccl" IS RCCL on ROCm).  A 1-rank group is only created when MNRF_FORCE_COLLECTIVES=1.
+    Returns (rank, world_size, device)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    want_group = ws > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ)
+    if want_group and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver
+        if device.type == "cuda":
+            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=ws)
+    return rank, ws, device
 
 
 def world():
@@ -39,14 +67,24 @@ def render_sharded(render_fn, rays, tile=TILE):
     return idx, render_fn(rays[idx].contiguous())
 
 
-def gather_frame(idx, results, n_rays, keys=None, dst=0):
-    """Optional assembly of full per-ray maps on rank `dst` (20 B/ray for rgb+depth+mask at most)."""
+def shard_count(n_rays, rank, world_size, tile=TILE):
+    """len(shard_indices(...)) without building the index."""
+    full, rem = divmod(n_rays, tile)
+    n = (full // world_size + (1 if rank < full % world_size else 0)) * tile
+    return n + (rem if full % world_size == rank else 0)
+
+
+def gather_frame(idx, results, n_rays, keys=None, dst=0, tile=TILE):
+    """Optional assembly of full per-ray maps on rank `dst` (20 B/ray for rgb+depth+mask at most).  `tile` must be the
+    tile size `idx` was dealt with (render_sharded's)."""
     rank, ws = world()
     keys = list(results) if keys is None else keys
-    if ws == 1:
+    if ws == 1 and not forced():
         return {k: results[k] for k in keys}
     out = {}
-    counts = [int(shard_indices(n_rays, r, ws, TILE).numel()) for r in range(ws)]
+    counts = [shard_count(n_rays, r, ws, tile) for r in range(ws)]
+    if counts[rank] != idx.numel():
+        raise RuntimeError(f"gather_frame: this rank holds {idx.numel()} rays but tile={tile} deals it {counts[rank]}")
     idx_parts = [torch.empty(c, dtype=idx.dtype, device=idx.device) for c in counts]
     dist.all_gather(idx_parts, idx) if len(set(counts)) == 1 else _all_gather_ragged(idx_parts, idx, counts)
     for k in keys:
@@ -73,7 +111,7 @@ def _all_gather_ragged(parts, mine, counts):
 def max_over_ranks(seconds, device):
     """The slowest rank's time (bench.py contract)."""
     rank, ws = world()
-    if ws == 1 and not (FORCE and dist.is_initialized()):
+    if ws == 1 and not forced():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -85,7 +123,7 @@ def allreduce_gradients(params, average=True):
     inside RCCL uses all 7 xGMI links; a 5.3 MB message is latency-, not bandwidth-bound)."""
     rank, ws = world()
     grads = [p.grad for p in params if p.grad is not None]
-    if (ws == 1 and not (FORCE and dist.is_initialized())) or not grads:
+    if (ws == 1 and not forced()) or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -77,12 +77,12 @@ def _reflect_autograd(rays, x_surface, normal, mask, compact):
     return sec, (index if compact else None), rdir
 
 
-def _blend_autograd(base, sec, index, mask, want_reflect):
+def _blend_autograd(base, sec, index, mask, want_reflect, detach_sec=False):
     """train.py:263-296 with gradient history (BlendFn); the optional visualisation output is detached."""
     from .autograd import BlendFn
     compact = index is not None
     idx = index if compact else torch.empty(0, dtype=torch.int32, device=base.device)
-    out = BlendFn.apply(base, sec, idx, mask, compact)
+    out = BlendFn.apply(base, sec, idx, mask, compact, detach_sec)
     refl = None
     if want_reflect:
         refl = torch.zeros_like(base)
@@ -145,6 +145,11 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     traced = False
     grad_path = torch.is_grad_enabled() and r[f"rgb_{sel}"].requires_grad
     reflect_fn, blend_fn = (_reflect_autograd, _blend_autograd) if grad_path else (_reflect, _blend)
+    if grad_path and getattr(hp, "detach_ref_color_for_blend", False) and \
+            extra_chunk.get("current_epoch", 0) >= getattr(hp, "train_geometry_stage_end_epoch", 4) + 1:
+        # train.py:284-289 (the reference reads Lightning's self.current_epoch; here: extra["current_epoch"], which
+        # training_step passes as the same number, train.py:426)
+        blend_fn = lambda *a: _blend_autograd(*a, detach_sec=True)  # noqa: E731
     if trace and N:
         nrm = _pick_normal(r, sel)
         if getattr(hp, "detach_normal_in_reflection", False):

@@ -8,7 +8,8 @@ mnrf_field_forward -> mnrf_composite.  Python only allocates outputs and assembl
 Differences from the reference that do not change values:
   * `chunk` does not split the MLP evaluation (the kernel is already tiled; results are
     independent of the split, SURVEY 8a noise-floor table);
-  * the three detach_* kwargs and `mirror_mask` only steer gradients in the reference;
+  * the three detach_* kwargs and `mirror_mask` only steer gradients (rendering.py:223-247, mirror_nerf.py:154-183);
+    they are honoured by the backward kernels (flags of mnrf_composite_backward / mnrf_field_backward);
   * random draws can be injected (`_perturb_rand`, `_noise_coarse`, `_noise_fine`, `_u`) so that
     tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator;
   * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
@@ -92,6 +93,28 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     train = torch.is_grad_enabled() and (rays.requires_grad or any(
         q.requires_grad for mdl in models.values() for q in params_of(mdl)))
+
+    # gradient steering (values are unaffected): rendering.py:223-247 for the compositing weights,
+    # mirror_nerf.py:154-183 for what the normal / mirror heads send into geo_feat
+    comp_detach, cut_heads, keep_mirror = 0, 0, None
+    if train:
+        if kwargs.get("detach_density_for_mask_loss", False):
+            comp_detach |= _lib.MNRF_DETACH_W_MASK
+            cut_heads |= _lib.MNRF_CUT_MIRROR_HEAD
+        elif kwargs.get("detach_density_outside_mirror_for_mask_loss", False) and kwargs.get("mirror_mask") is not None:
+            mm = kwargs["mirror_mask"]
+            if not bool((mm < 0).any().item()):
+                if mm.shape[0] != N:
+                    # the reference indexes the (N,S) weights with this mask and fails the same way when reflected rays
+                    # were compacted (train.py:253-259 passes the un-compacted mask on, SURVEY 8a hazard 10)
+                    raise IndexError(f"detach_density_outside_mirror_for_mask_loss: mirror_mask has {mm.shape[0]} entries "
+                                     f"for {N} rays (compacted reflected rays: use only_trace_rays_in_mirrors=False)")
+                keep_mirror = mm.bool().float().contiguous()
+        if kwargs.get("detach_density_for_normal_loss", False):
+            comp_detach |= _lib.MNRF_DETACH_W_NORMAL
+            cut_heads |= _lib.MNRF_CUT_NORMAL_HEAD
+        if hashgrid and (comp_detach or cut_heads or keep_mirror is not None):
+            raise NotImplementedError("the detach_density_* options are not implemented for the hash-grid field")
 
     # rendering.py:275-277 -- view encoding once per ray
     view = kwargs.get("view_dir", rays[:, 3:6])
@@ -180,8 +203,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:
-            sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
-                                                        *params_of(model))
+            want = bool(compute_normal)
+            if cut_heads or keep_mirror is not None:
+                want = (want, cut_heads, keep_mirror)
+            sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, want, *params_of(model))
         noise = kwargs.get(noise_key)
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()
@@ -189,7 +214,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             noise = torch.randn(N, S, device=dev) * noise_std
         nrm = normal if compute_normal else None
         weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
-            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back))
+            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror)
         results[f"weights_{typ}"] = weights
         results[f"opacity_{typ}"] = opacity
         results[f"z_vals_{typ}"] = z

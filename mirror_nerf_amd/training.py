@@ -45,8 +45,18 @@ def total_loss_fn(hparams=None, epoch=5):
     return fn
 
 
-def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss):
-    res = system(rays, {"mirror_mask": gt_mask, "is_eval": False, "train_geometry_stage": False})
+def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
+    """The `extra` dict training_step hands to NeRFSystem.forward (train.py:420-436), incl. the gradient-steering options."""
+    return {"mirror_mask": gt_mask, "is_eval": False, "train_geometry_stage": train_geometry_stage,
+            "only_one_field": getattr(hp, "only_one_field", False),
+            "only_one_field_fine_epoch": getattr(hp, "only_one_field_fine_epoch", 2), "current_epoch": epoch,
+            "detach_density_outside_mirror_for_mask_loss": getattr(hp, "detach_density_outside_mirror_for_mask_loss", False),
+            "detach_density_for_mask_loss": getattr(hp, "detach_density_for_mask_loss", False),
+            "detach_density_for_normal_loss": getattr(hp, "detach_density_for_normal_loss", False)}
+
+
+def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
+    res = system(rays, extra_info(system.hparams, gt_mask, epoch))
     loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()

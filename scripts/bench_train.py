@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mirror_nerf_amd import training  # noqa: E402
-from oracle import mirror_nerf_oracle as O  # noqa: E402
+from mirror_nerf_amd import dist as D, synthetic as SY  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
@@ -20,16 +20,10 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--loss", choices=("color_mask", "total"), default="color_mask",
                 help="total = the reference's TotalLoss through the fused HIP loss kernels (reads normal_*: second-order pass on)")
 a = ap.parse_args()
-world = int(os.environ.get("WORLD_SIZE", "1"))
-local = int(os.environ.get("LOCAL_RANK", "0"))
-torch.cuda.set_device(local)
-dev = torch.device("cuda", local)
-if world > 1 or (os.environ.get("MNRF_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
-rays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
+rank, world, dev = D.init_from_env()
+rays = SY.device_rays(800, 800, dev)
 r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch, loss_name=a.loss)
-if int(os.environ.get("RANK", "0")) == 0:
+if rank == 0:
     r["n_gpus"] = world
     print(json.dumps(r))
 if dist.is_initialized():

@@ -28,6 +28,29 @@ def _stub(name, **attrs):
     return mod
 
 
+def _create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=None):
+    """kornia.utils.create_meshgrid (kornia is absent from this image and un-pinned in the reference's README):
+    its published definition -- xs = linspace(0, W-1, W), ys = linspace(0, H-1, H), grid[0, y, x] = (xs[x], ys[y]),
+    shape (1, H, W, 2).  The reference only calls it with normalized_coordinates=False (datasets/ray_utils.py:18),
+    where every entry is an exactly representable integer, so there is no rounding to pin."""
+    import torch
+    if normalized_coordinates:
+        raise NotImplementedError("only the un-normalised grid is used by the reference's ray generator")
+    xs = torch.linspace(0, width - 1, width, device=device, dtype=dtype)
+    ys = torch.linspace(0, height - 1, height, device=device, dtype=dtype)
+    return torch.stack(torch.meshgrid([xs, ys], indexing="ij"), dim=-1).permute(1, 0, 2).unsqueeze(0)
+
+
+def ray_utils():
+    """datasets/ray_utils.py imported by path (the `datasets` package itself pulls cv2/PIL dataset classes)."""
+    install()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(REF_ROOT, "datasets", "ray_utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def install():
     """Make `models.rendering`, `models.mirror_nerf`, `train`, `eval` importable."""
     if not available():
@@ -75,7 +98,7 @@ def install():
     tv = _stub("torchvision")
     tv.transforms = _stub("torchvision.transforms")
     tv.utils = _stub("torchvision.utils")
-    k = _stub("kornia", create_meshgrid=None)
+    k = _stub("kornia", create_meshgrid=_create_meshgrid)
     k.losses = _stub("kornia.losses", ssim=None)
     _stub("imageio")
     ds = _stub("datasets", dataset_dict={})

@@ -25,6 +25,13 @@ def full_loss(res, target, gt):
     return L
 
 
+def mask_focus_loss(res, target, gt):
+    """A loss dominated by the composited mirror mask (fixtures G9b for the --detach_density_*_for_mask_loss options: with
+    the density detached from this term, the trunk is only reached through the small colour term)."""
+    L = 0.01 * (((res["rgb_coarse"] - target) ** 2).mean() + ((res["rgb_fine"] - target) ** 2).mean())
+    return L + ((res["mirror_mask_fine"] - gt) ** 2).mean() + ((res["mirror_mask_coarse"] - gt) ** 2).mean()
+
+
 def grad_summary(t, like=None):
     if t is None:   # parameter not reached by the loss
         t = torch.zeros_like(like)

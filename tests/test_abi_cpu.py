@@ -94,3 +94,22 @@ def test_module_mirrors_reference_names():
         assert (v.numpy() == ref[k]).all(), k     # same construction order => same init under a seed
     with pytest.raises(NotImplementedError):
         M.MirrorNeRF(W=128, predict_normal=True, predict_mirror_mask=True)
+
+
+def test_isa_invariants_of_the_built_field_kernels():
+    """scripts/check_isa.py on the objects linked into libmnrf_hip.so: the counted s_waitcnt schemes of the field
+    kernels require that no scalar load sits inside an MFMA range and that the forward kernels do not spill."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "ISA check ok" in r.stdout
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`--gpus N` must equal the launched world size (a mismatch used to run one process labelled n_gpus 1)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -30,6 +30,8 @@ def _worker(rank, ws, port, n_rays, q):
 
         idx, res = D.render_sharded(fake_render, rays, tile=D.TILE)
         full = D.gather_frame(idx, res, n_rays)
+        idx2, res2 = D.render_sharded(fake_render, rays, tile=1000)      # a non-default tile must size the gather buffers
+        full2 = D.gather_frame(idx2, res2, n_rays, tile=1000)
         t = D.max_over_ranks(1.0 + rank, "cpu")
         p = torch.nn.Parameter(torch.zeros(5))
         p.grad = torch.full((5,), float(rank + 1))
@@ -39,7 +41,7 @@ def _worker(rank, ws, port, n_rays, q):
         ok = True
         if rank == 0:
             want = fake_render(rays)
-            ok = all(torch.equal(full[k], want[k]) for k in want)
+            ok = all(torch.equal(full[k], want[k]) and torch.equal(full2[k], want[k]) for k in want)
         q.put((rank, int(idx.numel()), ok, t, p.grad.tolist(), p2.grad[0, 0].item()))
     finally:
         dist.destroy_process_group()
@@ -68,3 +70,11 @@ def test_shard_indices_partition():
     for n, ws in ((10, 1), (4096 * 5 + 7, 2), (4096 * 9, 4), (100, 8)):
         seen = torch.cat([D.shard_indices(n, r, ws) for r in range(ws)])
         assert torch.equal(torch.sort(seen)[0], torch.arange(n))
+
+
+def test_shard_count_matches_indices():
+    for n in (0, 1, 4095, 4096, 4097, 4096 * 5 + 7, 640000):
+        for ws in (1, 2, 3, 8):
+            for tile in (4096, 1000):
+                for r in range(ws):
+                    assert D.shard_count(n, r, ws, tile) == D.shard_indices(n, r, ws, tile).numel(), (n, ws, tile, r)

@@ -1,0 +1,108 @@
+"""RCCL on the GPU box: the collectives of mirror_nerf_amd.dist through backend "nccl" (= RCCL on ROCm).
+
+A 1-GPU box can only form a 1-rank group; MNRF_FORCE_COLLECTIVES=1 makes dist.py issue the collectives anyway, so the
+code path of the 8-GPU run (init_from_env -> allreduce_gradients / max_over_ranks / gather_frame on device tensors, the
+sharded render through the HIP path) executes here.  The 2-rank variant runs wherever two GPUs are visible.
+Each case runs in child processes (a process group cannot be re-initialised inside the pytest process)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, os.environ["MNRF_ROOT"])
+    import torch, torch.distributed as dist
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import dist as D, synthetic as SY, training
+
+    rank, ws, dev = D.init_from_env()
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == ws
+    assert dev.index == int(os.environ["LOCAL_RANK"]) == torch.cuda.current_device()
+
+    # max over ranks / flat gradient all-reduce on device tensors
+    assert D.max_over_ranks(1.0 + rank, dev) == float(ws)
+    p1 = torch.nn.Parameter(torch.zeros(5, device=dev)); p1.grad = torch.full((5,), float(rank + 1), device=dev)
+    p2 = torch.nn.Parameter(torch.zeros(2, 3, device=dev)); p2.grad = torch.full((2, 3), 10.0 * (rank + 1), device=dev)
+    D.allreduce_gradients([p1, p2])
+    mean = sum(range(1, ws + 1)) / ws
+    assert torch.allclose(p1.grad, torch.full((5,), mean, device=dev)) and torch.allclose(p2.grad, torch.full((2, 3), 10 * mean, device=dev))
+
+    # a frame dealt to the ranks in interleaved tiles through the HIP path, assembled on rank 0, equals the unsharded render
+    models, _ = SY.build_models(dev, SY.STRADDLE, seed=0)
+    emb = {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
+    rays = SY.device_rays(24, 24, dev)
+    args = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
+    render = lambda r: M.batched_inference(models, emb, r, 64, 64, False, 32768, args=args, trace_secondary_rays=True, to_cpu=False)
+    keys = ("rgb_fine", "depth_fine", "mirror_mask_fine")
+    idx, res = D.render_sharded(render, rays, tile=100)
+    full = D.gather_frame(idx, res, rays.shape[0], keys=keys, tile=100)
+    if rank == 0:
+        want = render(rays)
+        for k in keys:
+            assert torch.equal(full[k], want[k]), k
+
+    # the training step with the flat all-reduce: every rank ends with identical parameters
+    r = training.synthetic_train_bench(dev, SY.device_rays(64, 64, dev), steps=2, warmup=1, batch=256)
+    assert r["ms_per_step"] > 0
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MNRF_ROOT=ROOT, MNRF_FORCE_COLLECTIVES="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append((p.returncode, out))
+    for r, (rc, out) in enumerate(outs):
+        assert rc == 0 and f"RANK_OK {r}" in out, out[-3000:]
+
+
+def test_rccl_one_rank_group_runs_every_collective():
+    _run(1)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_rccl_two_ranks():
+    _run(2)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes under torch.distributed.run; here N = 1 with the
+    collectives forced and the launcher path taken (MNRF_BENCH_SPAWN=1), so that the RCCL legs (strong_scaling, train_step all-reduce) run and are reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MNRF_FORCE_COLLECTIVES="1", MNRF_BENCH_SPAWN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_world_size"] == 1 and line["config"]["collective_backend"].startswith("nccl")
+    assert line["strong_scaling"]["rays_per_s"] > 0 and line["train_step"]["ms_per_step"] > 0

@@ -346,6 +346,20 @@ def test_generate_rays_matches_oracle():
     assert np.all(r[:, 6] == np.float32(0.05)) and np.all(r[:, 7] == 8)
 
 
+@pytest.mark.parametrize("name", ["g12_rays_37x53", "g12_rays_64x64"])
+def test_generate_rays_golden(name):
+    """G12: mnrf_generate_rays against rays captured from the reference's datasets/ray_utils.py:6-53 + blender.py:159-168."""
+    from mirror_nerf_amd import synthetic as SY
+    fx = FX.Fixture(name)
+    m = fx.meta
+    angle = 2 * np.arctan(0.5 * m["W"] / m["focal"])
+    rays = SY.device_rays(m["H"], m["W"], DEV, fx.inputs["pose"], m["near"], m["far"], camera_angle_x=angle).cpu().numpy()
+    want = fx.outputs["rays"]
+    assert rays.shape == want.shape
+    assert np.max(np.abs(rays[:, :6] - want[:, :6])) <= 1e-6
+    assert np.array_equal(rays[:, 6:], want[:, 6:])
+
+
 def test_psnr_against_oracle_render():
     """BASELINE north star: PSNR within 0.1 dB of the reference.  The HIP render of a 24x24 view is
     compared with the oracle's render of the same view: the two images differ by ~1e-6, i.e. their

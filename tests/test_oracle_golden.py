@@ -101,6 +101,17 @@ def test_recursion_eval(name):
     _cmp(fx, got, skip=FX.PER_SAMPLE_FINE, base=5e-6)
 
 
+@pytest.mark.parametrize("name", ["g12_rays_37x53", "g12_rays_64x64"])
+def test_ray_generation_golden(name):
+    """G12: the oracle's pin-hole rays against the reference's (datasets/ray_utils.py:6-53, captured by make_golden_rays.py)."""
+    fx = FX.Fixture(name)
+    m = fx.meta
+    o, d = O.get_rays(O.get_ray_directions(m["H"], m["W"], m["focal"]), fx.inputs["pose"])
+    want = fx.outputs["rays"]
+    assert np.max(np.abs(o - want[:, 0:3])) <= 1e-6 and np.max(np.abs(d - want[:, 3:6])) <= 1e-6
+    assert np.all(want[:, 6] == np.float32(m["near"])) and np.all(want[:, 7] == np.float32(m["far"]))
+
+
 def test_synthetic_rays_shape_and_norm():
     rays = O.synthetic_rays(20, 30)
     assert rays.shape == (600, 8)
@@ -141,3 +152,20 @@ def test_sh4_is_orthonormal_on_the_sphere():
     Y = O.sh4(d).astype(np.float64)
     gram = 4 * np.pi * (Y.T @ Y) / d.shape[0]
     assert np.max(np.abs(gram - np.eye(16))) < 0.03
+
+
+def test_torch_port_matches_oracle():
+    """oracle/torch_port.py (the plain-torch CPU baseline bench.py times) against the pinned numpy oracle: eval
+    semantics, one and two bounces, all-mirror and straddling mirror heads."""
+    import torch
+    from mirror_nerf_amd import synthetic as SY
+    from oracle import torch_port as TP
+    rays = O.synthetic_rays(40, 40)[::13][:96].copy()
+    for tweaks, levels in ((SY.ALL_MIRROR, 1), (SY.STRADDLE, 2)):
+        sds = [SY.apply_tweaks(sd, tweaks) for sd in SY.make_state_dict(0, 2)]
+        args = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=levels)
+        want = O.render_eval({"coarse": sds[0], "fine": sds[1]}, {"xyz": 10, "dir": 4}, rays, 64, 128, False, 32768, args)
+        mt = {k: {n: torch.from_numpy(v) for n, v in sd.items()} for k, sd in zip(("coarse", "fine"), sds)}
+        got = TP.render_eval(mt, torch.from_numpy(rays), 64, 128, 32768, max_level=levels)
+        for k in ("rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine", "surface_normal_fine"):
+            assert np.abs(got[k].numpy() - want[k]).max() <= 2e-6, k

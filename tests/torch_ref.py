@@ -16,9 +16,10 @@ def embed(x, n):
     return torch.cat(out, -1)
 
 
-def field(w, xyz, dir_emb, with_normal=False):
+def field(w, xyz, dir_emb, with_normal=False, cut_normal=False, cut_mirror=False, keep_mirror=None):
     """w: dict name -> tensor (reference parameter names); returns sigma (B), rgb, pred_normal, is_mirror (B)
-    [, normal = l2n(-d sigma/d xyz) built with create_graph=True like utils/func.py:10-25]."""
+    [, normal = l2n(-d sigma/d xyz) built with create_graph=True like utils/func.py:10-25].
+    cut_normal / cut_mirror / keep_mirror (B, bool): the heads see geo_feat.detach() (mirror_nerf.py:154-183)."""
     if with_normal and not xyz.requires_grad:
         xyz = xyz.requires_grad_(True)
     enc = embed(xyz, 10)
@@ -31,9 +32,13 @@ def field(w, xyz, dir_emb, with_normal=False):
     fin = h @ w["xyz_encoding_final.weight"].T + w["xyz_encoding_final.bias"]
     hd = torch.relu(torch.cat([fin, dir_emb], -1) @ w["dir_encoding.0.weight"].T + w["dir_encoding.0.bias"])
     rgb = torch.sigmoid(hd @ w["rgb.0.weight"].T + w["rgb.0.bias"])
-    hn = h @ w["normal_net.0.weight"].T + w["normal_net.0.bias"]
+    hN = h.detach() if cut_normal else h
+    hM = h.detach() if cut_mirror else h
+    if keep_mirror is not None and not cut_mirror:
+        hM = torch.where(keep_mirror[:, None], h, h.detach())
+    hn = hN @ w["normal_net.0.weight"].T + w["normal_net.0.bias"]
     pn = l2n(hn @ w["normal_net.1.weight"].T + w["normal_net.1.bias"])
-    hm = torch.nn.functional.leaky_relu(h @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
+    hm = torch.nn.functional.leaky_relu(hM @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
     m = torch.sigmoid(hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"])[:, 0]
     if with_normal:
         (grad,) = torch.autograd.grad(sigma, xyz, torch.ones_like(sigma), create_graph=True, retain_graph=True)
@@ -41,8 +46,9 @@ def field(w, xyz, dir_emb, with_normal=False):
     return sigma, rgb, pn, m
 
 
-def composite(rays, sigma, z, noise, rgb, is_mirror, pn, nrm, white_back=False):
-    """models/rendering.py:181-264, 362-367 on (N,S) tensors."""
+def composite(rays, sigma, z, noise, rgb, is_mirror, pn, nrm, white_back=False, detach_mask=False, keep_mirror=None,
+              detach_normal=False):
+    """models/rendering.py:181-264, 362-367 on (N,S) tensors (detach_*: rendering.py:223-247)."""
     deltas = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
     sv = sigma if noise is None else sigma + noise
     alphas = 1 - torch.exp(-deltas * torch.relu(sv))
@@ -54,10 +60,14 @@ def composite(rays, sigma, z, noise, rgb, is_mirror, pn, nrm, white_back=False):
     if white_back:
         rgb_map = rgb_map + 1 - op[:, None]
     depth = (w * z).sum(1)
-    out.update(rgb=rgb_map, depth=depth, mask=(w * is_mirror).sum(1), sn=(w[..., None] * pn).sum(1))
+    wm = w.detach() if detach_mask else w
+    if keep_mirror is not None and not detach_mask:
+        wm = torch.where(keep_mirror[:, None], w, w.detach())
+    wn = w.detach() if detach_normal else w
+    out.update(rgb=rgb_map, depth=depth, mask=(wm * is_mirror).sum(1), sn=(wn[..., None] * pn).sum(1))
     if nrm is not None:
-        out["sng"] = (w[..., None] * nrm).sum(1)
-        out["nd"] = (w * ((nrm - pn) ** 2).sum(-1)).sum(1)
+        out["sng"] = (wn[..., None] * nrm).sum(1)
+        out["nd"] = (wn * ((nrm - pn) ** 2).sum(-1)).sum(1)
     out["xs"] = rays[:, :3] + rays[:, 3:6] * depth[:, None]
     return out
 
