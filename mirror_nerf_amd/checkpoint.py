@@ -2,12 +2,38 @@
 eval.py:996-1001): a Lightning `.ckpt` (or a plain dict) whose `state_dict` keys are
 `nerf_coarse.<param>` / `nerf_fine.<param>` loads into our MirrorNeRF modules unchanged, and
 `save_ckpt` writes the same layout back."""
+import os
+import pickle
+
 import torch
 
 
-def extract_model_state_dict(ckpt, model_name="model", prefixes_to_ignore=()):
-    """ckpt: path or an already loaded dict.  Returns {param name: tensor} of `model_name`."""
-    checkpoint = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) else ckpt
+def _load_file(path, trusted=False):
+    """torch.load of a checkpoint file.  Tensors-only first (`weights_only=True`, the default of this torch).  Lightning
+    1.5 checkpoints of the reference also pickle `hyper_parameters` (an argparse.Namespace / AttributeDict), callbacks
+    and optimizer states: those load with the known plain containers allow-listed; anything else needs `trusted=True`
+    (full unpickling executes code from the file -- only for checkpoints you wrote yourself)."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        first = e
+    import argparse
+    import collections
+    allow = [argparse.Namespace, collections.OrderedDict, collections.defaultdict, dict]
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if trusted:
+            return torch.load(path, map_location="cpu", weights_only=False)
+        raise RuntimeError(
+            f"{path}: the checkpoint pickles objects outside the tensors-only allow-list ({e}); if you trust the file, "
+            "pass trusted=True (load_ckpt / extract_model_state_dict) to unpickle it fully") from first
+
+
+def extract_model_state_dict(ckpt, model_name="model", prefixes_to_ignore=(), trusted=False):
+    """ckpt: path (str / bytes / os.PathLike) or an already loaded dict.  Returns {param name: tensor} of `model_name`."""
+    checkpoint = _load_file(os.fspath(ckpt), trusted) if isinstance(ckpt, (str, bytes, os.PathLike)) else ckpt
     if "state_dict" in checkpoint:   # pytorch-lightning checkpoint
         checkpoint = checkpoint["state_dict"]
     out = {}
@@ -21,11 +47,11 @@ def extract_model_state_dict(ckpt, model_name="model", prefixes_to_ignore=()):
     return out
 
 
-def load_ckpt(model, ckpt, model_name="model", prefixes_to_ignore=()):
+def load_ckpt(model, ckpt, model_name="model", prefixes_to_ignore=(), trusted=False):
     if not ckpt:
         return
     sd = model.state_dict()
-    got = extract_model_state_dict(ckpt, model_name, prefixes_to_ignore)
+    got = extract_model_state_dict(ckpt, model_name, prefixes_to_ignore, trusted)
     assert len(got) > 0, "[Error] can not find {} in checkpoint".format(model_name)
     sd.update(got)
     model.load_state_dict(sd, strict=False)

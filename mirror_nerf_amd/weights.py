@@ -82,7 +82,11 @@ def params_of(module):
 
 
 class PackedCache:
-    """Packed image of one nn.Module (ours or the reference's), refreshed when parameters change."""
+    """Packed image of one nn.Module (ours or the reference's), refreshed when parameters change.
+
+    "Changed" = a parameter was re-assigned, moved, or written through an autograd-visible in-place op (optimizer steps,
+    `load_state_dict`, `p.mul_()` under no_grad ...): those bump `Tensor._version`.  Writes through `p.data` (some EMA /
+    clamping code does that) do NOT -- call `invalidate_packed(module)` after such surgery."""
 
     def __init__(self):
         self.key = None
@@ -95,6 +99,17 @@ class PackedCache:
             self.packed = pack_state(sd, self.packed)
             self.key = key
         return self.packed
+
+
+def invalidate_packed(module):
+    """Force the next launch to re-pack `module`'s weights (needed only after writes through `param.data`, which
+    bypass the version counter the cache is keyed on).  Covers the MirrorNeRF packed image and the hash-grid field's
+    weight blob."""
+    cache = module.__dict__.get("_mnrf_packed")
+    if cache is not None:
+        cache.key = None
+    if hasattr(module, "_blob_key"):
+        module._blob_key = None
 
 
 def packed_of(module):

@@ -40,3 +40,36 @@ def test_missing_model_name_asserts(tmp_path):
     import pytest
     with pytest.raises(AssertionError):
         C.load_ckpt(_mk(), {"state_dict": {"other.x": torch.zeros(1)}}, "nerf_coarse")
+
+
+class _Opaque:      # stands for an arbitrary pickled object (a callback instance, a custom hparams class)
+    def __init__(self):
+        self.x = 1
+
+
+def test_lightning_shaped_checkpoint_with_hyper_parameters(tmp_path):
+    """A Lightning 1.5 .ckpt carries hyper_parameters (argparse.Namespace), callbacks and optimizer states besides the
+    state_dict; torch >= 2.6 loads with weights_only=True by default.  Path objects are accepted."""
+    import argparse
+    import collections
+    import pytest
+    sd = GW.make_state_dict(4, 1)[0]
+    ck = {"state_dict": collections.OrderedDict((f"nerf_coarse.{k}", torch.from_numpy(v)) for k, v in sd.items()),
+          "epoch": 7, "global_step": 1234, "pytorch-lightning_version": "1.5.4",
+          "hyper_parameters": argparse.Namespace(N_samples=64, N_importance=64, model_type="nerf"),
+          "callbacks": {"ModelCheckpoint": {"best_model_score": torch.tensor(0.5), "dirpath": "ckpts/x"}},
+          "optimizer_states": [{"state": {}, "param_groups": [{"lr": 5e-4, "betas": (0.9, 0.999), "params": [0, 1]}]}],
+          "lr_schedulers": [{"last_epoch": 7, "milestones": collections.Counter({20: 1})}]}
+    path = tmp_path / "epoch=7.ckpt"
+    torch.save(ck, path)
+    m = _mk()
+    C.load_ckpt(m, path, "nerf_coarse")                       # pathlib.Path
+    assert (m.sigma.weight.detach().numpy() == sd["sigma.weight"]).all()
+    # an object outside the allow-list: refused with a clear message unless the caller trusts the file
+    ck["callbacks"]["mine"] = _Opaque()
+    torch.save(ck, path)
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        C.load_ckpt(_mk(), path, "nerf_coarse")
+    m2 = _mk()
+    C.load_ckpt(m2, path, "nerf_coarse", trusted=True)
+    assert (m2.sigma.weight.detach().numpy() == sd["sigma.weight"]).all()
