@@ -52,6 +52,14 @@ extern "C" {
 #define MNRF_DETACH_W_MASK 1       /* mnrf_composite_backward: mirror mask = sum(weights.detach() * is_mirror) (rendering.py:223-226) */
 #define MNRF_DETACH_W_NORMAL 2     /* mnrf_composite_backward: the normal outputs use weights.detach() (rendering.py:244-264) */
 
+/* Range guard of the split-f16 arithmetic.  The LAST 32-bit word of a packed weight image (index
+ * mnrf_packed_floats() - 1) is a sticky device flag: mnrf_pack_weights clears it, every MNRF_SPLIT_F16 kernel ORs in */
+#define MNRF_GUARD_SATURATED 1u    /* an operand of a Linear reached the f16 maximum: hi/lo pairs no longer carry fp32 */
+#define MNRF_GUARD_WEIGHT 2u       /* a weight is non-finite or >= 65504 in magnitude (set by mnrf_pack_weights) */
+#define MNRF_GUARD_ENC_RANGE 4u    /* a position with |x| >= 16: sin/cos arguments beyond 2^13, outside the fast exact reduction */
+/* The fp32 kernels never touch it.  Host policy (mirror_nerf_amd.mirror_nerf.check_guard): read it once per frame /
+ * training step; non-zero -> the module is switched to the exact fp32 kernels and the work is repeated. */
+
 const char* mnrf_last_error(void);
 int mnrf_version(void);
 

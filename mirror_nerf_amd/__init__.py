@@ -7,7 +7,7 @@ rendering hot path behind the reference's own Python interfaces.
 
 All arithmetic runs in libmnrf_hip.so (include/mnrf.h).  There is no CPU fallback.
 """
-from .mirror_nerf import Embedding, MirrorNeRF  # noqa: F401
+from .mirror_nerf import Embedding, MirrorNeRF, check_guard, reset_guard, set_precision, verify_split  # noqa: F401
 from .mirror_nerf_tcnn import MirrorNeRFTcnn  # noqa: F401
 from .rendering import render_rays, sample_pdf  # noqa: F401
 from .recursion import NeRFSystem, batched_inference, render_rays_chunk_recursively  # noqa: F401

@@ -120,11 +120,14 @@ class FieldFn(torch.autograd.Function):
             _lib.check(L.mnrf_field_forward_train(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
                 p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj),
-                _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()), "mnrf_field_forward_train")
+                _lib.MNRF_SPLIT_F16 if _mn.precision_of(module).startswith("split") else 0, _lib.stream()), "mnrf_field_forward_train")
+        ctx.split = _mn.precision_of(module).startswith("split")    # the backward follows the arithmetic of ITS forward
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.set_materialize_grads(False)   # an unused `normal` must arrive as None, not as zeros: it gates the second-order pass
         ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj)
         ctx.param_shapes = [tuple(t.shape) for t in params]
+        from .weights import param_refs
+        ctx.param_names = [full for _, _, full in param_refs(module)]     # same order as `params` (weights.params_of)
         if normal is None:
             normal = f(0, 3)
             ctx.mark_non_differentiable(normal)
@@ -144,7 +147,11 @@ class FieldFn(torch.autograd.Function):
         z = lambda t, *s: torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()  # noqa: E731
         g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
         d_params = [f(*s) for s in ctx.param_shapes]
-        arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in d_params])
+        from .weights import PARAM_NAMES, PARAM_SHAPES
+        by_name = dict(zip(ctx.param_names, d_params))
+        # the kernels write all 32 gradients in state_dict order; an absent optional head gets scratch buffers
+        all32 = [by_name[n] if n in by_name else f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+        arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in all32])
         need = ctx.needs_input_grad
         want_xyz = (xyz is not None and need[2]) or (rays is not None and need[3])
         d_xyz = f(B, 3) if want_xyz else None
@@ -156,14 +163,14 @@ class FieldFn(torch.autograd.Function):
             _lib.check(L.mnrf_field_backward(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), p(ctx.keep_mirror),
-                (_lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0) | ctx.cut, _lib.stream()),
+                (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut, _lib.stream()),
                 "mnrf_field_backward")
             if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
                 ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
                 _lib.check(L.mnrf_field_backward2(
                     p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
                     p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz),
-                    _lib.MNRF_SPLIT_F16 if _mn.PRECISION.startswith("split") else 0, _lib.stream()), "mnrf_field_backward2")
+                    _lib.MNRF_SPLIT_F16 if ctx.split else 0, _lib.stream()), "mnrf_field_backward2")
         else:
             for t in d_params:
                 t.zero_()

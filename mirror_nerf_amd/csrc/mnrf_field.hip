@@ -140,6 +140,7 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     build_parts(T);
     const int threads = 256;
     const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
+    (void)hipMemsetAsync(packed + PACKED_FLOATS - 1, 0, sizeof(float), (hipStream_t)stream);   // range-guard word (mnrf.h)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
     launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
     return mnrf_check_launch("mnrf_pack_weights");

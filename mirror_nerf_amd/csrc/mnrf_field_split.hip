@@ -110,6 +110,7 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     }
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)(w - (float)hi);
+    if (!(fabsf(w) < 65504.f)) atomicOr((unsigned*)(packed + PACKED_FLOATS - 1), MNRF_GUARD_WEIGHT);   // inf / nan / out of range
     _Float16* dst = (_Float16*)(packed + (region == 2 ? OFF_SPLIT_HBWD : (region == 1 ? OFF_SPLIT_BWD : OFF_SPLIT_FWD)));
     dst[r] = is_lo ? lo : hi;
 }

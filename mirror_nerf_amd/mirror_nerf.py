@@ -53,6 +53,65 @@ def set_precision(mode):
     PRECISION = mode
 
 
+# ---- range guard of the split arithmetic (include/mnrf.h MNRF_GUARD_*, csrc/mnrf_field_split.inc "range guard")
+# The split kernels raise a sticky flag in the last word of the module's packed weight image when an operand of a Linear
+# reaches the f16 maximum (65504: the hi/lo pair stops carrying fp32 there), a weight is out of range, or a position has
+# |x| >= 16 (sin/cos arguments beyond the fast exact reduction).  The flag costs the kernels one VALU per converted pair;
+# the HOST reads it at the natural sync points -- the end of a frame (batched_inference), of a training forward
+# (NeRFSystem.forward), of a training step (training.train_step), of a stand-alone render_rays / MirrorNeRF.forward call
+# -- and when it is set the module is switched to the exact fp32 kernels for good and the work is repeated, so a result
+# computed outside the range of the fast arithmetic is never returned.  MNRF_GUARD=0 disables the host side.
+GUARD = os.environ.get("MNRF_GUARD", "1") != "0"
+GUARD_NAMES = {1: "an activation reached the f16 maximum (65504)", 2: "a weight is non-finite or >= 65504",
+               4: "a sample position has |x| >= 16 (encoding argument >= 2^13)"}
+
+
+def precision_of(module):
+    """The arithmetic `module` is evaluated in: the global PRECISION unless the range guard pinned it to fp32."""
+    return module.__dict__.get("_mnrf_precision") or PRECISION
+
+
+def reset_guard(module):
+    """Undo the guard's switch to fp32 (e.g. after loading other weights into the same module)."""
+    module.__dict__.pop("_mnrf_precision", None)
+
+
+def guard_words(modules):
+    """The guard words of `modules` (0 = clean) with ONE device->host read."""
+    packs = [m.__dict__["_mnrf_packed"].packed for m in modules
+             if m.__dict__.get("_mnrf_packed") is not None and m.__dict__["_mnrf_packed"].packed is not None]
+    if not packs:
+        return [0] * len(list(modules))
+    words = torch.cat([p[-1:] for p in packs]).view(torch.int32).tolist()
+    it = iter(words)
+    return [next(it) if (m.__dict__.get("_mnrf_packed") is not None and m.__dict__["_mnrf_packed"].packed is not None) else 0
+            for m in modules]
+
+
+def check_guard(modules):
+    """Read the range-guard flags of `modules` (an iterable of MirrorNeRF modules, or one NeRFSystem-like object with a
+    `.models` dict).  Returns True when a module running the split arithmetic tripped: it has then been switched to the
+    fp32 kernels (sticky, see reset_guard) and the caller must repeat the work whose results it was about to use.
+    Custom training loops call it after `loss.backward()`; the drivers of this package call it themselves."""
+    if not GUARD or not PRECISION.startswith("split"):
+        return False
+    if hasattr(modules, "models"):
+        modules = list(modules.models.values())
+    modules = [m for m in dict.fromkeys(modules) if isinstance(m, MirrorNeRF) and precision_of(m).startswith("split")]
+    if not modules:
+        return False
+    tripped = False
+    for m, w in zip(modules, guard_words(modules)):
+        if w:
+            import warnings
+            why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
+            warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range ({why}); this model is evaluated with "
+                          "the exact fp32 kernels from now on and the affected work is repeated", RuntimeWarning, stacklevel=2)
+            m.__dict__["_mnrf_precision"] = "fp32"
+            tripped = True
+    return tripped
+
+
 def verify_split(module, n=8192, bound=4.0, seed=0):
     """Evaluate `module` on n random positions of [-bound, bound]^3 with both arithmetics and return the largest
     difference of each output relative to max(1, |fp32 output|).  ~3e-6 is normal; a large value means some activation
@@ -64,13 +123,15 @@ def verify_split(module, n=8192, bound=4.0, seed=0):
     x = (torch.rand(n, 3, device=dev, generator=g) * 2 - 1) * bound
     d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=1)
     de = Embedding(4)(d)
-    old, out = PRECISION, {}
+    old, old_pin, out = PRECISION, module.__dict__.pop("_mnrf_precision", None), {}
     try:
         for mode in ("fp32", "split"):
             PRECISION = mode
             out[mode] = field_forward(module, n, xyz=x.contiguous(), xyz_stride=3, spr=1, dir_emb=de, dir_stride=27)
     finally:
         PRECISION = old
+        if old_pin is not None:
+            module.__dict__["_mnrf_precision"] = old_pin
     return {k: float((out["fp32"][k] - out["split"][k]).abs().max() / max(1.0, float(out["fp32"][k].abs().max())))
             for k in out["fp32"]}
 
@@ -92,24 +153,26 @@ def field_forward(module, B, *, xyz=None, xyz_stride=3, rays=None, z_vals=None, 
     dev = packed.device
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     out = {"sigma": f(B)}
-    has_normal_head = True
-    if has_normal_head and not sigma_only:
+    # optional heads (mirror_nerf.py:80-99): an absent head is packed as zeros and its output is simply not requested
+    if getattr(module, "predict_normal", True) and not sigma_only:
         out["pred_normal"] = f(B, 3)
     if not sigma_only:
         out["rgb"] = f(B, 3)
-        out["is_mirror"] = f(B)
+        if getattr(module, "predict_mirror_mask", True):
+            out["is_mirror"] = f(B)
     if grad_normal:
         out["normal"] = f(B, 3)
     if want_geo:
         out["geo_feat"] = f(B, 256)
     flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
-    if PRECISION == "split":
+    prec = precision_of(module)
+    if prec == "split":
         flags |= _lib.MNRF_SPLIT_F16
-    elif PRECISION == "split_h2":    # experiments only: force 16 KiB chunks
+    elif prec == "split_h2":    # experiments only: force 16 KiB chunks
         flags |= _lib.MNRF_SPLIT_F16 | 8
-    elif PRECISION == "split_h2x":   # experiments only: force 32 KiB chunks
+    elif prec == "split_h2x":   # experiments only: force 32 KiB chunks
         flags |= _lib.MNRF_SPLIT_F16 | 16
-    elif PRECISION == "split_h1":    # experiments only (library built with -DMNRF_EXP_H1)
+    elif prec == "split_h1":    # experiments only (library built with -DMNRF_EXP_H1)
         flags |= _lib.MNRF_SPLIT_F16 | 24
     p = _lib.ptr
     if LAUNCH_LOG is not None:
@@ -155,11 +218,10 @@ class MirrorNeRF(nn.Module):
             self.hidden_dim_is_mirror = W // 2
             self.is_mirror_net = nn.Sequential(nn.Linear(W, W // 2), nn.LeakyReLU(inplace=True),
                                                nn.Linear(W // 2, 1), nn.Sigmoid())
-        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]) or not (
-                self.predict_normal and self.predict_mirror_mask):
+        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]):
             raise NotImplementedError(
-                "the HIP field kernel covers the reference default: D=8, W=256, 63/27 input channels, "
-                "skips=[4], predict_normal=True, predict_mirror_mask=True")
+                "the HIP field kernel covers the reference's trunk: D=8, W=256, 63/27 input channels, skips=[4] "
+                "(with or without the normal / mirror-mask heads)")
 
     def forward(self, x, compute_normal=True, sigma_only=False, embedding_xyz=None, embedding_dir=None,
                 mirror_mask=None, detach_density_outside_mirror_for_mask_loss=False,
@@ -179,6 +241,8 @@ class MirrorNeRF(nn.Module):
         o = field_forward(self, B, xyz=x, xyz_stride=ld, spr=1,
                           dir_emb=None if sigma_only else x.view(-1)[3:], dir_stride=ld,
                           sigma_only=sigma_only, grad_normal=compute_normal, want_geo=True) if B else None
+        if B and check_guard([self]):      # range guard: the module is on the fp32 kernels now, evaluate again
+            return self.forward(x, compute_normal, sigma_only, embedding_xyz, embedding_dir)
         out = {}
         dev = x.device
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -188,14 +252,17 @@ class MirrorNeRF(nn.Module):
         out["geo_feat"] = o["geo_feat"] if B else z(0, 256)
         if sigma_only:
             # the reference evaluates normal_net here as well (mirror_nerf.py:154-161)
-            if B:
-                xx = torch.cat([x, torch.zeros(B, self.in_channels_dir, device=dev)], 1).contiguous()
-                o2 = field_forward(self, B, xyz=xx, xyz_stride=30, spr=1, dir_emb=xx.view(-1)[3:], dir_stride=30)
-                out["pred_normal"] = o2["pred_normal"]
-            else:
-                out["pred_normal"] = z(0, 3)
+            if self.predict_normal:
+                if B:
+                    xx = torch.cat([x, torch.zeros(B, self.in_channels_dir, device=dev)], 1).contiguous()
+                    o2 = field_forward(self, B, xyz=xx, xyz_stride=30, spr=1, dir_emb=xx.view(-1)[3:], dir_stride=30)
+                    out["pred_normal"] = o2["pred_normal"]
+                else:
+                    out["pred_normal"] = z(0, 3)
         else:
-            out["pred_normal"] = o["pred_normal"] if B else z(0, 3)
+            if self.predict_normal:
+                out["pred_normal"] = o["pred_normal"] if B else z(0, 3)
             out["rgb"] = o["rgb"] if B else z(0, 3)
-            out["is_mirror"] = o["is_mirror"].view(B, 1) if B else z(0, 1)
+            if self.predict_mirror_mask:
+                out["is_mirror"] = o["is_mirror"].view(B, 1) if B else z(0, 1)
         return out

@@ -161,7 +161,8 @@ class MirrorNeRFTcnn(nn.Module):
     # ---- weight blob of the small MLPs in the order include/mnrf.h documents
     def _weights(self):
         ps = self.mlp_params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        from .weights import _GENERATION      # fused optimizers do not bump _version (weights.py)
+        key = (_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in ps)
         if key != self._blob_key:
             def pad(w, cols):
                 w = w.detach().float()

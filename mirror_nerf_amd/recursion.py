@@ -22,6 +22,7 @@ from .mirror_nerf import Embedding, MirrorNeRF
 from .rendering import render_rays
 
 RAY_FORWARD_OFFSET = 0.1   # train.py:232, eval.py:529 (absolute near of a reflected ray)
+JITTER_RAYS = 262144       # rays per batched group of jittered reflections (roughness, eval.py:622-674)
 
 
 def _f(dev, *s):
@@ -106,7 +107,7 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     """train.py:129-348."""
     r = render_rays(models, embeddings, rays_chunk, hp.N_samples, hp.use_disp, hp.perturb, hp.noise_std,
                     hp.N_importance, hp.chunk, white_back, compute_normal=hp.trace_secondary_rays,
-                    **extra_chunk)
+                    **dict(extra_chunk, _guard=False))        # the range guard is read once, in NeRFSystem.forward
     N = rays_chunk.shape[0]
     dev = rays_chunk.device
     sel = "fine" if (hp.N_importance > 0 and not hp.only_one_field) else "coarse"
@@ -217,10 +218,18 @@ class NeRFSystem(nn.Module):
             self.models["fine"] = self.nerf_fine
 
     def forward(self, rays, extra=dict()):
+        out = self._forward(rays, extra)
+        from .mirror_nerf import check_guard
+        # (training.train_step passes _guard=False: it reads the sticky flag once, after the backward, for both passes)
+        if rays.shape[0] and extra.get("_guard", True) and check_guard(self):   # out of range: the models are on fp32 now
+            out = self._forward(rays, extra)
+        return out
+
+    def _forward(self, rays, extra):
         hp = self.hparams
         results = defaultdict(list)
         for i in range(0, rays.shape[0], hp.chunk):
-            ex = {k: (v[i:i + hp.chunk] if isinstance(v, torch.Tensor) else v) for k, v in extra.items()}
+            ex = {k: (v[i:i + hp.chunk] if isinstance(v, torch.Tensor) else v) for k, v in extra.items() if k != "_guard"}
             rc = rays[i:i + hp.chunk].contiguous()
             first = torch.ones(rc.shape[0], dtype=torch.bool, device=rc.device)
             out = render_rays_chunk_recursively(self.models, self.embeddings, hp, rc, first, 0, ex,
@@ -239,7 +248,8 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     global `dataset.white_back`), to_cpu (True, the default: eval.py:735-736 moves every value to the CPU; False: keep
     everything on the device; "maps": return only the per-ray maps -- rgb, depth, opacity, mirror mask, normals,
     x_surface, ~100 B/ray instead of ~3 KB/ray of per-sample tensors nobody downstream of eval.py:743-894 reads -- on
-    the CPU),
+    the CPU), batch_jitter (roughness: render the trace_ray_times jittered reflections of a level in groups through one
+    recursion call each instead of one by one; default on unless draws are injected),
     _normal_noise (iterator of pre-drawn (n,3) standard-normal tensors, for tests)."""
     args = kwargs.get("args")
     if isinstance(args, dict):
@@ -254,6 +264,7 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     noise_iter = kwargs.get("_normal_noise")
     to_cpu = kwargs.get("to_cpu", True)
     rough = getattr(args, "app_control_mirror_roughness", False)
+    batch_jitter = kwargs.get("batch_jitter", noise_iter is None)   # see the roughness branch of recurse()
     one_field = getattr(args, "only_one_field", False)
     fine_epoch = getattr(args, "only_one_field_fine_epoch", 2)
     sel = "fine" if (N_importance > 0 and not one_field) else "coarse"
@@ -268,7 +279,7 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
                         white_back, test_time=test_time,
                         compute_normal=trace_flag and (not args.predict_normal),
                         only_one_field=one_field, only_one_field_fine_epoch=fine_epoch,
-                        current_epoch=fine_epoch + 1)
+                        current_epoch=fine_epoch + 1, _guard=False)
         N = rays_chunk.shape[0]
         dev = rays_chunk.device
         only_in = not (level < 1)                                         # eval.py:159
@@ -298,15 +309,34 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
             r2 = recurse(sec.contiguous(), level + 1)
             if rough:                                                     # eval.py:622-674
                 times = args.trace_ray_times
-                for _ in range(times):
-                    s2, _, _ = _reflect(rays_chunk, r[f"x_surface_{sel}"], normal, mask, True, draw(N, dev),
-                                        noise_std, want_dir=False)
-                    r3 = recurse(s2.contiguous(), level + 1)
-                    for typ in ("coarse", "fine"):
-                        if f"rgb_{typ}" in r2:
-                            # the reference adds tensors of M = sum(mask) rows to the first secondary
-                            # render; at level 0 that only works when every ray is a mirror
-                            r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] + r3[f"rgb_{typ}"]
+                if batch_jitter and times > 0:
+                    # The reference renders the `times` jittered reflections one after the other (run.sh:187: 64 of them,
+                    # each a full secondary render).  Rays are independent, so groups of them go through ONE recursion
+                    # call (one field launch per pass for the whole group) and the colours are added in the reference's
+                    # order.  Groups are sized to JITTER_RAYS rays (~2.5 GB of per-sample tensors at 64+128 samples).
+                    # Not used when a test injects the draws: their order interleaves with the nested levels' draws.
+                    mj = max(1, r2[f"rgb_{sel}"].shape[0])     # rows the additions below need (eval.py:663-666)
+                    g = 0
+                    while g < times:
+                        n_g = max(1, min(times - g, JITTER_RAYS // mj))
+                        secs = [_reflect(rays_chunk, r[f"x_surface_{sel}"], normal, mask, True, draw(N, dev), noise_std,
+                                         want_dir=False)[0] for _ in range(n_g)]
+                        r3 = recurse(torch.cat(secs, 0).contiguous(), level + 1)
+                        for typ in ("coarse", "fine"):
+                            if f"rgb_{typ}" in r2:
+                                for piece in r3[f"rgb_{typ}"].view(n_g, -1, 3).unbind(0):
+                                    r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] + piece      # same order of additions as eval.py:663-666
+                        g += n_g
+                else:
+                    for _ in range(times):
+                        s2, _, _ = _reflect(rays_chunk, r[f"x_surface_{sel}"], normal, mask, True, draw(N, dev),
+                                            noise_std, want_dir=False)
+                        r3 = recurse(s2.contiguous(), level + 1)
+                        for typ in ("coarse", "fine"):
+                            if f"rgb_{typ}" in r2:
+                                # the reference adds tensors of M = sum(mask) rows to the first secondary
+                                # render; at level 0 that only works when every ray is a mirror
+                                r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] + r3[f"rgb_{typ}"]
                 for typ in ("coarse", "fine"):
                     if f"rgb_{typ}" in r2:
                         r2[f"rgb_{typ}"] = r2[f"rgb_{typ}"] / (times + 1)
@@ -331,4 +361,9 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
                 results[k] += [v.cpu() if to_cpu else v]
     if to_cpu == "maps" and rays.is_cuda:
         torch.cuda.current_stream().synchronize()
+    # range guard of the split arithmetic, once per call (= per frame): a tripped model is on the fp32 kernels now
+    from .mirror_nerf import check_guard
+    if rays.shape[0] and not kwargs.get("_guard_retry") and check_guard([m for m in models.values()]):
+        return batched_inference(models, embeddings, rays, N_samples, N_importance, use_disp, chunk,
+                                 **dict(kwargs, _guard_retry=True))
     return {k: torch.cat(v, 0) for k, v in results.items()}

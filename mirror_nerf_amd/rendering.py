@@ -155,7 +155,11 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         else:
             o = {"sigma": f(0)}
             if not sigma_only:
-                o.update(rgb=f(0, 3), pred_normal=f(0, 3), is_mirror=f(0))
+                o["rgb"] = f(0, 3)
+                if getattr(model, "predict_normal", True):
+                    o["pred_normal"] = f(0, 3)
+                if getattr(model, "predict_mirror_mask", True):
+                    o["is_mirror"] = f(0)
                 if compute_normal:
                     o["normal"] = f(0, 3)
         noise = kwargs.get(noise_key)
@@ -165,12 +169,13 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             noise = torch.randn(N, S, device=dev) * noise_std            # rendering.py:189
         weights, opacity = f(N, S), f(N)
         full = not sigma_only
+        has_m, has_n = full and "is_mirror" in o, full and "pred_normal" in o     # optional heads (mirror_nerf.py:80-99)
         rgb_map = f(N, 3) if full else None
         depth = f(N) if full else None
-        mask = f(N) if full else None
-        sn = f(N, 3) if full else None
+        mask = f(N) if has_m else None
+        sn = f(N, 3) if has_n else None
         sng = f(N, 3) if (full and compute_normal) else None
-        nd = f(N) if (full and compute_normal) else None
+        nd = f(N) if (has_n and compute_normal) else None
         xs = f(N, 3) if full else None
         if N:
             _lib.check(L.mnrf_composite(
@@ -185,13 +190,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             return                                                        # rendering.py:208-209
         results[f"rgb_{typ}"] = rgb_map
         results[f"depth_{typ}"] = depth
-        results[f"mirror_mask_{typ}"] = mask
+        if has_m:
+            results[f"mirror_mask_{typ}"] = mask
         if compute_normal:
             results[f"normal_{typ}"] = o["normal"].view(N, S, 3)
             results[f"surface_normal_grad_{typ}"] = sng
-        results[f"pred_normal_{typ}"] = o["pred_normal"].view(N, S, 3)
-        results[f"surface_normal_{typ}"] = sn
-        if compute_normal:
+        if has_n:
+            results[f"pred_normal_{typ}"] = o["pred_normal"].view(N, S, 3)
+            results[f"surface_normal_{typ}"] = sn
+        if compute_normal and has_n:
             results[f"normal_dif_{typ}"] = nd
         results[f"_x_surface_{typ}"] = xs
 
@@ -213,6 +220,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         elif noise_std != 0:
             noise = torch.randn(N, S, device=dev) * noise_std
         nrm = normal if compute_normal else None
+        if not getattr(model, "predict_mirror_mask", True):     # optional heads: evaluated on zero weights, never read
+            mir = None
+        if not getattr(model, "predict_normal", True):
+            pn = None
         weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
             rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror)
         results[f"weights_{typ}"] = weights
@@ -220,13 +231,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         results[f"z_vals_{typ}"] = z
         results[f"rgb_{typ}"] = rgb_map
         results[f"depth_{typ}"] = depth
-        results[f"mirror_mask_{typ}"] = mask
+        if mir is not None:
+            results[f"mirror_mask_{typ}"] = mask
         if compute_normal:
             results[f"normal_{typ}"] = normal.view(N, S, 3)
             results[f"surface_normal_grad_{typ}"] = sng
-        results[f"pred_normal_{typ}"] = pn.view(N, S, 3)
-        results[f"surface_normal_{typ}"] = sn
-        if compute_normal:
+        if pn is not None:
+            results[f"pred_normal_{typ}"] = pn.view(N, S, 3)
+            results[f"surface_normal_{typ}"] = sn
+        if compute_normal and pn is not None:
             results[f"normal_dif_{typ}"] = nd
         results[f"_x_surface_{typ}"] = xs
 
@@ -250,4 +263,11 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         xs = results.pop(f"_x_surface_{typ}", None)
         if f"depth_{typ}" in results:
             results[f"x_surface_{typ}"] = xs
+    # range guard of the split arithmetic (mirror_nerf.check_guard): a stand-alone call checks its own launches (one
+    # 8-byte device->host read); the recursion drivers pass _guard=False and check once per frame / training forward
+    if kwargs.get("_guard", True) and N and not hashgrid:
+        from .mirror_nerf import check_guard
+        if check_guard(list(models.values())):
+            return render_rays(models, embeddings, rays, N_samples, use_disp, perturb, noise_std, N_importance, chunk,
+                               white_back, test_time, **kwargs)
     return results

@@ -51,10 +51,13 @@ def make_state_dict(seed, n_models=1, W=256, D=8, in_xyz=63, in_dir=27, skips=(4
 
 
 def apply_tweaks(sd, tweaks):
-    """tweaks: list of [name, op, value], op in {"mul", "set", "add"} -- in place."""
+    """tweaks: list of [name, op, value], op in {"mul", "set", "add", "mul_cols"} -- in place.
+    "mul_cols": value = [first column, end column, factor] (a band of input channels of a weight matrix)."""
     for name, op, val in tweaks:
         a = sd[name]
-        if op == "mul":
+        if op == "mul_cols":
+            a[:, int(val[0]):int(val[1])] *= np.float32(val[2])
+        elif op == "mul":
             a *= np.float32(val)
         elif op == "set":
             a[...] = np.float32(val)
@@ -82,6 +85,11 @@ STRADDLE = [["is_mirror_net.2.weight", "mul", 200.0], ["is_mirror_net.2.bias", "
             ["sigma.bias", "set", 5.0], ["sigma.weight", "mul", 20.0]]
 # every ray is a mirror (fixture G8)
 ALL_MIRROR = OPAQUE + [["is_mirror_net.2.bias", "set", 10.0]]
+# a rough spectrum on top of trained weights (fixtures G11 "rough"): the 2^7..2^9 encoding bands (input columns 45..62
+# of the two layers that read the encoding; in layer 5 the encoding comes first, models/mirror_nerf.py:192-193) carry
+# 6x their trained weight and the density head 25x -- sigma of ~1e3 at surfaces, the worst case SURVEY 8a names
+ROUGH = [["xyz_encoding_1.0.weight", "mul_cols", [45, 63, 6.0]], ["xyz_encoding_5.0.weight", "mul_cols", [45, 63, 6.0]],
+         ["sigma.weight", "mul", 25.0], ["sigma.bias", "mul", 25.0]]
 
 
 # ----------------------------------------------------------------------------- synthetic camera

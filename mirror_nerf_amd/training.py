@@ -56,10 +56,13 @@ def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
 
 
 def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
-    res = system(rays, extra_info(system.hparams, gt_mask, epoch))
+    res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
     loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    from .mirror_nerf import check_guard
+    if check_guard(system):     # a scaled gradient left the f16 range in the backward: repeat the step on the fp32 kernels
+        return train_step(system, optimizer, rays, target, gt_mask, loss_fn, epoch)
     D.allreduce_gradients(params_of(system))                  # RCCL over xGMI when world_size > 1
     optimizer.step()
     return loss

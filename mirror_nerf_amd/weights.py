@@ -37,19 +37,33 @@ PARAM_SHAPES.update({
 })
 
 
+OPTIONAL_HEADS = ("normal_net.", "is_mirror_net.")     # predict_normal / predict_mirror_mask (mirror_nerf.py:80-99)
+_ZEROS = {}
+
+
+def _zeros(name, dev):
+    """Stand-in weights of an absent optional head: the kernel evaluates the head on zeros, nobody reads its output."""
+    t = _ZEROS.get((name, str(dev)))
+    if t is None:
+        t = torch.zeros(PARAM_SHAPES[name], dtype=torch.float32, device=dev)
+        _ZEROS[(name, str(dev))] = t
+    return t
+
+
 def pack_state(tensors, out=None):
-    """tensors: dict name -> fp32 CUDA tensor.  Returns the packed image (1-D fp32 CUDA tensor)."""
+    """tensors: dict name -> fp32 CUDA tensor.  Returns the packed image (1-D fp32 CUDA tensor).
+    The parameters of an absent optional head (predict_normal=False / predict_mirror_mask=False) are packed as zeros."""
     L = _lib.lib()
-    missing = [n for n in PARAM_NAMES if n not in tensors]
+    missing = [n for n in PARAM_NAMES if n not in tensors and not n.startswith(OPTIONAL_HEADS)]
     if missing:
         raise RuntimeError(
-            "the HIP field kernel implements the reference default architecture with normal and "
-            f"mirror heads (train.py:44-66); missing parameters: {missing}")
+            "the HIP field kernel implements the reference's D=8, W=256 trunk with the colour head "
+            f"(train.py:44-66); missing parameters: {missing}")
     keep = []
     arr = (ctypes.c_void_p * _lib.N_PARAMS)()
-    dev = None
+    dev = next(iter(tensors.values())).device
     for i, n in enumerate(PARAM_NAMES):
-        t = tensors[n].detach()
+        t = tensors[n].detach() if n in tensors else _zeros(n, dev)
         if tuple(t.shape) != PARAM_SHAPES[n]:
             raise RuntimeError(f"{n}: shape {tuple(t.shape)} != {PARAM_SHAPES[n]} (D=8, W=256, N_emb 10/4 only)")
         if t.dtype != torch.float32 or not t.is_cuda:
@@ -81,12 +95,32 @@ def params_of(module):
     return [sub._parameters[pname] for sub, pname, _ in param_refs(module)]
 
 
+# Optimizer steps must invalidate every packed image.  `Tensor._version` is NOT enough: torch's fused Adam/AdamW/SGD
+# (`fused=True`, one multi-tensor kernel) update the parameters without bumping it (measured on torch 2.10: the version of
+# every parameter stays where it was, the packed image went stale and training stood still while the loss only jittered
+# with the batches).  A global post-step hook on every torch optimizer bumps a generation number that is part of the
+# cache key; inference never steps an optimizer, so nothing is re-packed there.
+_GENERATION = [0]
+
+
+def bump_generation(*_a, **_k):
+    _GENERATION[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(bump_generation)
+except ImportError:      # very old torch: fall back to re-packing whenever a parameter requires grad
+    _reg_hook = None
+
+
 class PackedCache:
     """Packed image of one nn.Module (ours or the reference's), refreshed when parameters change.
 
-    "Changed" = a parameter was re-assigned, moved, or written through an autograd-visible in-place op (optimizer steps,
-    `load_state_dict`, `p.mul_()` under no_grad ...): those bump `Tensor._version`.  Writes through `p.data` (some EMA /
-    clamping code does that) do NOT -- call `invalidate_packed(module)` after such surgery."""
+    "Changed" = a parameter was re-assigned, moved, written through an autograd-visible in-place op (`load_state_dict`,
+    `p.mul_()` under no_grad ...: those bump `Tensor._version`), or ANY torch optimizer took a step (global post-step hook,
+    see _GENERATION).  Writes through `p.data` outside an optimizer (some EMA / clamping code does that) are invisible to
+    both -- call `invalidate_packed(module)` after such surgery."""
 
     def __init__(self):
         self.key = None
@@ -94,7 +128,9 @@ class PackedCache:
 
     def get(self, module):
         sd = {full: sub._parameters[pname] for sub, pname, full in param_refs(module)}
-        key = tuple((sd[n].data_ptr(), sd[n]._version) for n in PARAM_NAMES if n in sd)
+        key = (_GENERATION[0],) + tuple((sd[n].data_ptr(), sd[n]._version) for n in PARAM_NAMES if n in sd)
+        if _reg_hook is None and any(q.requires_grad for q in sd.values()):
+            self.key = None
         if key != self.key or self.packed is None:
             self.packed = pack_state(sd, self.packed)
             self.key = key

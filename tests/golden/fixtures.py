@@ -24,7 +24,11 @@ class Fixture:
     def state_dicts(self):
         """Rebuild the weights from (seed, tweaks) and verify the stored checksum."""
         n = self.meta.get("n_models", 1)
-        sds = W.make_state_dict(self.meta["seed"], n)
+        if self.meta.get("weights_file"):      # trained weights (fixtures G11): stored once, shared by the fixtures
+            z = np.load(os.path.join(HERE, self.meta["weights_file"]))
+            sds = [{k[len(m) + 2:]: z[k].copy() for k in z.files if k.startswith(m + "__")} for m in ("coarse", "fine")[:n]]
+        else:
+            sds = W.make_state_dict(self.meta["seed"], n)
         want = self.meta["checksum"]
         want = want if isinstance(want, list) else [want]
         for sd, c in zip(sds, want):

@@ -365,3 +365,27 @@ def test_split_training_path_agrees_with_fp32_path(precision):
     worst = max(_rel(a, b) for a, b in zip(res["split"], res["fp32"]))
     print("split vs fp32 training path: worst relative gradient difference", worst)
     assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_optimizer_steps_are_seen_by_the_next_launch(fused):
+    """The kernels read a packed image of the weights, cached per module.  torch's FUSED optimizers update parameters
+    without bumping Tensor._version (the cache key of round 1): the image went stale and training stood still.  Now any
+    optimizer step invalidates the images (weights._GENERATION): the loss of a repeated batch must fall, and the image
+    must follow the parameters, with either Adam implementation."""
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import synthetic as SY, training
+    torch.manual_seed(0)
+    system = M.NeRFSystem(training.default_hparams(N_importance=64, perturb=0.0, noise_std=0.0)).to(DEV)
+    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=fused)
+    rays = SY.device_rays(32, 32, DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    tgt, gt = torch.rand(1024, 3, device=DEV, generator=g), (torch.rand(1024, device=DEV, generator=g) < 0.25).float()
+    loss_fn = training.total_loss_fn(SimpleNamespace(), epoch=5)
+    losses, images = [], []
+    for _ in range(12):
+        losses.append(float(training.train_step(system, opt, rays, tgt, gt, loss_fn, epoch=5)))
+        images.append(system.nerf_fine.__dict__["_mnrf_packed"].packed[:4096].clone())
+    assert min(losses[6:]) < losses[0] - 5e-3, losses
+    assert all(not torch.equal(images[i], images[i + 1]) for i in range(1, 11)), "the packed image does not follow the optimizer"

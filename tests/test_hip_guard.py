@@ -1,0 +1,196 @@
+"""GPU tests of the range guard of the split-f16 arithmetic (include/mnrf.h MNRF_GUARD_*, mirror_nerf.check_guard):
+the kernels raise a sticky device flag when an operand leaves the range the hi/lo f16 pairs carry at fp32 accuracy, the
+drivers read it at their sync points, pin the model to the exact fp32 kernels and repeat the work -- a result computed out
+of range is never returned."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ARGS = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
+
+
+@pytest.fixture(autouse=True)
+def split_precision():
+    from mirror_nerf_amd import mirror_nerf as MN
+    old = MN.PRECISION
+    MN.set_precision("split")
+    yield
+    MN.set_precision(old)
+
+
+def _models(tweaks):
+    from mirror_nerf_amd import synthetic as SY
+    models, _ = SY.build_models(DEV, tweaks, seed=0)
+    return models
+
+
+def _emb():
+    import mirror_nerf_amd as M
+    return {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
+
+
+def _rays(n=96):
+    from mirror_nerf_amd import synthetic as SY
+    return SY.device_rays(40, 40, DEV)[::13][:n].contiguous()
+
+
+def _words(models):
+    from mirror_nerf_amd import mirror_nerf as MN
+    return MN.guard_words(list(models.values()))
+
+
+def _fp32_render(tweaks, rays, **kw):
+    """The same render on a fresh pair pinned to the exact kernels."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    models = _models(tweaks)
+    MN.set_precision("fp32")
+    try:
+        return M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False, **kw)
+    finally:
+        MN.set_precision("split")
+
+
+def test_random_init_stays_clean():
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    models = _models(SY.OPAQUE)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        M.render_rays(models, _emb(), _rays(), 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+        M.batched_inference(models, _emb(), _rays(), 64, 64, False, 32768, args=ARGS, trace_secondary_rays=True, to_cpu=False)
+    assert _words(models) == [0, 0]
+    assert all(MN.precision_of(m) == "split" for m in models.values())
+
+
+@pytest.mark.parametrize("level,trips", [(60000.0, False), (70000.0, True)])
+def test_saturation_threshold_is_the_f16_maximum(level, trips):
+    """A constant first-layer output of `level`: 60 000 is carried exactly by the hi/lo pair, 70 000 saturates hi."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    m = _models([])["coarse"]
+    with torch.no_grad():
+        m.xyz_encoding_1[0].weight.zero_()
+        m.xyz_encoding_1[0].bias.fill_(level)
+        m.xyz_encoding_2[0].weight.mul_(1e-6)     # keep what follows small
+    x = torch.rand(300, 3, device=DEV)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = m(x, compute_normal=False, sigma_only=True, embedding_xyz=M.Embedding(10))
+    assert (MN.precision_of(m) == "fp32") == trips
+    assert bool(rec) == trips
+    if trips:
+        assert "f16 maximum" in str(rec[0].message)
+        # what was returned is the fp32 evaluation
+        MN.set_precision("fp32")
+        m2 = _models([])["coarse"]
+        m2.load_state_dict(m.state_dict())
+        want = m2.to(DEV)(x, compute_normal=False, sigma_only=True, embedding_xyz=M.Embedding(10))
+        assert torch.equal(out["sigma"], want["sigma"])
+
+
+def test_render_rays_falls_back_and_returns_the_fp32_result():
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    tweaks = SY.OPAQUE + [["xyz_encoding_3.0.weight", "mul", 1e7]]       # activations of ~1e6 from layer 3 on
+    models = _models(tweaks)
+    rays = _rays()
+    with pytest.warns(RuntimeWarning, match="split-f16 arithmetic left its range"):
+        got = M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    assert all(MN.precision_of(m) == "fp32" for m in models.values())
+    want = _fp32_render(tweaks, rays)
+    for k in ("rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine", "weights_coarse"):
+        assert torch.equal(got[k], want[k]), k
+    # sticky: later calls run on the exact kernels without another warning; reset_guard undoes the pin
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    MN.reset_guard(models["coarse"])
+    assert MN.precision_of(models["coarse"]) == "split"
+
+
+def test_positions_beyond_the_fast_sincos_range_fall_back():
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    models = _models(SY.OPAQUE)
+    rays = _rays(64).clone()
+    rays[:, 0] += 30.0                   # origins at x ~ 30: 2^9 * x > 2^13
+    with pytest.warns(RuntimeWarning, match=r"\|x\| >= 16"):
+        got = M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    assert _words(models)[0] & 4
+    want = _fp32_render(SY.OPAQUE, rays)
+    for k in ("rgb_fine", "depth_fine", "opacity_fine"):
+        assert torch.equal(got[k], want[k]), k
+    assert MN.precision_of(models["fine"]) == "fp32"
+
+
+def test_non_finite_weight_is_flagged_at_pack_time():
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    m = _models([])["coarse"]
+    with torch.no_grad():
+        m.xyz_encoding_4[0].weight[3, 5] = 1e6
+    x = torch.rand(64, 3, device=DEV)
+    with pytest.warns(RuntimeWarning, match="weight"):
+        m(x, compute_normal=False, sigma_only=True, embedding_xyz=M.Embedding(10))
+    assert MN.precision_of(m) == "fp32"
+
+
+def test_frame_driver_and_training_step_fall_back():
+    """batched_inference reads the flag once per frame; training.train_step once per step (after the backward)."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    from mirror_nerf_amd import training
+    tweaks = SY.ALL_MIRROR + [["xyz_encoding_6.0.weight", "mul", 1e8]]
+    models = _models(tweaks)
+    rays = _rays()
+    with pytest.warns(RuntimeWarning):
+        got = M.batched_inference(models, _emb(), rays, 64, 64, False, 32768, args=ARGS, trace_secondary_rays=True, to_cpu=False)
+    assert all(MN.precision_of(m) == "fp32" for m in models.values())
+    MN.set_precision("fp32")
+    want = M.batched_inference(_models(tweaks), _emb(), rays, 64, 64, False, 32768, args=ARGS, trace_secondary_rays=True, to_cpu=False)
+    MN.set_precision("split")
+    for k in ("rgb_fine", "depth_fine", "mirror_mask_fine"):
+        assert torch.equal(got[k], want[k]), k
+
+    # training: the same step on a pinned-fp32 twin gives the same loss and gradients
+    def system():
+        torch.manual_seed(0)
+        s = M.NeRFSystem(training.default_hparams()).to(DEV)
+        with torch.no_grad():
+            s.nerf_fine.xyz_encoding_2[0].weight.mul_(1e7)
+        return s
+    batch = (rays, torch.rand(rays.shape[0], 3, device=DEV), (torch.rand(rays.shape[0], device=DEV) < 0.3).float())
+    s1, s2 = system(), system()
+    hp = dict(perturb=0.0, noise_std=0.0)
+    for s in (s1, s2):
+        for k, v in hp.items():
+            setattr(s.hparams, k, v)
+    o1 = torch.optim.SGD(s1.parameters(), lr=0.0)
+    with pytest.warns(RuntimeWarning):
+        l1 = training.train_step(s1, o1, *batch)
+    assert MN.precision_of(s1.nerf_fine) == "fp32" and MN.precision_of(s1.nerf_coarse) == "split"   # only the model that tripped
+    s2.nerf_fine.__dict__["_mnrf_precision"] = "fp32"
+    l2 = training.train_step(s2, torch.optim.SGD(s2.parameters(), lr=0.0), *batch)
+    assert float(l1) == float(l2)
+    for (n, p), q in zip(s1.named_parameters(), s2.parameters()):
+        assert (p.grad is None) == (q.grad is None)
+        if p.grad is not None:
+            assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
+
+
+def test_guard_costs_no_accuracy_on_clean_models():
+    """verify_split (both arithmetics on the model's own samples) still reports fp32-noise-class differences."""
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    d = MN.verify_split(_models(SY.OPAQUE)["fine"])
+    assert max(d.values()) < 2e-5, d
+    assert np.isfinite(list(d.values())).all()

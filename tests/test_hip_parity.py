@@ -40,7 +40,8 @@ def _M():
 
 def _module(sd):
     M = _M()
-    m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+    m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal="normal_net.0.weight" in sd,
+                     predict_mirror_mask="is_mirror_net.0.weight" in sd)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return m.to(DEV)
 
@@ -165,6 +166,118 @@ def test_render_rays_golden(name):
         assert np.max(np.abs(got["z_vals_fine"] - fx.outputs["z_vals_fine"])) <= 5e-3
 
 
+# --------------------------------------------------------------------------- G13: without the optional heads
+@pytest.mark.parametrize("name", [n for n in FX.names("g13_") if not n.endswith("_eval")])
+def test_render_rays_without_optional_heads_golden(name):
+    """models/mirror_nerf.py:80-99: predict_normal=False and/or predict_mirror_mask=False (plain NeRF for
+    extract_color_mesh.py, ablations): same kernels, absent heads packed as zeros, their keys absent from the dict."""
+    fx = FX.Fixture(name)
+    m = fx.meta
+    from tests.golden import weights as GW
+    sds = GW.make_state_dict(m["seed"], 2, predict_normal=m["predict_normal"], predict_mirror_mask=m["predict_mirror_mask"])
+    for sd, c in zip(sds, m["checksum"]):
+        GW.apply_tweaks(sd, m["tweaks"])
+        assert abs(GW.checksum(sd) - c) <= 1e-9 * max(1.0, abs(c))
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    got = _np(_M().render_rays(models, _emb(), rays, 64, False, 0, 0, 64, 32768, False, m["test_time"], **m["kwargs"]))
+    assert set(got) - set(PER_SAMPLE_OK) == set(fx.outputs) - set(PER_SAMPLE_OK), set(got) ^ set(fx.outputs)
+    _cmp(name, got, fx.outputs, m, skip=list(FX.PER_SAMPLE_FINE) + ["normal_coarse", "normal_fine"])
+
+
+def test_eval_without_normal_head_uses_the_density_gradient_normal():
+    """predict_normal=False: eval.py:147-148 turns compute_normal on and reflects about the composited density-gradient
+    normal (eval.py:338-360) -- a noise-dominated quantity in fp32 (floors measured per key in the fixture)."""
+    fx = FX.Fixture("g13_no_normal_head_eval")
+    m = fx.meta
+    from tests.golden import weights as GW
+    sds = GW.make_state_dict(m["seed"], 2, predict_normal=False, predict_mirror_mask=True)
+    for sd in sds:
+        GW.apply_tweaks(sd, m["tweaks"])
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    got = _np(_M().batched_inference(models, _emb(), torch.from_numpy(fx.inputs["rays"]).to(DEV), 64, 64, False, 32768,
+                                     args=m["args"], trace_secondary_rays=True))
+    assert "surface_normal_fine" not in got and "surface_normal_grad_fine" in got
+    meta = dict(m, floor={k: max(v, 5e-3 if k in ("reflect_direction",) else 0.0) for k, v in m["floor"].items()})
+    _cmp("g13_no_normal_head_eval", got, fx.outputs, meta, skip=FX.PER_SAMPLE_FINE)
+
+
+PER_SAMPLE_OK = ("pred_normal_coarse", "pred_normal_fine", "normal_coarse", "normal_fine")
+
+
+# --------------------------------------------------------------------------- G11: trained weights
+def _cmp_trained(name, got, fx, skip=()):
+    """Parity on TRAINED weights (fixtures G11).  There the reference is not stable at 1e-4 against ITSELF: its fp32 and
+    fp64 runs put a few fine samples into different inverse-CDF bins, and on those rays the composited outputs move by up
+    to 1e-2 while every other ray agrees to 1e-6 (both numbers are measured per fixture: meta.floor, meta.floor_frac).
+    Two conditions, both relative to that measured noise: (1) max-abs <= max(1e-4 [8e-4 depth-like], 4 x floor);
+    (2) the FRACTION of rays that differ by more than the plain 1e-4 / 8e-4 bar is at most twice the reference's own
+    fraction plus two rays -- so the bulk of the rays still has to meet the north-star bar exactly."""
+    meta = fx.meta
+    n_checked = 0
+    for k, want in fx.outputs.items():
+        if k in skip or k not in got:
+            continue
+        g = got[k].astype(np.float64)
+        assert g.shape == want.shape, (name, k)
+        tol = FX.tolerance(k, meta)
+        d = np.abs(g - want).reshape(want.shape[0], -1).max(1) if want.size else np.zeros(0)
+        assert d.max(initial=0.0) <= tol, f"{name}:{k} max-abs {d.max():.3e} > {tol:.1e}"
+        bar = 8e-4 if k.startswith(("depth", "x_surface", "z_vals")) else 1e-4
+        if k in FX.GRAD_NORMAL_KEYS:
+            continue
+        frac = float((d > bar).mean()) if d.size else 0.0
+        allowed = 2.0 * meta.get("floor_frac", {}).get(k, 0.0) + 2.0 / max(1, d.size)
+        assert frac <= allowed, f"{name}:{k} {frac:.4f} of the rays off by more than {bar:.0e} (reference fp32 vs fp64: {allowed:.4f} allowed)"
+        n_checked += 1
+    assert n_checked >= 4, (name, n_checked)
+
+
+@pytest.mark.parametrize("name", [n for n in FX.names("g11_") if "_render_" in n])
+def test_trained_weights_render_golden(name):
+    fx, got = _render_fixture(name)
+    skip = list(FX.PER_SAMPLE_FINE) + ["normal_coarse", "normal_fine", "pred_normal_coarse"]
+    _cmp_trained(name, got, fx, skip)
+    for typ in ("coarse", "fine"):
+        assert np.max(np.abs(got[f"weights_{typ}"].sum(1) - got[f"opacity_{typ}"])) <= 1e-5
+        assert np.all(np.diff(got[f"z_vals_{typ}"], axis=1) >= 0)
+
+
+@pytest.mark.parametrize("name", [n for n in FX.names("g11_") if "_eval_" in n])
+def test_trained_weights_eval_golden(name):
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    got = _np(_M().batched_inference(models, _emb(), torch.from_numpy(fx.inputs["rays"]).to(DEV), m["N_samples"],
+                                     m["N_importance"], False, m["chunk"], args=m["args"], trace_secondary_rays=True,
+                                     normal_noise_std=m["args"]["normal_noise_std"]))
+    _cmp_trained(name, got, fx, FX.PER_SAMPLE_FINE)
+
+
+@pytest.mark.parametrize("name", [n for n in FX.names("g11_") if n.endswith("_psnr")])
+def test_trained_weights_psnr_within_a_tenth_of_a_db(name):
+    """BASELINE north star: PSNR within 0.1 dB of the reference on the synthetic mirror scene.  The held-out view of the
+    analytic scene rendered by the reference (captured) and by the HIP path, both scored against the analytic ground
+    truth with the device metric."""
+    from mirror_nerf_amd import metrics
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    out = _M().batched_inference(models, _emb(), rays, m["N_samples"], m["N_importance"], False, 32768, args=m["args"],
+                                 trace_secondary_rays=True, to_cpu=False)
+    gt = torch.from_numpy(fx.inputs["gt_rgb"]).to(DEV)
+    psnr = float(metrics.psnr(out["rgb_fine"], gt))
+    assert abs(psnr - m["psnr_ref"]) <= 0.1, (psnr, m["psnr_ref"])
+    got = _np({k: out[k] for k in fx.outputs})
+    # and the HIP image is, pixel for pixel, as close to the reference's as the reference's fp64 run is
+    _cmp_trained(name, got, fx)
+    acc = float(((got["mirror_mask_fine"] > 0.5) == (fx.inputs["gt_mask"] > 0.5)).mean())
+    assert abs(acc - m["mask_accuracy_ref"]) <= 2.0 / got["mirror_mask_fine"].size + 1e-9
+
+
 def test_render_rays_empty_and_single():
     from tests.golden import weights as GW
     sds = GW.make_state_dict(0, 2)
@@ -284,7 +397,7 @@ def test_recursion_train_golden(name):
 
 
 # --------------------------------------------------------------------------- a13 / a14
-@pytest.mark.parametrize("name", FX.names("g7_") + FX.names("g8_"))
+@pytest.mark.parametrize("name", FX.names("g7_") + FX.names("g8_") + FX.names("g8b_"))
 def test_recursion_eval_golden(name):
     fx = FX.Fixture(name)
     m = fx.meta
@@ -297,6 +410,36 @@ def test_recursion_eval_golden(name):
                                      trace_secondary_rays=True, normal_noise_std=m["args"]["normal_noise_std"],
                                      _normal_noise=noise))
     _cmp(name, got, fx.outputs, m, skip=FX.PER_SAMPLE_FINE)
+
+
+def test_roughness_jitters_batched_equal_one_by_one():
+    """Config 4 (run.sh:187-188): the trace_ray_times jittered reflections of a level rendered in groups through one
+    recursion call (batch_jitter, the production path) give the same colours as the reference's one-by-one loop, given
+    the same draws (one bounce: no nested draws to interleave)."""
+    fx = FX.Fixture("g8_rough_allmirror")
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    args = dict(m["args"], trace_ray_times=7)
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    rs = np.random.RandomState(3)
+    draws = [torch.from_numpy(rs.normal(size=(rays.shape[0], 3)).astype(np.float32)) for _ in range(8)]
+    M = _M()
+    from mirror_nerf_amd import recursion as R
+    outs = []
+    for batch, group in ((False, None), (True, 262144), (True, 3 * rays.shape[0])):    # one by one; one group; groups of 3
+        old = R.JITTER_RAYS
+        if group:
+            R.JITTER_RAYS = group
+        try:
+            outs.append(M.batched_inference(models, _emb(), rays, m["N_samples"], m["N_importance"], False, m["chunk"], args=args,
+                                            trace_secondary_rays=True, normal_noise_std=args["normal_noise_std"],
+                                            _normal_noise=iter(draws), batch_jitter=batch, to_cpu=False))
+        finally:
+            R.JITTER_RAYS = old
+    for o in outs[1:]:
+        assert torch.equal(o["rgb_fine"], outs[0]["rgb_fine"])
+        assert torch.equal(o["rgb_fine_reflect"], outs[0]["rgb_fine_reflect"])
 
 
 # --------------------------------------------------------------------------- full-size properties

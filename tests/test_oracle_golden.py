@@ -90,7 +90,7 @@ def test_recursion_train(name):
     _cmp(fx, got, skip=FX.PER_SAMPLE_FINE)
 
 
-@pytest.mark.parametrize("name", FX.names("g7_") + FX.names("g8_"))
+@pytest.mark.parametrize("name", FX.names("g7_") + FX.names("g8_") + FX.names("g8b_"))
 def test_recursion_eval(name):
     fx = FX.Fixture(name)
     m = fx.meta
@@ -169,3 +169,22 @@ def test_torch_port_matches_oracle():
         got = TP.render_eval(mt, torch.from_numpy(rays), 64, 128, 32768, max_level=levels)
         for k in ("rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine", "surface_normal_fine"):
             assert np.abs(got[k].numpy() - want[k]).max() <= 2e-6, k
+
+
+@pytest.mark.parametrize("name", [n for n in FX.names("g13_") if not n.endswith("_eval")])
+def test_render_rays_without_optional_heads(name):
+    """G13: the oracle on models without the normal / mirror-mask heads (models/mirror_nerf.py:80-99)."""
+    from tests.golden import weights as GW
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = GW.make_state_dict(m["seed"], 2, predict_normal=m["predict_normal"], predict_mirror_mask=m["predict_mirror_mask"])
+    for sd in sds:
+        GW.apply_tweaks(sd, m["tweaks"])
+    got = O.render_rays({"coarse": sds[0], "fine": sds[1]}, EMB, fx.inputs["rays"], 64, False, 0, 0, 64, 32768, False, m["test_time"],
+                        **m["kwargs"])
+    for k, want in fx.outputs.items():
+        if k in FX.PER_SAMPLE_FINE or k.startswith("normal_"):
+            continue
+        tol = 2e-2 if k in FX.GRAD_NORMAL_KEYS else 5e-6
+        assert np.max(np.abs(got[k].astype(np.float64) - want)) <= tol, (name, k)
+    assert set(fx.outputs) - {"pred_normal_fine", "pred_normal_coarse", "normal_fine", "normal_coarse"} <= set(got)
