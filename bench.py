@@ -157,6 +157,42 @@ def hash_grid_leg(dev, rays):
                     "against tinycudann unpinned (DESIGN.md 4.3); VALU + gather kernels, the MLPs are not on MFMA yet"}
 
 
+def roughness_leg(dev, models, emb):
+    """BASELINE config 4 at the shape run.sh:185-208 runs it (mode 5, control_mirror_roughness): 480x360 (run.sh:47-48),
+    64 coarse + 64 importance samples, chunk 16384, one bounce, trace_ray_times = 64 jittered reflections per mirror ray,
+    normal_noise_std = 0.0025, every pixel a mirror (so that the reference's level-0 addition is well-formed):
+    172 800 primary + 65 x 172 800 reflected rays per frame.  The 64 jittered renders of a chunk go through the recursion
+    in groups (recursion.JITTER_RAYS) instead of one by one.  Also: two bounces with eval.py's default trace_ray_times = 4
+    (the jitters nest: (1 + 5) + 5 x ... renders per level)."""
+    import torch
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import synthetic as SY
+    Hc, Wc = 360, 480
+    rays = SY.device_rays(Hc, Wc, dev)
+    out = {}
+    for name, levels, times in (("one_bounce_64_jitters", 1, 64), ("two_bounces_4_jitters", 2, 4)):
+        args = dict(ARGS, max_recursive_level=levels, app_control_mirror_roughness=True, trace_ray_times=times)
+
+        def frame():
+            return M.batched_inference(models, emb, rays, N_SAMPLES, 64, False, 16384, args=args, trace_secondary_rays=True,
+                                       normal_noise_std=0.0025, to_cpu=False)
+        if name.startswith("one"):
+            M.batched_inference(models, emb, rays[:16384], N_SAMPLES, 64, False, 16384, args=args, trace_secondary_rays=True,
+                                normal_noise_std=0.0025, to_cpu=False)      # warm-up on one chunk
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = Hc * Wc
+        rays_total = n * (1 + (times + 1)) if levels == 1 else n * (1 + (times + 1) * (1 + (times + 1)))
+        out[name] = {"rays_per_s": rays_total / dt, "frame_s": dt, "rays_per_frame": rays_total,
+                     "samples_per_s": rays_total / dt * (2 * N_SAMPLES + 64)}
+    out["note"] = ("eval.batched_inference with app_control_mirror_roughness on the all-mirror random-init pair, 480x360, "
+                   "64+64 samples, chunk 16384, normal_noise_std 0.0025 (run.sh:185-208); jittered reflections batched per level")
+    return out
+
+
 def _respawn(a):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
@@ -319,6 +355,7 @@ def main():
                                     if k in train_total}
 
     hash_grid = hash_grid_leg(dev, rays) if (world == 1 and not a.no_train) else None
+    rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train) else None
 
     if rank == 0:
         split = a.precision == "split"
@@ -370,6 +407,8 @@ def main():
             res["train_step"] = train
         if hash_grid is not None:
             res["hash_grid_variant"] = hash_grid
+        if rough is not None:
+            res["roughness_variant"] = rough
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -49,6 +49,9 @@ extern "C" {
 /* gradient steering of the training backward (the reference's --detach_density_* options; values are unaffected) */
 #define MNRF_CUT_NORMAL_HEAD 32u   /* mnrf_field_backward: normal_net sees geo_feat.detach() (mirror_nerf.py:154-158) */
 #define MNRF_CUT_MIRROR_HEAD 64u   /* mnrf_field_backward: is_mirror_net sees geo_feat.detach() (mirror_nerf.py:169-170) */
+#define MNRF_DW_ACCUMULATE 128u     /* mnrf_field_backward: ADD the parameter gradients to d_params instead of overwriting them (a
+                                      module evaluated more than once per step -- primary and reflected rays -- then needs
+                                      no separate accumulation kernels) */
 #define MNRF_DETACH_W_MASK 1       /* mnrf_composite_backward: mirror mask = sum(weights.detach() * is_mirror) (rendering.py:223-226) */
 #define MNRF_DETACH_W_NORMAL 2     /* mnrf_composite_backward: the normal outputs use weights.detach() (rendering.py:244-264) */
 
@@ -205,7 +208,8 @@ int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_
                         const float* keep_mirror /* (B/spr) per ray [(B) with xyz] or null: 0 = the mirror head of this ray's
                                                     samples sees geo_feat.detach() (models/mirror_nerf.py:172-183) */,
                         unsigned flags /* MNRF_SPLIT_F16: activation gradients on the f16 pipe; MNRF_CUT_NORMAL_HEAD /
-                                          MNRF_CUT_MIRROR_HEAD: that head sees geo_feat.detach() (mirror_nerf.py:157, 169-170) */,
+                                          MNRF_CUT_MIRROR_HEAD: that head sees geo_feat.detach() (mirror_nerf.py:157, 169-170);
+                                          MNRF_DW_ACCUMULATE: add to d_params */,
                         void* stream);
 
 /* Second-order term of the field backward: the gradient that reaches the trunk weights, sigma.weight

@@ -28,6 +28,7 @@ MNRF_GRAD_NORMAL = 2
 MNRF_SPLIT_F16 = 4
 MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
+MNRF_DW_ACCUMULATE = 128
 MNRF_DETACH_W_MASK = 1
 MNRF_DETACH_W_NORMAL = 2
 N_PARAMS = 32

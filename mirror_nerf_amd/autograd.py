@@ -5,6 +5,12 @@ import torch
 from . import _lib
 
 
+import os
+
+# MNRF_FOLD_GRADS=0: leave the accumulation of a module's parameter gradients over its evaluations to autograd
+FOLD_GRADS = os.environ.get("MNRF_FOLD_GRADS", "1") != "0"
+
+
 def _c(t):
     return None if t is None else t.contiguous()
 
@@ -128,6 +134,8 @@ class FieldFn(torch.autograd.Function):
         ctx.param_shapes = [tuple(t.shape) for t in params]
         from .weights import param_refs
         ctx.param_names = [full for _, _, full in param_refs(module)]     # same order as `params` (weights.params_of)
+        # how many evaluations of this module await their backward (primary + reflected rays: see backward)
+        module.__dict__["_mnrf_uses"] = module.__dict__.get("_mnrf_uses", 0) + 1
         if normal is None:
             normal = f(0, 3)
             ctx.mark_non_differentiable(normal)
@@ -146,7 +154,19 @@ class FieldFn(torch.autograd.Function):
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         z = lambda t, *s: torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()  # noqa: E731
         g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
-        d_params = [f(*s) for s in ctx.param_shapes]
+        # A module evaluated several times in one step (primary rays, then reflected rays: train.py:253-259) gets one
+        # gradient per evaluation and autograd would add them with one kernel per parameter (64 launches per step).
+        # Instead the FIRST backward of a pass allocates the gradient tensors and hands them to autograd; the following
+        # ones ADD into those same tensors in the finish kernel (MNRF_DW_ACCUMULATE) and return None.  The tensors are
+        # remembered on the module only until the backward pass ends (engine callback) or the last pending evaluation has
+        # run -- dropping our reference then lets AccumulateGrad adopt them without a copy.  A mis-count can only cost that
+        # copy or fall back to autograd's additions, never a wrong sum.
+        mod = ctx.module
+        uses = max(0, mod.__dict__.get("_mnrf_uses", 1) - 1)
+        mod.__dict__["_mnrf_uses"] = uses
+        pending = mod.__dict__.get("_mnrf_pending") if FOLD_GRADS else None
+        accumulate = pending is not None and [tuple(t.shape) for t in pending] == ctx.param_shapes
+        d_params = pending if accumulate else [f(*s) for s in ctx.param_shapes]
         from .weights import PARAM_NAMES, PARAM_SHAPES
         by_name = dict(zip(ctx.param_names, d_params))
         # the kernels write all 32 gradients in state_dict order; an absent optional head gets scratch buffers
@@ -163,7 +183,7 @@ class FieldFn(torch.autograd.Function):
             _lib.check(L.mnrf_field_backward(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), p(ctx.keep_mirror),
-                (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut, _lib.stream()),
+                (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut | (_lib.MNRF_DW_ACCUMULATE if accumulate else 0), _lib.stream()),
                 "mnrf_field_backward")
             if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
                 ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
@@ -171,9 +191,20 @@ class FieldFn(torch.autograd.Function):
                     p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
                     p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz),
                     _lib.MNRF_SPLIT_F16 if ctx.split else 0, _lib.stream()), "mnrf_field_backward2")
-        else:
+        elif not accumulate:
             for t in d_params:
                 t.zero_()
+        if FOLD_GRADS and B:
+            if accumulate:
+                if uses == 0:
+                    mod.__dict__.pop("_mnrf_pending", None)
+            elif uses > 0:
+                mod.__dict__["_mnrf_pending"] = d_params
+
+                def _end_of_pass(m=mod):
+                    m.__dict__.pop("_mnrf_pending", None)
+                    m.__dict__["_mnrf_uses"] = 0
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
         g_xyz = g_rays = g_de = None
         if d_xyz is not None:
             if xyz is not None:
@@ -187,7 +218,7 @@ class FieldFn(torch.autograd.Function):
                 g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
         if d_dir is not None:
             g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
-        return (None, None, g_xyz, g_rays, None, g_de, None, *d_params)
+        return (None, None, g_xyz, g_rays, None, g_de, None, *([None] * len(d_params) if accumulate else d_params))
 
 
 class EmbedFn(torch.autograd.Function):

@@ -433,7 +433,7 @@ static void gemm(DwBatch& bt, const float* A, int lda, int N, const float* X, in
 }
 
 int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long long B, float* ws, float* const* d_params,
-              hipStream_t s) {
+              int accumulate, hipStream_t s) {
     const int splits = dw_splits(B);
     const int ssplits = dw_small_splits(B);
     DwBatch bt;
@@ -444,7 +444,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     auto X = [&](int sec) { return save_x + (long long)sec * B; };
     auto Y = [&](int sec) { return dY + (long long)sec * B; };
     DwFinishArgs F;
-    F.accumulate = 0;
+    F.accumulate = accumulate;
     for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
     for (int gq = 0; gq < 4; ++gq)
         for (int t = 0; t < 16; ++t) {

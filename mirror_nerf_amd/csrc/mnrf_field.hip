@@ -238,7 +238,7 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");
     int rc = mnrf_check_launch("mnrf_field_backward (activation gradients)");
     if (rc != MNRF_OK) return rc;
-    if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, s) != 0)
+    if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, (flags & MNRF_DW_ACCUMULATE) ? 1 : 0, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: workspace accounting error");
     return mnrf_check_launch("mnrf_field_backward (weight gradients)");
 }

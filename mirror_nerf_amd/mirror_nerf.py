@@ -60,7 +60,10 @@ def set_precision(mode):
 # the HOST reads it at the natural sync points -- the end of a frame (batched_inference), of a training forward
 # (NeRFSystem.forward), of a training step (training.train_step), of a stand-alone render_rays / MirrorNeRF.forward call
 # -- and when it is set the module is switched to the exact fp32 kernels for good and the work is repeated, so a result
-# computed outside the range of the fast arithmetic is never returned.  MNRF_GUARD=0 disables the host side.
+# computed outside the range of the fast arithmetic is never returned.  The one exception is training.train_step, which
+# reads the flag asynchronously and learns about a trip one step late (that step's update used saturated values; every
+# later step runs on fp32): a synchronous read there drains the queue before the optimizer step and costs 6 % of the step.
+# MNRF_GUARD=0 disables the host side.
 GUARD = os.environ.get("MNRF_GUARD", "1") != "0"
 GUARD_NAMES = {1: "an activation reached the f16 maximum (65504)", 2: "a weight is non-finite or >= 65504",
                4: "a sample position has |x| >= 16 (encoding argument >= 2^13)"}
@@ -107,6 +110,45 @@ def check_guard(modules):
             why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
             warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range ({why}); this model is evaluated with "
                           "the exact fp32 kernels from now on and the affected work is repeated", RuntimeWarning, stacklevel=2)
+            m.__dict__["_mnrf_precision"] = "fp32"
+            tripped = True
+    return tripped
+
+
+def guard_async_begin(modules):
+    """Training: start an asynchronous read of the guard words (device -> pinned host memory on the current stream) and
+    return a token for guard_async_end.  Unlike check_guard this does not drain the GPU queue: the host keeps running ahead
+    of the device across the optimizer step (a synchronous read costs ~0.5 ms of an 8 ms step)."""
+    if not GUARD or not PRECISION.startswith("split"):
+        return None
+    if hasattr(modules, "models"):
+        modules = list(modules.models.values())
+    modules = [m for m in dict.fromkeys(modules) if isinstance(m, MirrorNeRF) and precision_of(m).startswith("split")
+               and m.__dict__.get("_mnrf_packed") is not None and m.__dict__["_mnrf_packed"].packed is not None]
+    if not modules:
+        return None
+    dev_words = torch.cat([m.__dict__["_mnrf_packed"].packed[-1:] for m in modules]).view(torch.int32)
+    host = torch.empty(len(modules), dtype=torch.int32, pin_memory=True)
+    host.copy_(dev_words, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return modules, host, ev
+
+
+def guard_async_end(token):
+    """Finish guard_async_begin (waits for that copy only -- it completed long ago when called one step later).  Returns
+    True when a module tripped; it is then pinned to the fp32 kernels like check_guard does."""
+    if token is None:
+        return False
+    modules, host, ev = token
+    ev.synchronize()
+    tripped = False
+    for m, w in zip(modules, host.tolist()):
+        if w and precision_of(m).startswith("split"):
+            import warnings
+            why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
+            warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range in the previous training step ({why}); "
+                          "this model is evaluated with the exact fp32 kernels from now on", RuntimeWarning, stacklevel=3)
             m.__dict__["_mnrf_precision"] = "fp32"
             tripped = True
     return tripped

@@ -56,13 +56,13 @@ def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
 
 
 def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
+    from .mirror_nerf import guard_async_begin, guard_async_end
+    guard_async_end(system.__dict__.pop("_mnrf_guard_token", None))    # the previous step's range-guard words (no queue drain)
     res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
     loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    from .mirror_nerf import check_guard
-    if check_guard(system):     # a scaled gradient left the f16 range in the backward: repeat the step on the fp32 kernels
-        return train_step(system, optimizer, rays, target, gt_mask, loss_fn, epoch)
+    system.__dict__["_mnrf_guard_token"] = guard_async_begin(system)   # forward + backward flags of THIS step, read at the next
     D.allreduce_gradients(params_of(system))                  # RCCL over xGMI when world_size > 1
     optimizer.step()
     return loss
@@ -107,7 +107,22 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     refl = float(refl.item())
+    # algorithmic work of a step (FLOP = 2 MAC; per sample, every sample of a training render is a full
+    # 4-head evaluation): forward 1 318 912 + density-gradient normal 982 528 (compute_normal = trace_secondary_rays,
+    # train.py:143) + activation gradients 1 318 912 + weight gradients 1 318 912; with a loss on normal_* keys the
+    # second-order pass adds a tangent pass, the density-gradient chain once more and the trunk weight gradients
+    # (3 x 982 528).  Priced against the dense f16 MFMA peak (the split path; the dW GEMMs run bf16 x 6 on the same pipe).
+    from .mirror_nerf import FLOP_FULL, FLOP_GRAD
+    samples = (batch * steps + refl) * (64 + 128)
+    flop_sample = 3 * FLOP_FULL + FLOP_GRAD + (3 * FLOP_GRAD if loss_name == "total" else 0)
+    achieved = samples * flop_sample / dt / 1e12
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": 2516.6, "unit": "TFLOP/s", "frac": achieved / 2516.6,
+                "flop_per_sample": flop_sample, "samples_per_step": samples / steps,
+                "note": "ALGORITHMIC fp32 FLOPs of forward + density-gradient normal + activation gradients + weight gradients"
+                        + (" + second-order pass" if loss_name == "total" else "") + " over the whole step time (host, losses, "
+                        "optimizer and all-reduce included); dense f16 MFMA peak"}
     return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)",
+            "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
             "samples_per_ray": 64 + 128, "steps": steps, "loss": float(loss.item()),
             "loss_fn": "losses.TotalLoss (colour, mask, normal, normal_reg; fused HIP kernels; second-order pass on)" if loss_name == "total"

@@ -174,17 +174,42 @@ def test_frame_driver_and_training_step_fall_back():
     for s in (s1, s2):
         for k, v in hp.items():
             setattr(s.hparams, k, v)
-    o1 = torch.optim.SGD(s1.parameters(), lr=0.0)
-    with pytest.warns(RuntimeWarning):
+    class NoStep:      # leaves the weights alone (SGD with lr = 0 turns an inf gradient into a NaN weight)
+        def __init__(self, params):
+            self.params = list(params)
+
+        def zero_grad(self, set_to_none=True):
+            for q in self.params:
+                q.grad = None
+
+        def step(self):
+            pass
+    o1 = NoStep(s1.parameters())
+    # train_step reads the flag asynchronously: the tripping step itself passes silently, the NEXT one reports it and runs
+    # (from then on) on the exact kernels -- only the model that tripped
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        training.train_step(s1, o1, *batch)
+    with pytest.warns(RuntimeWarning, match="previous training step"):
         l1 = training.train_step(s1, o1, *batch)
-    assert MN.precision_of(s1.nerf_fine) == "fp32" and MN.precision_of(s1.nerf_coarse) == "split"   # only the model that tripped
+    assert MN.precision_of(s1.nerf_fine) == "fp32" and MN.precision_of(s1.nerf_coarse) == "split"
     s2.nerf_fine.__dict__["_mnrf_precision"] = "fp32"
-    l2 = training.train_step(s2, torch.optim.SGD(s2.parameters(), lr=0.0), *batch)
+    l2 = training.train_step(s2, NoStep(s2.parameters()), *batch)
     assert float(l1) == float(l2)
     for (n, p), q in zip(s1.named_parameters(), s2.parameters()):
         assert (p.grad is None) == (q.grad is None)
         if p.grad is not None:
             assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
+    # NeRFSystem.forward on its own (validation, custom loops) checks synchronously and repeats the forward
+    s3 = system()
+    for k, v in hp.items():
+        setattr(s3.hparams, k, v)
+    with pytest.warns(RuntimeWarning, match="affected work is repeated"):
+        with torch.no_grad():
+            r3 = s3(batch[0], {"mirror_mask": batch[2], "is_eval": False, "train_geometry_stage": False})
+    with torch.no_grad():
+        r2 = s2(batch[0], {"mirror_mask": batch[2], "is_eval": False, "train_geometry_stage": False})
+    assert torch.equal(r3["rgb_fine"], r2["rgb_fine"])
 
 
 def test_guard_costs_no_accuracy_on_clean_models():
