@@ -46,6 +46,9 @@ extern "C" {
                                   hi/lo f16 pair (3 MFMAs per product block, fp32 accumulation; ~2^-20 relative per
                                   product instead of the bit-exact fp32 fmaf chain of the default) */
 
+#define MNRF_TCNN_VALU 8u       /* mnrf_tcnn_forward: evaluate the small MLPs with fp32 FMAs on the VALU, one thread per sample
+                                  (the first implementation; default: hi/lo f16 tiles on the matrix pipe, ~1e-6 of it) */
+
 /* gradient steering of the training backward (the reference's --detach_density_* options; values are unaffected) */
 #define MNRF_CUT_NORMAL_HEAD 32u   /* mnrf_field_backward: normal_net sees geo_feat.detach() (mirror_nerf.py:154-158) */
 #define MNRF_CUT_MIRROR_HEAD 64u   /* mnrf_field_backward: is_mirror_net sees geo_feat.detach() (mirror_nerf.py:169-170) */

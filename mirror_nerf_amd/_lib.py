@@ -26,6 +26,7 @@ _str = ctypes.c_void_p      # hipStream_t
 MNRF_SIGMA_ONLY = 1
 MNRF_GRAD_NORMAL = 2
 MNRF_SPLIT_F16 = 4
+MNRF_TCNN_VALU = 8
 MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128

@@ -168,12 +168,9 @@ __device__ __forceinline__ unsigned grid_index(unsigned x, unsigned y, unsigned 
 
 // one level of the encoding: the two features and (GRAD) their derivatives w.r.t. the [0,1] coordinates
 template <bool GRAD>
-__device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const float (&u)[3], bool oob, float& a0, float& a1,
-                                             float (&g0)[3], float (&g1)[3]) {
-    const float scale = A.scale[lv];
-    const unsigned res = A.res[lv];
-    const unsigned hsize = A.off[lv + 1] - A.off[lv];
-    const float2* tab = (const float2*)A.table + A.off[lv];
+__device__ __forceinline__ void encode_level_p(const float* table, float scale, unsigned res, unsigned off0, unsigned hsize, unsigned mode,
+                                               const float (&u)[3], bool oob, float& a0, float& a1, float (&g0)[3], float (&g1)[3]) {
+    const float2* tab = (const float2*)table + off0;
     unsigned pg[3];
     float fr[3];
 #pragma unroll
@@ -193,7 +190,7 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
         const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
         const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
         // unconditional loads: the eight gathers of a level (and of the next levels, the loop is unrolled) go out together
-        const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
+        const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, mode)];
         const float w = wx * wy * wz * in_box;
         a0 += w * v.x; a1 += w * v.y;
         if (GRAD) {
@@ -205,6 +202,12 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
             g0[2] += sz * v.x; g1[2] += sz * v.y;
         }
     }
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const float (&u)[3], bool oob, float& a0, float& a1,
+                                             float (&g0)[3], float (&g1)[3]) {
+    encode_level_p<GRAD>(A.table, A.scale[lv], A.res[lv], A.off[lv], A.off[lv + 1] - A.off[lv], A.mode[lv], u, oob, a0, a1, g0, g1);
 }
 
 template <bool SIGMA_ONLY, bool GRAD>
@@ -358,6 +361,422 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
     }
 }
 #undef VEC
+
+// ------------------------------------------------------------------------------------------------------------
+// The same field with its MLPs on the matrix pipe (inference / training forward).
+//
+// tcnn_kernel above spends most of its time on 11 k scalar-operand FMAs per sample (VALU 31 % busy, waiting on the
+// weight stream through the scalar cache, profiles/r01s_pmc_tcnn).  Here a wavefront owns NG GROUPS of 16 samples
+// and evaluates every Linear transposed, Out^T[rows x 16 samples] = W . In^T, on v_mfma_f32_16x16x32_f16 with the hi/lo
+// f16 split of the 8x256 field kernel (three products per tile, fp32 accumulation: ~2^-20 relative, so the results stay
+// within fp32 noise of the VALU kernel; tinycudann itself runs these MLPs in plain fp16).
+//     (Here: 8 waves x 2 groups per workgroup iteration, one workgroup per CU: with <= 128 registers for a second one the
+//     64 gathers a lane keeps in flight spill.)
+//   * The gathers run with one lane per sample (phase 1: every gather instruction of a wave addresses one level for 64
+//     consecutive samples; a first version in which the four lanes of a sample shared its levels -- no exchange needed --
+//     made 16 samples x 4 levels out of every instruction and gathered 15 % slower) and hand the 32 features to the MLP
+//     lanes through a per-wave LDS area.  Lane (j = l & 15, g = l >> 4) then works for sample j of each group: features
+//     8g .. 8g+7 are its slots of the B operand of sigma_net.0 and, as in mnrf_layout.h, accumulator register r of row
+//     block nb (row 16 nb + 4 g + r) is its slot of the next layer's B operand: activations stay in their lane.
+//   * The weights (11 204 floats) become 33 hi/lo tile pairs of 2 KiB in LDS, built by the workgroup itself from the fp32
+//     blob in the column order those slots imply (tile_value below); workgroups are persistent (one per CU), so this is
+//     paid once per ~24 000 samples.  A tile pair is read once per four groups: 66 KiB of LDS reads per 64 samples.
+//   * 29 tile pairs x 3 products x 4 groups = 348 MFMAs per 64 samples: 0.25 ms of matrix-pipe time per 6.29 M-sample
+//     launch -- the kernel is left with its 128 gathers per sample.
+//   * GRAD: d sigma / d features = W_s0^T (relu' * W_s1[0,:]) as one more transposed product (4 tile pairs) whose output
+//     rows are ordered so that lane g receives features 8g .. 8g+7; they go back through the LDS area to the sample's lane,
+//     which runs the second gather pass with the interpolation-weight derivatives (phase 3).
+namespace mf {
+
+constexpr int WAVES = 6;                            // 2 workgroups x 6 waves per CU: 3 waves per SIMD at <= 168 registers
+constexpr int NG = 2;                               // groups of 16 samples per wave iteration (4: 800 B/lane of spills at 256 registers)
+constexpr int TILE = WAVES * NG * 16;               // samples per workgroup iteration
+constexpr int NT_FWD = 29, NT_ALL = 33;             // tile pairs (the last four: W_s0^T for the density gradient)
+constexpr int PAIR_B = 2048;
+constexpr int LDS_TILES = NT_ALL * PAIR_B;          // 66 KiB
+constexpr int LDS_WS1 = LDS_TILES;                  // sigma_net.1 row 0 (64 floats) + mirror biases (33 floats)
+constexpr int LDS_BYTES = LDS_WS1 + 128 * 4;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+enum Kind : int { K_ENC = 0, K_H = 1, K_GEO = 2, K_SHGEO = 3, K_TRANS = 4 };
+struct TileDesc { short w_off, n_true, ld, nb, T, kind; };
+// consumption order of the forward: S0 (4), S1 (2), N0 (4), N1 (2), M0 (2), M1 (1), C0 (4), C1 (8: T-major), C2 (2); then S0^T (4)
+__device__ __forceinline__ TileDesc tile_desc(int id) {
+    if (id < 4) return TileDesc{W_S0, 64, 32, (short)id, 0, K_ENC};
+    if (id < 6) return TileDesc{W_S1, 16, 64, 0, (short)(id - 4), K_H};
+    if (id < 10) return TileDesc{W_N0, 64, 16, (short)(id - 6), 0, K_GEO};
+    if (id < 12) return TileDesc{W_N1, 3, 64, 0, (short)(id - 10), K_H};
+    if (id < 14) return TileDesc{W_M0, 32, 16, (short)(id - 12), 0, K_GEO};
+    if (id < 15) return TileDesc{W_M1, 1, 32, 0, 0, K_H};
+    if (id < 19) return TileDesc{W_C0, 64, 32, (short)(id - 15), 0, K_SHGEO};
+    if (id < 27) return TileDesc{W_C1, 64, 64, (short)((id - 19) & 3), (short)((id - 19) >> 2), K_H};
+    if (id < 29) return TileDesc{W_C2, 3, 64, 0, (short)(id - 27), K_H};
+    return TileDesc{W_S0, 64, 32, (short)((id - 29) & 1), (short)((id - 29) >> 1), K_TRANS};
+}
+// element (lane, e) of the A operand of a tile: W[row 16 nb + (lane & 15)][column of slot (T, lane >> 4, e)]
+__device__ __forceinline__ float tile_value(const float* W, int id, int lane, int e) {
+    const TileDesc d = tile_desc(id);
+    const int i = lane & 15, g = lane >> 4;
+    const int kh = 32 * d.T + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));      // slot -> previous layer's row (K_H)
+    if (d.kind == K_TRANS) {
+        const int feat = 8 * (i >> 2) + 4 * d.nb + (i & 3);     // output row 16 nb + i delivers this encoding feature
+        return W[W_S0 + kh * 32 + feat];                        // contraction over the 64 hidden units of sigma_net.0
+    }
+    const int row = 16 * d.nb + i;
+    if (row >= d.n_true) return 0.f;
+    int col = -1;
+    if (d.kind == K_ENC) col = 8 * g + e;
+    else if (d.kind == K_H) col = kh;
+    else {      // K_GEO / K_SHGEO: slots 0-3 = the lane's four rows of sigma_net.1's output (row 0 is sigma: no weight)
+        if (e < 4) { const int rr = 4 * g + e; col = rr >= 1 ? (d.kind == K_SHGEO ? 16 : 0) + rr - 1 : -1; }
+        else if (d.kind == K_SHGEO) col = 4 * g + (e - 4);                  // spherical-harmonics components 4g .. 4g+3
+    }
+    if (col < 0 || col >= d.ld) return 0.f;
+    return W[d.w_off + row * d.ld + col];
+}
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void to_b(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { unsigned h, l; split_pair(v[2 * w], v[2 * w + 1], h, l); hi[w] = h; lo[w] = l; }
+}
+__device__ __forceinline__ f32x4 mfma3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), __builtin_bit_cast(h8, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bl), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bh), c, 0, 0, 0);
+}
+
+extern __shared__ __attribute__((aligned(16))) char smem_mf[];
+
+__device__ __forceinline__ void read_pair(int id, int lane, u32x4& ah, u32x4& al) {
+    const char* p = smem_mf + id * PAIR_B + lane * 16;
+    ah = *(const u32x4*)p;
+    al = *(const u32x4*)(p + 1024);
+}
+
+// One Linear for the NG groups of a wave: NB row blocks, NTK k-steps, tiles id0 .. in T-major order (id0 + T*NB + nb)
+template <int NB, int NTK>
+__device__ __forceinline__ void layer(int id0, int lane, const u32x4 (&bh)[NG][NTK], const u32x4 (&bl)[NG][NTK], f32x4 (&acc)[NG][NB]) {
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[gi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NTK; ++T)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            u32x4 ah, al;
+            read_pair(id0 + T * NB + nb, lane, ah, al);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) acc[gi][nb] = mfma3(ah, al, bh[gi][T], bl[gi][T], acc[gi][nb]);
+        }
+}
+// accumulators of 2*NTK row blocks -> the next layer's NTK B operands (ACT: 0 none, 1 relu, 2 leaky relu 0.01 with bias)
+template <int NTK, int ACT>
+__device__ __forceinline__ void next_b(const f32x4 (&acc)[NG][2 * NTK], u32x4 (&bh)[NG][NTK], u32x4 (&bl)[NG][NTK], const float* bias4) {
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+        for (int T = 0; T < NTK; ++T) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = acc[gi][2 * T + (e >> 2)][e & 3];
+                if (ACT == 2) { a += bias4[4 * (2 * T + (e >> 2)) + (e & 3)]; a = a > 0.f ? a : 0.01f * a; }
+                v[e] = ACT == 1 ? fmaxf(a, 0.f) : a;
+            }
+            to_b(v, bh[gi][T], bl[gi][T]);
+        }
+}
+
+// A lane's levels depend on its lane group: their parameters live in registers (kernel arguments cannot be indexed per
+// lane).  Level kinds here: dense, or hashed with a power-of-two size (a mask); a hashed level of any other size needs an
+// integer modulo per corner -- mnrf_tcnn_forward sends such configurations to the VALU kernel.
+struct LevelP { float scale; unsigned res, off0, hmask; bool dense; };
+template <bool GRAD>
+__device__ __forceinline__ void encode_level_p(const float* table, const LevelP& L, const float (&u)[3], bool oob, float& a0, float& a1,
+                                               float (&g0)[3], float (&g1)[3]) {
+    const float2* tab = (const float2*)table + L.off0;
+    unsigned pg[3];
+    float fr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pos = (oob ? 0.5f : u[a]) * L.scale + 0.5f;
+        const float fl = floorf(pos);
+        pg[a] = (unsigned)fl;
+        fr[a] = pos - fl;
+    }
+    const float in_box = oob ? 0.f : 1.f;
+    a0 = 0.f; a1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g0[a] = 0.f; g1[a] = 0.f; }
+    const unsigned r1 = L.res + 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
+        const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
+        const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
+        const unsigned x = pg[0] + (c & 1), y = pg[1] + ((c >> 1) & 1), z = pg[2] + ((c >> 2) & 1);
+        const unsigned lin = x + r1 * (y + r1 * z);
+        const unsigned hsh = ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & L.hmask;
+        const float2 v = tab[L.dense ? lin : hsh];
+        const float w = wx * wy * wz * in_box;
+        a0 += w * v.x; a1 += w * v.y;
+        if (GRAD) {
+            const float sx = ((c & 1) ? L.scale : -L.scale) * wy * wz * in_box;
+            const float sy = ((c & 2) ? L.scale : -L.scale) * wx * wz * in_box;
+            const float sz = ((c & 4) ? L.scale : -L.scale) * wx * wy * in_box;
+            g0[0] += sx * v.x; g1[0] += sx * v.y;
+            g0[1] += sy * v.x; g1[1] += sy * v.y;
+            g0[2] += sz * v.x; g1[2] += sz * v.y;
+        }
+    }
+}
+
+template <bool SIGMA_ONLY, bool GRAD>
+__global__ __launch_bounds__(64 * WAVES, GRAD ? 2 : 3) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    // ---- weight tiles (hi | lo) and the few fp32 rows used outside the GEMMs
+    {
+        constexpr int NT = GRAD ? NT_ALL : NT_FWD;
+        for (int q = tid; q < NT * 512; q += 64 * WAVES) {   // one (tile, lane, half) per step
+            const int id = q >> 9, l = (q >> 3) & 63, e = q & 7;
+            const float w = tile_value(A.weights, id, l, e);
+            const _Float16 hi = (_Float16)w;
+            _Float16* dst = (_Float16*)(smem_mf + id * PAIR_B + l * 16) + e;
+            dst[0] = hi;
+            dst[512] = (_Float16)(w - (float)hi);
+        }
+        float* ws1 = (float*)(smem_mf + LDS_WS1);
+        if (tid < 64) ws1[tid] = A.weights[W_S1 + tid];
+        if (tid < 32) ws1[64 + tid] = A.weights[B_M0 + tid];
+        if (tid == 0) ws1[96] = A.weights[B_M1];
+    }
+    __syncthreads();
+    const float* ws1 = (const float*)(smem_mf + LDS_WS1);
+    LevelP lvl[4];                          // levels 4g .. 4g+3 (static indices into the argument arrays, selected per lane)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lvl[q] = LevelP{0.f, 0u, 0u, 0u, true};
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv)
+            if (lv == 4 * g + q)
+                lvl[q] = LevelP{A.scale[lv], A.res[lv], A.off[lv], A.off[lv + 1] - A.off[lv] - 1u, A.mode[lv] == 0u};
+    }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        long long idx[NG];
+        bool live[NG];
+        float u[NG][3];
+        bool oob[NG];
+        u32x4 eh[NG][1], el[NG][1];
+        // ---- positions and the lane's four levels of the encoding
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            long long i = (long long)tile * TILE + wave * (NG * 16) + gi * 16 + j;
+            live[gi] = i < A.B;
+            if (!live[gi]) i = A.B - 1;
+            idx[gi] = i;
+            float x[3];
+            if (A.xyz) {
+                const float* p = A.xyz + i * A.xyz_stride;
+                x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+            } else {
+                const float* r = A.rays + (i / A.spr) * 8;
+                const float z = A.z_vals[i];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) x[a] = r[a] + r[3 + a] * z;
+            }
+            oob[gi] = false;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                u[gi][a] = (x[a] + A.bound) / (2.f * A.bound);
+                oob[gi] |= u[gi][a] < 0.f || u[gi][a] > 1.f;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            float f8[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float g0[3], g1[3];
+                encode_level_p<false>(A.table, lvl[q], u[gi], oob[gi], f8[2 * q], f8[2 * q + 1], g0, g1);
+            }
+            to_b(f8, eh[gi][0], el[gi][0]);
+        }
+        // ---- sigma net: 32 -> 64 (ReLU) -> 16
+        unsigned relu_bits[NG];
+        u32x4 sh_[NG][2], sl_[NG][2];
+        {
+            f32x4 acc[NG][4];
+            layer<4, 1>(0, lane, eh, el, acc);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                unsigned m = 0;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m |= (unsigned)(acc[gi][nb][r] > 0.f) << (4 * nb + r);
+                relu_bits[gi] = m;
+            }
+            next_b<2, 1>(acc, sh_, sl_, nullptr);
+        }
+        f32x4 s1[NG][1];      // row 0 = sigma (lane group 0, register 0), rows 1..15 = geo_feat
+        layer<1, 2>(4, lane, sh_, sl_, s1);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (!live[gi]) continue;
+            if (A.sigma && g == 0) A.sigma[idx[gi]] = s1[gi][0][0];
+            if (A.geo_feat) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * g + r;
+                    if (row >= 1) A.geo_feat[idx[gi] * 15 + row - 1] = s1[gi][0][r];
+                }
+            }
+        }
+        if (GRAD && A.normal) {
+            // d sigma / d features through the transposed sigma_net.0, then the derivative gathers of the lane's levels
+            u32x4 gh[NG][2], gl[NG][2];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int nb = 2 * T + (e >> 2), r = e & 3;
+                        v[e] = ((relu_bits[gi] >> (4 * nb + r)) & 1u) ? ws1[16 * nb + 4 * g + r] : 0.f;
+                    }
+                    to_b(v, gh[gi][T], gl[gi][T]);
+                }
+            f32x4 ge[NG][2];
+            layer<2, 2>(29, lane, gh, gl, ge);
+            const float sc = 1.f / (2.f * A.bound);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                float gd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a0, a1, g0[3], g1[3];
+                    encode_level_p<true>(A.table, lvl[q], u[gi], oob[gi], a0, a1, g0, g1);
+                    const float e0 = ge[gi][q >> 1][2 * (q & 1)], e1 = ge[gi][q >> 1][2 * (q & 1) + 1];     // features 8g + 2q, 8g + 2q + 1
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) gd[a] += e0 * g0[a] + e1 * g1[a];
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { gd[a] += __shfl_xor(gd[a], 16); gd[a] += __shfl_xor(gd[a], 32); }
+                const float n0 = -gd[0] * sc, n1 = -gd[1] * sc, n2 = -gd[2] * sc;
+                const float inv = 1.f / sqrtf(fmaxf(n0 * n0 + n1 * n1 + n2 * n2, EPS32));
+                if (live[gi] && g == 0) { float* o = A.normal + idx[gi] * 3; o[0] = n0 * inv; o[1] = n1 * inv; o[2] = n2 * inv; }
+            }
+        }
+        // ---- B operand of the three heads that read geo_feat: slots 0-3 = the lane's rows of sigma_net.1's output
+        u32x4 qh[NG][1], ql[NG][1];
+        if (A.pred_normal || !SIGMA_ONLY) {
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const float v[8] = {s1[gi][0][0], s1[gi][0][1], s1[gi][0][2], s1[gi][0][3], 0.f, 0.f, 0.f, 0.f};
+                to_b(v, qh[gi][0], ql[gi][0]);
+            }
+        }
+        // ---- predicted normal: 15 -> 64 (ReLU) -> 3, l2-normalised
+        if (A.pred_normal) {
+            u32x4 nh[NG][2], nl[NG][2];
+            {
+                f32x4 acc[NG][4];
+                layer<4, 1>(6, lane, qh, ql, acc);
+                next_b<2, 1>(acc, nh, nl, nullptr);
+            }
+            f32x4 o3[NG][1];
+            layer<1, 2>(10, lane, nh, nl, o3);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const float v0 = o3[gi][0][0], v1 = o3[gi][0][1], v2 = o3[gi][0][2];
+                const float inv = 1.f / sqrtf(fmaxf(v0 * v0 + v1 * v1 + v2 * v2, EPS32));
+                if (live[gi] && g == 0) { float* o = A.pred_normal + idx[gi] * 3; o[0] = v0 * inv; o[1] = v1 * inv; o[2] = v2 * inv; }
+            }
+        }
+        if (SIGMA_ONLY) continue;
+        // ---- mirror probability: 15 -> 32 LeakyReLU(0.01) -> 1 sigmoid, with biases
+        if (A.is_mirror) {
+            u32x4 mh[NG][1], ml[NG][1];
+            {
+                f32x4 acc[NG][2];
+                layer<2, 1>(12, lane, qh, ql, acc);
+                float b4[8];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b4[4 * nb + r] = ws1[64 + 16 * nb + 4 * g + r];
+                next_b<1, 2>(acc, mh, ml, b4);
+            }
+            f32x4 o1[NG][1];
+            layer<1, 1>(14, lane, mh, ml, o1);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+                if (live[gi] && g == 0) A.is_mirror[idx[gi]] = 1.f / (1.f + expf(-(o1[gi][0][0] + ws1[96])));
+        }
+        // ---- colour: cat[SH4(d), geo_feat] -> 64 -> 64 -> 3 sigmoid; slots 4-7 = SH components 4g .. 4g+3
+        if (A.rgb) {
+            u32x4 ch[NG][1], cl[NG][1];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const float* dp;
+                if (A.xyz) dp = A.xyz + idx[gi] * A.xyz_stride + 3;
+                else { const long long ray = idx[gi] / A.spr; dp = A.dirs ? A.dirs + ray * A.dir_stride : A.rays + ray * 8 + 3; }
+                const float X = dp[0], Y = dp[1], Z = dp[2];
+                const float xy = X * Y, xz = X * Z, yz = Y * Z, x2 = X * X, y2 = Y * Y, z2 = Z * Z;
+                float sh4[4];
+                if (g == 0) {
+                    sh4[0] = 0.28209479177387814f; sh4[1] = -0.48860251190291987f * Y;
+                    sh4[2] = 0.48860251190291987f * Z; sh4[3] = -0.48860251190291987f * X;
+                } else if (g == 1) {
+                    sh4[0] = 1.0925484305920792f * xy; sh4[1] = -1.0925484305920792f * yz;
+                    sh4[2] = 0.94617469575755997f * z2 - 0.31539156525251999f; sh4[3] = -1.0925484305920792f * xz;
+                } else if (g == 2) {
+                    sh4[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; sh4[1] = 0.59004358992664352f * Y * (-3.0f * x2 + y2);
+                    sh4[2] = 2.8906114426405538f * xy * Z; sh4[3] = 0.45704579946446572f * Y * (1.0f - 5.0f * z2);
+                } else {
+                    sh4[0] = 0.3731763325901154f * Z * (5.0f * z2 - 3.0f); sh4[1] = 0.45704579946446572f * X * (1.0f - 5.0f * z2);
+                    sh4[2] = 1.4453057213202769f * Z * (x2 - y2); sh4[3] = 0.59004358992664352f * X * (-x2 + 3.0f * y2);
+                }
+                const float v[8] = {s1[gi][0][0], s1[gi][0][1], s1[gi][0][2], s1[gi][0][3], sh4[0], sh4[1], sh4[2], sh4[3]};
+                to_b(v, ch[gi][0], cl[gi][0]);
+            }
+            u32x4 h1[NG][2], l1[NG][2];
+            {
+                f32x4 acc[NG][4];
+                layer<4, 1>(15, lane, ch, cl, acc);
+                next_b<2, 1>(acc, h1, l1, nullptr);
+            }
+            u32x4 h2[NG][2], l2[NG][2];
+            {
+                f32x4 acc[NG][4];
+                layer<4, 2>(19, lane, h1, l1, acc);
+                next_b<2, 1>(acc, h2, l2, nullptr);
+            }
+            f32x4 o3[NG][1];
+            layer<1, 2>(27, lane, h2, l2, o3);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+                if (live[gi] && g == 0) {
+                    float* o = A.rgb + idx[gi] * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) o[k] = 1.f / (1.f + expf(-o3[gi][0][k]));
+                }
+        }
+    }
+}
+
+}  // namespace mf
 
 // ------------------------------------------------------------------------------------------------------------
 // Backward of the hash-grid field (training of config 5; autograd equivalent of loss.backward() through
@@ -929,9 +1348,36 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     A.off[NL] = (unsigned)offsets17_host[NL];
     level_modes(A);
     A.sigma = sigma; A.rgb = rgb; A.pred_normal = pred_normal; A.is_mirror = is_mirror; A.normal = normal; A.geo_feat = geo_feat;
+    hipStream_t s = (hipStream_t)stream;
+    // MLPs on the matrix pipe (default); MNRF_TCNN_VALU=1 selects the one-thread-per-sample VALU kernel (A/B measurements)
+    static const bool env_valu = [] { const char* e = getenv("MNRF_TCNN_VALU"); return e && e[0] == '1'; }();
+    bool any_modulo = false;
+    for (int l = 0; l < NL; ++l) any_modulo |= A.mode[l] == 2u;
+    // The matrix-pipe kernel pays for the rest of the network (3.35 vs 5.46 ms per 6.29 M full samples); a sigma-only launch
+    // is gathers + 3 k MACs and stays on the VALU kernel (0.96 vs 1.15 ms per 2.1 M), as do tables with a hashed level whose
+    // size is not a power of two (integer modulo per corner).
+    static const bool env_sig = [] { const char* e = getenv("MNRF_TCNN_MFMA_SIGMA"); return e && e[0] == '1'; }();   // A/B knob
+    const bool valu = env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !grad && !env_sig);
+    if (!valu) {
+        const long long n_tiles = (B + mf::TILE - 1) / mf::TILE;
+        if (n_tiles > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            return true;
+        }();
+        (void)attr;
+        const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two 6-wave workgroups per CU
+        if (sigma_only && !grad) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<true, false>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        else if (sigma_only) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<true, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        else if (!grad) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<false, false>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        else hipLaunchKernelGGL((mf::tcnn_mfma_kernel<false, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        return mnrf_check_launch("mnrf_tcnn_forward");
+    }
     const dim3 grid((unsigned)((B + TPB - 1) / TPB)), block(TPB);
     const size_t lds = (VEC_OFF + 64 * TPB) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     if (sigma_only && !grad) hipLaunchKernelGGL((tcnn_kernel<true, false>), grid, block, lds, s, A);
     else if (sigma_only) hipLaunchKernelGGL((tcnn_kernel<true, true>), grid, block, lds, s, A);
     else if (!grad) hipLaunchKernelGGL((tcnn_kernel<false, false>), grid, block, lds, s, A);

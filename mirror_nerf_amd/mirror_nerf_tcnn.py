@@ -190,14 +190,24 @@ class MirrorNeRFTcnn(nn.Module):
         if want_geo:
             out["geo_feat"] = f(B, 15)
         flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
+        if getattr(self, "mlp_on_valu", False):     # the fp32 VALU kernel instead of hi/lo f16 tiles on the matrix pipe (~1e-6 apart)
+            flags |= _lib.MNRF_TCNN_VALU
         offs = _offsets17(self.cfg)
         p = _lib.ptr
+        from . import mirror_nerf as _mn
+        log = _mn.LAUNCH_LOG if B else None
+        if log is not None:      # bench.py: kernel time from events on the launching stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_forward(
                 p(table.contiguous()), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
                 p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3,
                 p(out["sigma"]), p(out.get("rgb")), p(out["pred_normal"]), p(out.get("is_mirror")), p(out.get("normal")),
                 p(out.get("geo_feat")), _lib.stream()), "mnrf_tcnn_forward")
+        if log is not None:
+            e1.record()
+            log.append((flags | 0x1000, B, e0, e1))       # 0x1000: hash-grid field
         return out
 
     def forward(self, x, compute_normal=True, sigma_only=False, embedding_xyz=None, embedding_dir=None,

