@@ -383,26 +383,26 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
 //     paid once per ~24 000 samples.  A tile pair is read once per four groups: 66 KiB of LDS reads per 64 samples.
 //   * 29 tile pairs x 3 products x 4 groups = 348 MFMAs per 64 samples: 0.25 ms of matrix-pipe time per 6.29 M-sample
 //     launch -- the kernel is left with its 128 gathers per sample.
-//   * GRAD: d sigma / d features = W_s0^T (relu' * W_s1[0,:]) as one more transposed product (4 tile pairs) whose output
-//     rows are ordered so that lane g receives features 8g .. 8g+7; they go back through the LDS area to the sample's lane,
-//     which runs the second gather pass with the interpolation-weight derivatives (phase 3).
+//   * Launches that also want the density-gradient normal (a second gather pass) or sigma only stay on tcnn_kernel: measured
+//     per 6.29 M samples, full + normal 7.8 (this structure, spilling at 256 registers) vs 7.1 ms, sigma only 1.11 vs 0.98 ms
+//     per 2.1 M; the full evaluation without the normal -- the fine pass of every eval render -- 2.83 vs 5.46 ms.
 namespace mf {
 
 constexpr int WAVES = 6;                            // 2 workgroups x 6 waves per CU: 3 waves per SIMD at <= 168 registers
 constexpr int NG = 2;                               // groups of 16 samples per wave iteration (4: 800 B/lane of spills at 256 registers)
 constexpr int TILE = WAVES * NG * 16;               // samples per workgroup iteration
-constexpr int NT_FWD = 29, NT_ALL = 33;             // tile pairs (the last four: W_s0^T for the density gradient)
+constexpr int NT_FWD = 29;                          // tile pairs
 constexpr int PAIR_B = 2048;
-constexpr int LDS_TILES = NT_ALL * PAIR_B;          // 66 KiB
+constexpr int LDS_TILES = NT_FWD * PAIR_B;          // 58 KiB
 constexpr int LDS_WS1 = LDS_TILES;                  // sigma_net.1 row 0 (64 floats) + mirror biases (33 floats)
 constexpr int LDS_BYTES = LDS_WS1 + 128 * 4;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-enum Kind : int { K_ENC = 0, K_H = 1, K_GEO = 2, K_SHGEO = 3, K_TRANS = 4 };
+enum Kind : int { K_ENC = 0, K_H = 1, K_GEO = 2, K_SHGEO = 3 };
 struct TileDesc { short w_off, n_true, ld, nb, T, kind; };
-// consumption order of the forward: S0 (4), S1 (2), N0 (4), N1 (2), M0 (2), M1 (1), C0 (4), C1 (8: T-major), C2 (2); then S0^T (4)
+// consumption order: S0 (4), S1 (2), N0 (4), N1 (2), M0 (2), M1 (1), C0 (4), C1 (8: T-major), C2 (2)
 __device__ __forceinline__ TileDesc tile_desc(int id) {
     if (id < 4) return TileDesc{W_S0, 64, 32, (short)id, 0, K_ENC};
     if (id < 6) return TileDesc{W_S1, 16, 64, 0, (short)(id - 4), K_H};
@@ -412,18 +412,13 @@ __device__ __forceinline__ TileDesc tile_desc(int id) {
     if (id < 15) return TileDesc{W_M1, 1, 32, 0, 0, K_H};
     if (id < 19) return TileDesc{W_C0, 64, 32, (short)(id - 15), 0, K_SHGEO};
     if (id < 27) return TileDesc{W_C1, 64, 64, (short)((id - 19) & 3), (short)((id - 19) >> 2), K_H};
-    if (id < 29) return TileDesc{W_C2, 3, 64, 0, (short)(id - 27), K_H};
-    return TileDesc{W_S0, 64, 32, (short)((id - 29) & 1), (short)((id - 29) >> 1), K_TRANS};
+    return TileDesc{W_C2, 3, 64, 0, (short)(id - 27), K_H};
 }
 // element (lane, e) of the A operand of a tile: W[row 16 nb + (lane & 15)][column of slot (T, lane >> 4, e)]
 __device__ __forceinline__ float tile_value(const float* W, int id, int lane, int e) {
     const TileDesc d = tile_desc(id);
     const int i = lane & 15, g = lane >> 4;
     const int kh = 32 * d.T + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));      // slot -> previous layer's row (K_H)
-    if (d.kind == K_TRANS) {
-        const int feat = 8 * (i >> 2) + 4 * d.nb + (i & 3);     // output row 16 nb + i delivers this encoding feature
-        return W[W_S0 + kh * 32 + feat];                        // contraction over the 64 hidden units of sigma_net.0
-    }
     const int row = 16 * d.nb + i;
     if (row >= d.n_true) return 0.f;
     int col = -1;
@@ -540,13 +535,12 @@ __device__ __forceinline__ void encode_level_p(const float* table, const LevelP&
     }
 }
 
-template <bool SIGMA_ONLY, bool GRAD>
-__global__ __launch_bounds__(64 * WAVES, GRAD ? 2 : 3) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
+__global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     // ---- weight tiles (hi | lo) and the few fp32 rows used outside the GEMMs
     {
-        constexpr int NT = GRAD ? NT_ALL : NT_FWD;
+        constexpr int NT = NT_FWD;
         for (int q = tid; q < NT * 512; q += 64 * WAVES) {   // one (tile, lane, half) per step
             const int id = q >> 9, l = (q >> 3) & 63, e = q & 7;
             const float w = tile_value(A.weights, id, l, e);
@@ -612,20 +606,10 @@ __global__ __launch_bounds__(64 * WAVES, GRAD ? 2 : 3) void tcnn_mfma_kernel(Tcn
             to_b(f8, eh[gi][0], el[gi][0]);
         }
         // ---- sigma net: 32 -> 64 (ReLU) -> 16
-        unsigned relu_bits[NG];
         u32x4 sh_[NG][2], sl_[NG][2];
         {
             f32x4 acc[NG][4];
             layer<4, 1>(0, lane, eh, el, acc);
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                unsigned m = 0;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m |= (unsigned)(acc[gi][nb][r] > 0.f) << (4 * nb + r);
-                relu_bits[gi] = m;
-            }
             next_b<2, 1>(acc, sh_, sl_, nullptr);
         }
         f32x4 s1[NG][1];      // row 0 = sigma (lane group 0, register 0), rows 1..15 = geo_feat
@@ -642,45 +626,9 @@ __global__ __launch_bounds__(64 * WAVES, GRAD ? 2 : 3) void tcnn_mfma_kernel(Tcn
                 }
             }
         }
-        if (GRAD && A.normal) {
-            // d sigma / d features through the transposed sigma_net.0, then the derivative gathers of the lane's levels
-            u32x4 gh[NG][2], gl[NG][2];
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi)
-#pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int nb = 2 * T + (e >> 2), r = e & 3;
-                        v[e] = ((relu_bits[gi] >> (4 * nb + r)) & 1u) ? ws1[16 * nb + 4 * g + r] : 0.f;
-                    }
-                    to_b(v, gh[gi][T], gl[gi][T]);
-                }
-            f32x4 ge[NG][2];
-            layer<2, 2>(29, lane, gh, gl, ge);
-            const float sc = 1.f / (2.f * A.bound);
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                float gd[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a0, a1, g0[3], g1[3];
-                    encode_level_p<true>(A.table, lvl[q], u[gi], oob[gi], a0, a1, g0, g1);
-                    const float e0 = ge[gi][q >> 1][2 * (q & 1)], e1 = ge[gi][q >> 1][2 * (q & 1) + 1];     // features 8g + 2q, 8g + 2q + 1
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) gd[a] += e0 * g0[a] + e1 * g1[a];
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { gd[a] += __shfl_xor(gd[a], 16); gd[a] += __shfl_xor(gd[a], 32); }
-                const float n0 = -gd[0] * sc, n1 = -gd[1] * sc, n2 = -gd[2] * sc;
-                const float inv = 1.f / sqrtf(fmaxf(n0 * n0 + n1 * n1 + n2 * n2, EPS32));
-                if (live[gi] && g == 0) { float* o = A.normal + idx[gi] * 3; o[0] = n0 * inv; o[1] = n1 * inv; o[2] = n2 * inv; }
-            }
-        }
         // ---- B operand of the three heads that read geo_feat: slots 0-3 = the lane's rows of sigma_net.1's output
         u32x4 qh[NG][1], ql[NG][1];
-        if (A.pred_normal || !SIGMA_ONLY) {
+        {
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 const float v[8] = {s1[gi][0][0], s1[gi][0][1], s1[gi][0][2], s1[gi][0][3], 0.f, 0.f, 0.f, 0.f};
@@ -704,7 +652,6 @@ __global__ __launch_bounds__(64 * WAVES, GRAD ? 2 : 3) void tcnn_mfma_kernel(Tcn
                 if (live[gi] && g == 0) { float* o = A.pred_normal + idx[gi] * 3; o[0] = v0 * inv; o[1] = v1 * inv; o[2] = v2 * inv; }
             }
         }
-        if (SIGMA_ONLY) continue;
         // ---- mirror probability: 15 -> 32 LeakyReLU(0.01) -> 1 sigmoid, with biases
         if (A.is_mirror) {
             u32x4 mh[NG][1], ml[NG][1];
@@ -1353,27 +1300,20 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     static const bool env_valu = [] { const char* e = getenv("MNRF_TCNN_VALU"); return e && e[0] == '1'; }();
     bool any_modulo = false;
     for (int l = 0; l < NL; ++l) any_modulo |= A.mode[l] == 2u;
-    // The matrix-pipe kernel pays for the rest of the network (3.35 vs 5.46 ms per 6.29 M full samples); a sigma-only launch
-    // is gathers + 3 k MACs and stays on the VALU kernel (0.96 vs 1.15 ms per 2.1 M), as do tables with a hashed level whose
-    // size is not a power of two (integer modulo per corner).
-    static const bool env_sig = [] { const char* e = getenv("MNRF_TCNN_MFMA_SIGMA"); return e && e[0] == '1'; }();   // A/B knob
-    const bool valu = env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !grad && !env_sig);
+    // The matrix-pipe kernel takes the full evaluations without the density-gradient normal (see its header for the
+    // measurements); everything else, and tables with a hashed level whose size is not a power of two (integer modulo per
+    // corner), stays on the VALU kernel.
+    const bool valu = env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || sigma_only || grad;
     if (!valu) {
         const long long n_tiles = (B + mf::TILE - 1) / mf::TILE;
         if (n_tiles > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
         static const bool attr = [] {
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             return true;
         }();
         (void)attr;
         const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two 6-wave workgroups per CU
-        if (sigma_only && !grad) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<true, false>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
-        else if (sigma_only) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<true, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
-        else if (!grad) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<false, false>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
-        else hipLaunchKernelGGL((mf::tcnn_mfma_kernel<false, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        hipLaunchKernelGGL(mf::tcnn_mfma_kernel, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
         return mnrf_check_launch("mnrf_tcnn_forward");
     }
     const dim3 grid((unsigned)((B + TPB - 1) / TPB)), block(TPB);
