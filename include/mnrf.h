@@ -249,15 +249,18 @@ int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double 
  * d_table (entries,2) and d_weights (mnrf_tcnn_weight_floats() floats, the layout of `weights`; padded columns
  * receive zeros): the caller zero-initialises both, and `workspace` (mnrf_tcnn_backward_workspace_floats() floats:
  * private per-XCD copies of the coarse levels' gradient, folded into d_table at the end; null = none).  Optional outputs d_xyz (B,3) = dL/d position, d_dir (B,3) =
- * dL/d raw direction.  Nothing is saved by the forward: the kernel re-evaluates each tile.  First order only: no
- * gradient is propagated through the density-gradient normal (`normal` of the forward). */
+ * dL/d raw direction.  Nothing is saved by the forward: the kernel re-evaluates each tile.
+ * g_normal (B,3) or null: dL/d(`normal` of the forward, the normalised density gradient).  When given, a second kernel
+ * adds the SECOND-ORDER term -- the gradient that reaches the table, sigma_net and the position through
+ * normal = l2n(-d sigma/dx), i.e. what autograd.grad(sigma, x, create_graph=True) propagates in
+ * models/mirror_nerf_tcnn.py:172-218 / utils/func.py:10-25 -- to d_table, d_weights and d_xyz. */
 int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host);
 int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                        int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
                        int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
-                       const float* g_is_mirror, float* workspace, float* d_table, float* d_weights, float* d_xyz,
-                       float* d_dir, void* stream);
+                       const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                       float* d_weights, float* d_xyz, float* d_dir, void* stream);
 
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,

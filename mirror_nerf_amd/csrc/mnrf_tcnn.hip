@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
 // ds_read_b128 pass hit 16 different bank quads.  Activation gradients go through the same rows: dX = W^T G is a loop over
 // the rows of G (wave-uniform weight rows from LDS, as in the forward).  At the end every workgroup adds its tiles to the
 // gradient blob (<= 256 atomic adds per weight); the table gradient is scattered with global_atomic_add_f32 like the
-// reference does.  First-order only: the density-gradient normal is a constant of the graph here.
+// reference does.  This kernel is the first-order part; tcnn_bwd2_kernel adds the term through the density-gradient normal.
 constexpr int BT = 256;                         // samples per tile = threads
 constexpr int RS = BT + 4;                      // row stride (floats)
 constexpr int XO = BWD_W_FLOATS;                     // X rows: 64
@@ -752,6 +752,7 @@ constexpr int BWD_LDS_FLOATS = GO + 32 * RS;
 struct TcnnBwdArgs {
     TcnnArgs f;                                  // inputs as in the forward (outputs unused)
     const float* g_sigma; const float* g_rgb; const float* g_pn; const float* g_m;   // dL/d outputs, any may be null
+    const float* g_normal;                       // dL/d (density-gradient normal), (B,3) or null: second-order pass (tcnn_bwd2_kernel)
     float* d_table;                              // (entries, 2), zero-initialised by the caller; accumulated
     float* d_weights;                            // W_TOTAL floats, zero-initialised by the caller; accumulated
     float* d_xyz;                                // (B,3) or null
@@ -847,6 +848,43 @@ __device__ __forceinline__ void sh4_backward(const float (&d)[3], const float* g
             + h * (1.f - 5.f * z2) * g[11] - 2.f * m * Y * Z * g[14] + 6.f * f * X * Y * g[15];
     gd[2] = a * g[2] - b * Y * g[5] + 2.f * c * Z * g[6] - b * X * g[7] + gg * X * Y * g[10] - 10.f * h * Y * Z * g[11]
             + k * (15.f * z2 - 3.f) * g[12] - 10.f * h * X * Z * g[13] + m * (x2 - y2) * g[14];
+}
+
+// Table-gradient scatter of one level for this thread's sample: v0[c], v1[c] = the two feature gradients at corner c.
+// Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): on levels whose cell
+// key fits 3 x 10 bits each run of lanes with equal cell is summed into its first lane (segmented suffix sum, 6 shuffle
+// steps) and only that lane scatters.  Every lane of the wave must call it (shuffles).
+__device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, const unsigned (&pg)[3], float (&v0)[8], float (&v1)[8],
+                                                bool active, int lane, float* dtab, unsigned hsize, unsigned res) {
+    const TcnnArgs& A = P.f;
+    bool head = true;
+    if (lv < P.agg_levels) {
+        const unsigned key = pg[0] | (pg[1] << 10) | (pg[2] << 20);          // (agg_levels: res < 1024)
+        const unsigned prev = __shfl_up(key, 1);
+        const int prev_active = __shfl_up((int)active, 1);
+        head = !(lane > 0 && active && prev_active && prev == key);
+        const unsigned long long heads = __ballot(head);
+        const int run = __popcll(heads & (~0ull >> (63 - lane)));
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int run_d = __shfl_down(run, dlt);          // (every lane executes the shuffle: no short circuit)
+            const bool ok = (lane + dlt < 64) & (run_d == run);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float t0 = __shfl_down(v0[c], dlt), t1 = __shfl_down(v1[c], dlt);
+                v0[c] += ok ? t0 : 0.f;
+                v1[c] += ok ? t1 : 0.f;
+            }
+        }
+    }
+    if (active && head && !P.exp_noscatter) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
+            fadd(dtab + 2ll * idx, v0[c]);
+            fadd(dtab + 2ll * idx + 1, v1[c]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
@@ -1159,37 +1197,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                     gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
                 }
             }
-            bool head = true;
-            if (lv < P.agg_levels) {
-                // Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): sum each
-                // run of lanes with equal cell into its first lane (segmented suffix sum, 6 shuffle steps) and let only
-                // that lane scatter.
-                const unsigned key = pg[0] | (pg[1] << 10) | (pg[2] << 20);          // (agg_levels: res < 1024)
-                const unsigned prev = __shfl_up(key, 1);
-                const int prev_active = __shfl_up((int)active, 1);
-                head = !(lane > 0 && active && prev_active && prev == key);
-                const unsigned long long heads = __ballot(head);
-                const int run = __popcll(heads & (~0ull >> (63 - lane)));
-#pragma unroll
-                for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                    const int run_d = __shfl_down(run, dlt);          // (every lane executes the shuffle: no short circuit)
-                    const bool ok = (lane + dlt < 64) & (run_d == run);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float t0 = __shfl_down(v0[c], dlt), t1 = __shfl_down(v1[c], dlt);
-                        v0[c] += ok ? t0 : 0.f;
-                        v1[c] += ok ? t1 : 0.f;
-                    }
-                }
-            }
-            if (active && head && !P.exp_noscatter) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
-                    fadd(dtab + 2ll * idx, v0[c]);
-                    fadd(dtab + 2ll * idx + 1, v1[c]);
-                }
-            }
+            scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
         }
         if (P.d_xyz && live) {
             const float s = 1.f / (2.f * A.bound);
@@ -1217,6 +1225,179 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) db_m1 += __shfl_xor(db_m1, o);
     if (lane == 0) fadd(D + B_M1, db_m1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Second-order term: the gradient that reaches the table, sigma_net and x through  normal = l2n(-J),
+// J = d sigma / dx = s * sum_f genc_f * dfeat_f/du   (s = 1 / (2 bound), u = the [0,1] coordinates),
+// genc = W_s0^T (m . w1): m = ReLU mask of sigma_net.0, w1 = row 0 of sigma_net.1 -- what autograd.grad(sigma, x,
+// create_graph=True) differentiates in models/mirror_nerf_tcnn.py:172-218 (utils/func.py:10-25).  With J^ = dL/dJ:
+//   * table:        dL/dT[idx_c][ch] += s * genc_{lv,ch} * sum_a J^_a dw_c/du_a          (a scatter like the first-order one)
+//   * sigma_net.0:  dL/dW_s0[k][f]   += (m_k w1_k) * Df_f,   Df_f = s * sum_a J^_a dfeat_f/du_a   (feature tangent along J^)
+//   * sigma_net.1:  dL/dw1_k         += m_k * (W_s0 Df)_k
+//   * x:            dL/dx_b          += s^2 * sum_{lv,c,ch} genc * T[idx_c][ch] * sum_{a != b} J^_a d2w_c/du_a du_b
+//     (trilinear interpolation: the pure second derivatives vanish inside a cell, the mixed ones do not)
+// One thread per sample, same LDS layout and tile helpers as tcnn_bwd_kernel; three gather passes (features for the mask,
+// derivatives for J, derivatives again for the scatter); runs before tcnn_fold_kernel and ADDS to d_table / d_weights / d_xyz.
+__global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
+    const TcnnArgs& A = P.f;
+    for (int k = threadIdx.x; k < W_TOTAL; k += BT) wlds[k] = A.weights[k];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 t_s0[2] = {z4, z4}, t_s1 = z4;
+    const float sc = 1.f / (2.f * A.bound);
+    const long long ntiles = (A.B + BT - 1) / BT;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        long long i = tile * BT + threadIdx.x;
+        const bool live = i < A.B;
+        if (!live) i = A.B - 1;
+        float x[3];
+        if (A.xyz) {
+            const float* p = A.xyz + i * A.xyz_stride;
+            x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+        } else {
+            const float* r = A.rays + (i / A.spr) * 8;
+            const float z = A.z_vals[i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) x[a] = r[a] + r[3 + a] * z;
+        }
+        float u[3];
+        bool oob = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            u[a] = (x[a] + A.bound) / (2.f * A.bound);
+            oob |= u[a] < 0.f || u[a] > 1.f;
+        }
+        const bool active = live && !oob;
+        // ---- pass 1: features -> ReLU mask of sigma_net.0 -> q = m . w1 -> genc = W_s0^T q
+        unsigned long long bits_h1 = 0;
+        {
+#pragma unroll 1
+            for (int lv = 0; lv < NL; ++lv) {
+                float a0, a1, g0[3], g1[3];
+                encode_level<false>(A, lv, u, oob, a0, a1, g0, g1);
+                XR(2 * lv) = a0;
+                XR(2 * lv + 1) = a1;
+            }
+            float in[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) in[k] = XR(k);
+#pragma unroll 1
+            for (int o = 0; o < 64; ++o) bits_h1 |= (unsigned long long)(dot_row_lds(in, W_S0 + o * 32) > 0.f) << o;
+        }
+        float genc[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) genc[k] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) GR(k) = ((bits_h1 >> (32 * h + k)) & 1ull) ? wlds[W_S1 + 32 * h + k] : 0.f;
+            back_rows<32>(32, W_S0 + 32 * h * 32, genc);      // (own column of GR: no barrier needed)
+        }
+        // ---- pass 2: J, then J^ from dL/dnormal through n = -J / max(|J|, sqrt(eps))
+        float J[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 32; ++k) XR(k) = genc[k];          // (indexed by level below)
+#pragma unroll 1
+        for (int lv = 0; lv < NL; ++lv) {
+            float a0, a1, g0[3], g1[3];
+            encode_level<true>(A, lv, u, oob, a0, a1, g0, g1);
+            const float e0 = XR(2 * lv), e1 = XR(2 * lv + 1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) J[a] += e0 * g0[a] + e1 * g1[a];
+        }
+        float Jh[3];
+        {
+            const float n0 = -J[0] * sc, n1 = -J[1] * sc, n2 = -J[2] * sc;
+            const float sq = n0 * n0 + n1 * n1 + n2 * n2;
+            const float inv = 1.f / sqrtf(fmaxf(sq, EPS32));
+            const float g0 = live ? P.g_normal[i * 3] : 0.f, g1 = live ? P.g_normal[i * 3 + 1] : 0.f, g2 = live ? P.g_normal[i * 3 + 2] : 0.f;
+            // normal = v * inv with v = -s J:  dL/dv = (g - n (n.g)) * inv  (clamped branch: g * inv);  dL/dJ = -s dL/dv
+            float d0 = g0 * inv, d1 = g1 * inv, d2 = g2 * inv;
+            if (sq > EPS32) {
+                const float m0 = n0 * inv, m1 = n1 * inv, m2 = n2 * inv, dt = m0 * g0 + m1 * g1 + m2 * g2;
+                d0 = (g0 - m0 * dt) * inv; d1 = (g1 - m1 * dt) * inv; d2 = (g2 - m2 * dt) * inv;
+            }
+            Jh[0] = -sc * d0; Jh[1] = -sc * d1; Jh[2] = -sc * d2;
+        }
+        // ---- pass 3: feature tangent Df, table scatter, mixed second derivatives for dL/dx
+        float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int lv = 0; lv < NL; ++lv) {
+            const float e0 = active ? XR(2 * lv) : 0.f, e1 = active ? XR(2 * lv + 1) : 0.f;      // genc of this level
+            const float scale = A.scale[lv];
+            const unsigned res = A.res[lv];
+            const unsigned hsize = A.off[lv + 1] - A.off[lv];
+            const float2* tab = (const float2*)A.table + A.off[lv];
+            const bool coarse = P.cp_n[lv] != 0;
+            float* dtab = coarse ? P.copies + P.cp_off[lv] + 2ll * hsize * (blockIdx.x % (unsigned)P.cp_n[lv])
+                                 : P.d_table + 2ll * A.off[lv];
+            unsigned pg[3];
+            float fr[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float pos = u[a] * scale + 0.5f;
+                const float fl = floorf(pos);
+                pg[a] = active ? (unsigned)fl : 0u;
+                fr[a] = pos - fl;
+            }
+            float v0[8], v1[8], df0 = 0.f, df1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wx = (c & 1) ? fr[0] : 1.f - fr[0];
+                const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
+                const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
+                const float sx = (c & 1) ? scale : -scale, sy = (c & 2) ? scale : -scale, sz = (c & 4) ? scale : -scale;
+                // sum_a J^_a dw_c/du_a
+                const float dw = Jh[0] * sx * wy * wz + Jh[1] * sy * wx * wz + Jh[2] * sz * wx * wy;
+                v0[c] = dw * e0;
+                v1[c] = dw * e1;
+                float2 v = float2{0.f, 0.f};
+                if (active) v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
+                df0 += dw * v.x; df1 += dw * v.y;
+                if (P.d_xyz) {
+                    const float ev = e0 * v.x + e1 * v.y;
+                    gx[0] += ev * (Jh[1] * sx * sy * wz + Jh[2] * sx * sz * wy);
+                    gx[1] += ev * (Jh[0] * sx * sy * wz + Jh[2] * sy * sz * wx);
+                    gx[2] += ev * (Jh[0] * sx * sz * wy + Jh[1] * sy * sz * wx);
+                }
+            }
+            GR(2 * lv) = active ? df0 : 0.f;                   // (own column; collected into registers after the loop)
+            GR(2 * lv + 1) = active ? df1 : 0.f;
+            scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
+        }
+        float Df[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) Df[k] = GR(k);
+        if (P.d_xyz && live) {
+            P.d_xyz[i * 3] += gx[0] * sc; P.d_xyz[i * 3 + 1] += gx[1] * sc; P.d_xyz[i * 3 + 2] += gx[2] * sc;
+        }
+        // ---- weight gradients: dW_s0 += q (x) Df over the tile's samples; dw1 += m . (W_s0 Df)
+#pragma unroll 1
+        for (int o = 0; o < 64; ++o) XR(o) = ((bits_h1 >> o) & 1ull) ? dot_row_lds(Df, W_S0 + o * 32) : 0.f;
+        __syncthreads();
+        GR(0) = 1.f;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) GR(k) = 0.f;
+        __syncthreads();
+        dw_tile(t_s1, 0, 16 * wave);                            // row 0 of sigma_net.1 (the other 15 rows of the tile get zeros)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) XR(k) = Df[k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) GR(k) = ((bits_h1 >> (32 * h + k)) & 1ull) ? wlds[W_S1 + 32 * h + k] : 0.f;
+            __syncthreads();
+            dw_tile(t_s0[h], 16 * (wave >> 1), 16 * (wave & 1));       // sigma_net.0 (64 x 32), as in tcnn_bwd_kernel
+            __syncthreads();
+        }
+    }
+    float* D = P.d_weights;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) flush_tile(D, t_s0[h], W_S0, 32, 32 * h + 16 * (wave >> 1), 16 * (wave & 1), 64, 32, -1, 0);
+    flush_tile(D, t_s1, W_S1, 64, 0, 16 * wave, 1, 64, -1, 0);
 }
 #undef XR
 #undef GR
@@ -1335,8 +1516,8 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
                                   int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
                                   int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
-                                  const float* g_is_mirror, float* workspace, float* d_table, float* d_weights, float* d_xyz,
-                                  float* d_dir, void* stream) {
+                                  const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                                  float* d_weights, float* d_xyz, float* d_dir, void* stream) {
     if (!table || !offsets17_host || !weights || !d_table || !d_weights)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: null pointer");
     if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: negative sample count");
@@ -1357,7 +1538,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     A.off[NL] = (unsigned)offsets17_host[NL];
     level_modes(A);
     A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
-    P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror;
+    P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror; P.g_normal = g_normal;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
     P.copies = workspace;
     P.exp_noscatter = getenv("MNRF_EXP_TCNN_NOSCATTER") != nullptr;
@@ -1376,6 +1557,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256)), block(BT);      // persistent: one workgroup per CU of the MI355X
     const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
+    if (g_normal) hipLaunchKernelGGL(tcnn_bwd2_kernel, grid, block, lds, (hipStream_t)stream, P);     // adds the second-order term
     if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     return mnrf_check_launch("mnrf_tcnn_backward");
 }

@@ -10,8 +10,9 @@ the small MLPs keep the reference's names (`sigma_net.N.weight`, `color_net.N.we
 `normal_net.N.weight`, `is_mirror_net.{0,2}.{weight,bias}`).
 
 Training: `TcnnFieldFn` chains the forward kernel with `mnrf_tcnn_backward` (table gradient by atomic scatter, MLP
-weight gradients by in-kernel fp32 MFMA products, dL/d position and dL/d direction).  First order only: the
-density-gradient normal (`normal`) is a constant of the graph.
+weight gradients by in-kernel fp32 MFMA products, dL/d position and dL/d direction); a gradient arriving at the
+density-gradient normal (`normal`) is the second-order term of models/mirror_nerf_tcnn.py:172-218 and is propagated
+by a second kernel of the same call (table, sigma_net, position).
 """
 import ctypes
 
@@ -51,7 +52,8 @@ class TcnnFieldFn(torch.autograd.Function):
     """mnrf_tcnn_forward / mnrf_tcnn_backward.
     apply(module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *mlp_params) ->
         sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty), geo_feat (B,15)
-        [the last two are not differentiable]
+        [geo_feat is not differentiable; a gradient arriving at `normal` -- the normalised density gradient -- is the
+        second-order term of models/mirror_nerf_tcnn.py:172-218 and is propagated by tcnn_bwd2_kernel]
     Positions/directions come from `xyz6` (B,6) or from rays (N,8) + z_vals (N,spr) with per-ray raw directions
     `dirs` (N,3; None: the ray direction).  `mlp_params`: the 11 tensors of _BLOB in that order."""
 
@@ -68,17 +70,18 @@ class TcnnFieldFn(torch.autograd.Function):
         normal = o.get("normal")
         if normal is None:
             normal = torch.empty(0, 3, dtype=torch.float32, device=o["sigma"].device)
-        ctx.mark_non_differentiable(normal, o["geo_feat"])
+            ctx.mark_non_differentiable(normal)
+        ctx.mark_non_differentiable(o["geo_feat"])
         return o["sigma"], o["rgb"], o["pred_normal"], o["is_mirror"], normal, o["geo_feat"]
 
     @staticmethod
-    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, _g_normal, _g_geo):
+    def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal, _g_geo):
         xyz6, rays, z_vals, dirs = ctx.saved_tensors
         m, B, spr = ctx.module, ctx.B, ctx.spr
         table = m.encoder.embeddings.detach().contiguous()
         dev = table.device
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
-        g_sigma, g_rgb, g_pn, g_m = c(g_sigma), c(g_rgb), c(g_pn), c(g_m)
+        g_sigma, g_rgb, g_pn, g_m, g_normal = c(g_sigma), c(g_rgb), c(g_pn), c(g_m), c(g_normal)
         need = ctx.needs_input_grad
         d_table = torch.zeros_like(table)
         d_blob = torch.zeros(_lib.lib().mnrf_tcnn_weight_floats(), dtype=torch.float32, device=dev)
@@ -93,7 +96,7 @@ class TcnnFieldFn(torch.autograd.Function):
             _lib.check(_lib.lib().mnrf_tcnn_backward(
                 p(table), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
-                p(g_m), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
+                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
         grads, off = [], 0
         for _name, rows, used, padded in _BLOB:
             if padded:
@@ -219,7 +222,7 @@ class MirrorNeRFTcnn(nn.Module):
         B = x.shape[0]
         if (not sigma_only and x.shape[1] == 6 and torch.is_grad_enabled()
                 and (x.requires_grad or any(q.requires_grad for q in self.parameters()))):
-            # training route (geo_feat and the density-gradient normal are constants of the graph)
+            # training route (geo_feat is a constant of the graph; the density-gradient normal carries its second-order term)
             sigma, rgb, pn, mir, normal, geo = TcnnFieldFn.apply(self, 1, x, None, None, None, bool(compute_normal),
                                                                  self.encoder.embeddings, *self.mlp_params())
             out = {"normal": normal} if compute_normal else {}

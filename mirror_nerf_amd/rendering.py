@@ -208,16 +208,6 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         S = z.shape[1]
         if hashgrid:
             from .mirror_nerf_tcnn import TcnnFieldFn
-            if compute_normal and not _WARNED.get("tcnn_normal"):
-                # models/mirror_nerf_tcnn.py:172-218 differentiates THROUGH autograd.grad(sigma, x, create_graph=True); the
-                # hash-grid backward here is first order: normal_* / surface_normal_grad_* / normal_dif_* are constants of
-                # the graph, so NormalLoss and the normal_fine term of NormalRegLoss send nothing to the table or sigma_net
-                import warnings
-                warnings.warn("mirror_nerf_amd: the hash-grid field (model_type nerf_tcnn) has no second-order backward: keys "
-                              "derived from the density-gradient normal (normal_*, surface_normal_grad_*, normal_dif_*) carry no "
-                              "gradient, unlike the reference (the 8x256 MirrorNeRF field does propagate it)", RuntimeWarning,
-                              stacklevel=3)
-                _WARNED["tcnn_normal"] = True
             sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:

@@ -350,3 +350,45 @@ def test_tcnn_mfma_kernel_agrees_with_valu_kernel(sigma_only, grad):
             assert float(d.max(-1)[0].median()) <= 1e-5 and float((d.max(-1)[0] < 1e-3).float().mean()) > 0.95
         else:
             assert float(d.max()) <= 2e-5 * max(1.0, float(a[k].abs().max())), (k, float(d.max()))
+
+
+@pytest.mark.parametrize("bound,B", [(1.0, 700), (3.0, 1200)])
+def test_tcnn_second_order_backward_matches_double_backward(bound, B):
+    """The gradient that reaches the hash table, sigma_net and the positions through normal = l2n(-d sigma/dx)
+    (models/mirror_nerf_tcnn.py:172-218 differentiates autograd.grad(sigma, x, create_graph=True)): tcnn_bwd2_kernel against
+    torch's double backward through the plain-torch restatement, in fp64."""
+    from tests import torch_ref as R
+    m, _w, cfg = _model(bound, seed=5, table_scale=0.3)
+    g = torch.Generator().manual_seed(B)
+    xyz = (torch.rand(B, 3, generator=g) * 2 - 1) * bound * 0.98
+    xyz[:3] *= 1.5                                         # outside the box
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    x6 = torch.cat([xyz, d], 1).to(DEV)
+    cot_n = torch.randn(B, 3, generator=g).to(DEV)
+    cot_s = torch.randn(B, generator=g).to(DEV) * 0.1
+    # HIP
+    m.zero_grad()
+    x = x6.clone().requires_grad_(True)
+    out = m(x, compute_normal=True)
+    ((out["normal"] * cot_n).sum() + (out["sigma"] * cot_s).sum()).backward()
+    got = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in m.named_parameters()}
+    got["x6"] = x.grad.clone()
+    # torch, fp64
+    w = {k: v.detach().double().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x6.detach().double().clone().requires_grad_(True)
+    sigma, rgb, pn, mm, nrm = R.tcnn_field_with_normal(w, xr, cfg)
+    ((nrm * cot_n.double()).sum() + (sigma * cot_s.double()).sum()).backward()
+    # the normals themselves agree where the gradient is well conditioned
+    dn = (out["normal"].detach() - nrm.detach().float()).abs().max(-1).values
+    assert float(dn.median()) <= 1e-5
+    for k in ("encoder.embeddings", "sigma_net.0.weight", "sigma_net.1.weight"):
+        wv = w[k].grad.float()
+        scale = float(wv.abs().max()) + 1e-12
+        err = float((got[k] - wv).abs().max())
+        print(f"{k:24s} err {err:.3e} scale {scale:.3e}")
+        assert err <= 2e-3 * scale, (k, err, scale)
+    for k in ("color_net.0.weight", "normal_net.0.weight", "is_mirror_net.0.weight"):
+        assert float(got[k].abs().max()) == 0.0            # untouched by this loss
+    gx, wx = got["x6"][:, :3], xr.grad.float()[:, :3]
+    rel = (gx - wx).abs().max(-1).values / (wx.abs().max(-1).values + 1e-3 * float(wx.abs().max()))
+    assert float(rel.median()) <= 1e-3 and float((rel < 5e-2).float().mean()) > 0.9, (float(rel.median()), float((rel < 5e-2).float().mean()))

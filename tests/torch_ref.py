@@ -96,6 +96,16 @@ def blend(base, sec, mask, compact):
     return m * part + (1 - m) * base
 
 
+def tcnn_field_with_normal(w, x6, cfg):
+    """tcnn_field plus normal = l2n(-d sigma/dx) built with create_graph=True (models/mirror_nerf_tcnn.py:172-218,
+    utils/func.py:10-25): torch's double backward through it is the reference for the second-order kernel."""
+    if not x6.requires_grad:
+        x6 = x6.requires_grad_(True)
+    sigma, rgb, pn, m = tcnn_field(w, x6, cfg)
+    (grad,) = torch.autograd.grad(sigma, x6, torch.ones_like(sigma), create_graph=True, retain_graph=True)
+    return sigma, rgb, pn, m, l2n(-grad[:, :3])
+
+
 def tcnn_field(w, x6, cfg):
     """MirrorNeRFTcnn.forward (models/mirror_nerf_tcnn.py:220-259) with torch ops: the hash-grid cells and interpolation
     weights follow the oracle (`hashgrid_encode` / `_grid_index`), the table look-up is a differentiable gather.
