@@ -28,7 +28,6 @@ from .weights import params_of
 __all__ = ["render_rays", "sample_pdf"]
 
 _LINSPACE = {}
-_WARNED = {}
 
 
 def _linspace01(n, device):

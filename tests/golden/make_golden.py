@@ -247,6 +247,8 @@ def train_case(name, n_rays, gt_mode, tweaks, **hp_over):
     rs = np.random.RandomState(66)
     if gt_mode == "gt25":
         gt = (rs.uniform(size=n_rays) < 0.25).astype(np.float32)
+    elif gt_mode == "gt0":
+        gt = np.zeros(n_rays, dtype=np.float32)          # valid GT without a single mirror pixel
     else:
         gt = -np.ones(n_rays, dtype=np.float32)  # invalid GT -> predicted mask
     is_eval = hp_over.get("is_eval", False)
@@ -429,6 +431,10 @@ def main():
                    max_recursive_level=2, is_eval=True, chunk=32)
         train_case("g6_train_nomirror_eval", 48, "invalid", W.OPAQUE, only_trace_rays_in_mirrors=True,
                    max_recursive_level=1, is_eval=True)
+    if want("g6_train_forvis"):
+        # for_vis: trace although no pixel is a mirror (train.py:172-178), every ray, so that the *_reflect maps exist
+        train_case("g6_train_forvis_eval", 48, "gt0", W.OPAQUE, only_trace_rays_in_mirrors=False, max_recursive_level=1,
+                   is_eval=True, for_vis=True)
     if want("g7"):
         eval_case("g7_eval_l1", 96, W.STRADDLE, 1)
         eval_case("g7_eval_l2_chunk32", 96, W.STRADDLE, 2, chunk=32)
