@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
@@ -283,6 +284,233 @@ __global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(DwJobs J, long long B
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined version of dw_gemm_bf16_kernel<128> (round 2).  The kernel above runs in phases -- wait for the stage's rows,
+// convert and store them, barrier, MFMAs, barrier -- and leans on a second resident workgroup to fill the matrix pipe
+// while one converts.  Here ONE workgroup of EIGHT waves per CU owns two LDS buffers and four register sets, and every
+// wave overlaps the three activities itself:
+//   stage i:  global loads of stage i+4 -> register set i % 4            (three stages of load latency hidden)
+//             MFMAs on LDS buffer i % 2, and BETWEEN them the conversion of stage i+1 (register set (i+1) % 4) into
+//             LDS buffer (i+1) % 2: one column task (2 samples x 1 column -> 3 words) per 6 MFMAs
+//             one barrier
+// Two waves per SIMD, not one: a single wave issues its ~450 non-MFMA instructions per stage one dependent instruction at
+// a time (measured with 4 waves: 2400 cycles per stage with the MFMAs compiled out, whatever the prefetch depth).
+// Sample ranges of the splits are multiples of 32; the one partial stage of a launch is done behind the pipeline.
+// OUTCOME (profiles/r02i_dw_ab.txt): the largest launch of a 1024-ray step takes 1.23 ms against 1.12 ms of the phased
+// kernel, the step 7.96 vs 7.73 ms -- no gain, so the phased kernel stays the default (MNRF_DW_PIPE=1 selects this one).
+// What the exercise established: both kernels sit at ~2500-2800 cycles per 32-sample stage against 1536 cycles of MFMA
+// time because the fp32 -> 3 x bf16 conversion (5.5 VALU per element, 832 VALU cycles per SIMD and stage) plus the
+// MFMA issue slots fill the vector issue port to ~80 %; the XCD-aware tile placement halves the L2 misses (5.2 GB per
+// step instead of 10.1, L2 hit rate 47 %) without changing the time, i.e. the GEMM was not HBM-bound either.
+constexpr int DWP_WAVES = 8;
+constexpr int DWP_TK = 128;
+struct DwpRegs {
+    f32x4 a[2], x[2];      // one column quad of dY and one of X, rows 2*rp and 2*rp + 1
+};
+
+__device__ __forceinline__ void stage_col(char* plane0, int plane_bytes, int col, int rp, float v0, float v1) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(v0, h0, m0, l0);
+    split3(v1, h1, m1, l1);
+    char* w = plane0 + col * DWS_STRIDE + rp * 4;
+    *(unsigned*)(w) = (h0 >> 16) | h1;
+    *(unsigned*)(w + plane_bytes) = (m0 >> 16) | m1;
+    *(unsigned*)(w + 2 * plane_bytes) = (l0 >> 16) | l1;
+}
+
+template <bool HINT>
+__global__ __launch_bounds__(64 * DWP_WAVES, 1) void dw_gemm_bf16p_kernel(DwJobs J, long long B, int splits, int njobs) {
+    constexpr int TK = DWP_TK;
+    // Workgroup -> (job, split, tile).  The up-to-four tiles of one (job, split) read the same 32 rows of dY and X per
+    // stage, two tiles each: at full matrix-pipe rate a 128 x 128 tile needs 32 KB of operands per 0.73 us, 11 TB/s over
+    // the chip -- more than HBM delivers (the phased kernel: 4.9 TB/s of L2 misses).  Workgroups are dealt to the 8 XCDs
+    // round robin (id % 8) and each XCD has its own L2: the four tiles of a pair get ids 8 apart -- same XCD, same round,
+    // same pace -- so that an operand line comes from HBM once and is hit in L2 once (measured: L2 misses halved).
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int tile = slot & 3, pair = (slot >> 2) * 8 + xcd;
+    if (pair >= splits * njobs) return;
+    const int split = pair % splits;
+    const DwJob jb = J.job[pair / splits];
+    const float* __restrict__ A = jb.A;
+    const float* __restrict__ X = jb.X;
+    float* __restrict__ Cpart = jb.C;
+    float* __restrict__ bpart = jb.bp;
+    const int lda = jb.lda, ldx = jb.ldx, N = jb.N, K = jb.K;
+    const int tiles_n = N / DW_TN;
+    const int tile_n = tile % tiles_n, tile_k = tile / tiles_n;
+    if (tile_k >= K / TK) return;
+    extern __shared__ __attribute__((aligned(16))) char dws[];
+    constexpr int PA = DW_TN * DWS_STRIDE;      // one plane of dY^T
+    constexpr int PX = TK * DWS_STRIDE;         // one plane of X^T
+    constexpr int BUF = 3 * (PA + PX);          // one stage: 3 planes of each operand
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int wn = wave >> 1, wk = wave & 1;
+    constexpr int MB = 2;              // 32 rows of dW per wave
+    constexpr int KB = TK / 32;        // TK/2 columns per wave
+    constexpr int NTASK = 8;           // column tasks of a thread per stage: 4 of dY, 4 of X
+    const int n0 = tile_n * DW_TN, k0 = tile_k * TK;
+    const long long per = (((B + splits - 1) / splits) + DWS_CH - 1) & ~(long long)(DWS_CH - 1);
+    const long long s_begin = split * per < B ? split * per : B;
+    const long long s_end = s_begin + per < B ? s_begin + per : B;
+    // whole stages go through the pipeline; the one partial stage of the launch (the split that ends at B) is done after it
+    const int nstage = (int)((s_end - s_begin) / DWS_CH);
+    const bool partial = (s_end - s_begin) % DWS_CH != 0;
+
+    f32x4 acc[MB][KB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: a thread owns row pair rp of every stage and column quad cq of both operands (as in dw_gemm_bf16_kernel)
+    const int rp = lane & 15, cq = (lane >> 4) + 4 * wave;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const float* const a_row = A + n0 + cq * 4;
+    const float* const x_row = X + k0 + cq * 4;
+    // Rows are clamped to the last sample instead of predicated (a predicated load is a branch, and a branch splits the
+    // block the conversion is scheduled in).
+    auto fetch = [&](DwpRegs& R, long long s0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            long long row = s0 + 2 * rp + r;
+            row = row < B ? row : B - 1;
+            R.a[r] = *(const f32x4*)(a_row + row * lda);
+            R.x[r] = *(const f32x4*)(x_row + row * ldx);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the loads leave BEFORE the MFMA block (left alone, hipcc sinks them to its end)
+    };
+    auto zero_surplus = [&](DwpRegs& R, long long s0) {      // rows at and past s_end contribute nothing
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool ok = s0 + 2 * rp + r < s_end;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                R.a[r][c] = ok ? R.a[r][c] : 0.f;
+                R.x[r][c] = ok ? R.x[r][c] : 0.f;
+            }
+        }
+    };
+    // column task t of a stage: t < 4 -> dY column t of the quad (also feeds the bias sums, weight bw: 0 for a stage past
+    // the range); else X
+    auto task = [&](const DwpRegs& R, char* buf, int t, float bw) {
+        if (t < 4) {
+            stage_col(buf, PA, cq * 4 + t, rp, R.a[0][t], R.a[1][t]);
+            bsum[t] = fmaf(bw, R.a[0][t] + R.a[1][t], bsum[t]);
+        } else {
+            stage_col(buf + 3 * PA, PX, cq * 4 + (t - 4), rp, R.x[0][t - 4], R.x[1][t - 4]);
+        }
+    };
+    // MFMAs of the stage in `cur`, conversion of `R` into `nxt` (convert_c: a next stage exists)
+    auto compute = [&](auto convert_c, const char* cur, const DwpRegs& R, char* nxt, float bw) {
+        constexpr bool convert = decltype(convert_c)::value;     // compile-time: a branch would split the MFMA block
+        const char* As = cur;
+        const char* Xs = cur + 3 * PA;
+        u32x4 b[KB][3];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[kb][pl] = *(const u32x4*)(Xs + pl * PX + (wk * (TK / 2) + kb * 16 + i) * DWS_STRIDE + g * 16);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = *(const u32x4*)(As + pl * PA + (wn * 32 + mb * 16 + i) * DWS_STRIDE + g * 16);
+            // six products per 16 x 16 block, smallest first; two column blocks alternate so that an accumulator is
+            // touched by every second MFMA only
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int kp = 0; kp < KB; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[mb][kp + u] = mfma_bf16(a[pa[j]], b[kp + u][pb[j]], acc[mb][kp + u]);
+            if (convert) {
+#pragma unroll
+                for (int t = 0; t < NTASK / MB; ++t) task(R, nxt, mb * (NTASK / MB) + t, bw);
+            }
+            if (HINT) {
+                // one MFMA, then the conversion instructions that fit its shadow; 6 * KB MFMAs per row block
+#pragma unroll
+                for (int m = 0; m < 6 * KB; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    if (m % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+        }
+    };
+
+    // Control flow: the loop body is four unconditional stages.  A skipped fetch or a skipped conversion that flows back
+    // into the loop makes hipcc's waitcnt insertion merge the two paths and drain every outstanding load before the next
+    // fetch (measured on the first version: 4800 cycles per stage).  Fetches and conversions past the workgroup's range
+    // therefore stay in (rows clamped to valid memory, results never multiplied, bias weight 0), and the last 0..3 stages
+    // are written out behind the loop.
+    DwpRegs R[4];
+    char* const buf0 = dws;
+    char* const buf1 = dws + BUF;
+    auto at = [&](int st) { return s_begin + (long long)st * DWS_CH; };
+    if (nstage > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch(R[j], at(j));
+#pragma unroll
+        for (int t = 0; t < NTASK; ++t) task(R[0], buf0, t, 1.f);
+        __syncthreads();
+        int st = 0;
+        for (; st + 4 <= nstage; st += 4) {
+            const float bw_last = st + 4 < nstage ? 1.f : 0.f;      // the stage converted by j = 3 may lie past the range
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fetch(R[j], at(st + j + 4));
+                compute(std::true_type{}, j % 2 ? buf1 : buf0, R[(j + 1) % 4], j % 2 ? buf0 : buf1, j == 3 ? bw_last : 1.f);
+                __syncthreads();
+            }
+        }
+        const int left = nstage - st;     // 0..3 stages: buf0 holds stage st, R[1..3] the rows of the following ones
+        if (left >= 2) compute(std::true_type{}, buf0, R[1], buf1, 1.f);
+        else if (left == 1) compute(std::false_type{}, buf0, R[1], buf1, 0.f);
+        if (left >= 2) {
+            __syncthreads();
+            if (left == 3) compute(std::true_type{}, buf1, R[2], buf0, 1.f);
+            else compute(std::false_type{}, buf1, R[2], buf0, 0.f);
+        }
+        if (left == 3) {
+            __syncthreads();
+            compute(std::false_type{}, buf0, R[3], buf1, 0.f);
+        }
+    }
+    if (partial) {      // wave-uniform, at most one workgroup per tile: plain fetch -> convert -> MFMAs
+        __syncthreads();
+        fetch(R[0], at(nstage));
+        zero_surplus(R[0], at(nstage));
+#pragma unroll
+        for (int t = 0; t < NTASK; ++t) task(R[0], buf0, t, 1.f);
+        __syncthreads();
+        compute(std::false_type{}, buf0, R[1], buf1, 0.f);
+    }
+    float* C = Cpart + (long long)split * N * K;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + mb * 16 + 4 * g + r;
+                const int k = k0 + wk * (TK / 2) + kb * 16 + i;
+                C[(long long)n * K + k] = acc[mb][kb][r];
+            }
+    if (bpart && tile_k == 0) {
+        // column sums of dY: the 16 lanes of a lane group hold the 16 row pairs of the same columns
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = bsum[c];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (rp == 0) bpart[(long long)split * N + n0 + cq * 4 + c] = v;
+        }
+    }
+}
+
 // dW for Linears with <= 3 output rows: Cpart[split][3][K], bpart[split][3]; up to four of them per launch (blockIdx.y)
 struct DwSmallJob {
     const float* A; int lda, n_true;
@@ -387,6 +615,20 @@ int dw_splits(long long B) {          // MFMA GEMMs, batched launches: >= 512 sa
     long long s = (B + per - 1) / per;
     return (int)(s < 1 ? 1 : (s > cap ? cap : s));
 }
+// Pipelined kernels run ONE workgroup per CU, so a launch costs whole rounds of 256 workgroups: pick the split count
+// (<= dw_splits(B), the workspace is sized for that) that minimises rounds x (stages per workgroup + fill/epilogue).
+static int dw_splits_rounds(long long B, int tiles) {
+    const int cap = dw_splits(B);
+    int best = 1;
+    long long best_cost = -1;
+    for (int sp = 1; sp <= cap; ++sp) {
+        const long long wg = (long long)sp * tiles, rounds = (wg + 255) / 256;
+        const long long stages = ((B + sp - 1) / sp + DWS_CH - 1) / DWS_CH;
+        const long long cost = rounds * (stages + 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
 int dw_small_splits(long long B) {    // 1-/3-row Linears: HBM-bound streaming, 128 samples per workgroup
     long long s = (B + 127) / 128;
     return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
@@ -401,18 +643,49 @@ long long dw_workspace_floats(long long B) {
     return (long long)dw_splits(B) * DW_PER_SPLIT + (long long)dw_small_splits(B) * DW_PER_SMALL_SPLIT;
 }
 
+// MNRF_DW_PIPE: 0 (default) = the phased kernels everywhere, 1 = pipelined kernel for the 128-wide tiles (equal step time,
+// half the HBM traffic: see the kernel's header);
+// MNRF_DW_HINT=0 drops the scheduling-group hints of the pipelined kernel
+static int dw_pipe() {
+    static const int v = [] { const char* e = getenv("MNRF_DW_PIPE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static bool dw_hint() {
+    static const bool v = [] { const char* e = getenv("MNRF_DW_HINT"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 struct DwBatch {
     DwJobs j128, j64, j32;
     int n128 = 0, n64 = 0, n32 = 0;
     long long B;
-    int splits;
+    int splits;          // of the phased kernels (and of the fp32 path)
+    int splits_p;        // of the pipelined kernels
     hipStream_t s;
+    template <int TK>
+    static bool pipelined() { return !dw_fp32() && TK == DWP_TK && dw_pipe() >= 1; }
+    template <int TK>
+    int splits_of() const { return pipelined<TK>() ? splits_p : splits; }
     template <int TK>
     void launch(const DwJobs& J, int n) {
         if (n) hipLaunchKernelGGL((dw_gemm_bf16_kernel<TK>), dim3(4, splits, n), dim3(256), 3 * (DW_TN + TK) * DWS_STRIDE, s, J, B, splits);
     }
+    void launch_pipelined(const DwJobs& J, int n) {
+        if (!n) return;
+        constexpr int lds = 2 * 3 * (DW_TN + DWP_TK) * DWS_STRIDE;
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)dw_gemm_bf16p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)dw_gemm_bf16p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            return true;
+        }();
+        (void)once;
+        const int grid = 32 * ((splits_p * n + 7) / 8);      // 8 XCDs x 4 tiles per group of 8 (job, split) pairs
+        if (dw_hint()) hipLaunchKernelGGL((dw_gemm_bf16p_kernel<true>), dim3(grid), dim3(64 * DWP_WAVES), lds, s, J, B, splits_p, n);
+        else hipLaunchKernelGGL((dw_gemm_bf16p_kernel<false>), dim3(grid), dim3(64 * DWP_WAVES), lds, s, J, B, splits_p, n);
+    }
     void flush() {
-        launch<128>(j128, n128);
+        if (pipelined<128>()) launch_pipelined(j128, n128);
+        else launch<128>(j128, n128);
         launch<64>(j64, n64);
         launch<32>(j32, n32);
         n128 = n64 = n32 = 0;
@@ -438,8 +711,10 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
     const int ssplits = dw_small_splits(B);
     DwBatch bt;
     bt.B = B; bt.splits = splits; bt.s = s;
+    bt.splits_p = dw_splits_rounds(B, 8 * 4 + 3 * 2);      // 8 GEMMs of four 128 x 128 tiles, 3 of two
+    const int s128 = bt.splits_of<128>(), s64 = bt.splits_of<64>();
     float* p = ws;
-    auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
+    auto take = [&](long long n) { float* r = p; p += n * splits; return r; };      // sized for the larger split count
     auto take_small = [&](long long n) { float* r = p; p += n * ssplits; return r; };
     auto X = [&](int sec) { return save_x + (long long)sec * B; };
     auto Y = [&](int sec) { return dY + (long long)sec * B; };
@@ -462,17 +737,17 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         if (i == 0) {
             float* c = take(256 * 64);
             gemm<64>(bt, Y(DY_L), 256, 256, X(SEC_ENC), 64, 64, c, bp);
-            layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1, bp);
+            layer(0, 256, 63, DwSource{c, 64, 256, s64}, DwSource{c, 64, 256, s64}, 63, 1, bp);
         } else if (i == 4) {
             float* ce = take(256 * 64);
             float* ch = take(256 * 256);
             gemm<64>(bt, Y(DY_L + 256 * 4), 256, 256, X(SEC_ENC), 64, 64, ce, bp);
             gemm<128>(bt, Y(DY_L + 256 * 4), 256, 256, X(SEC_H + 256 * 3), 256, 256, ch, nullptr);
-            layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1, bp);
+            layer(4, 256, 319, DwSource{ce, 64, 256, s64}, DwSource{ch, 256, 256, s128}, 63, 1, bp);
         } else {
             float* c = take(256 * 256);
             gemm<128>(bt, Y(DY_L + 256 * i), 256, 256, X(SEC_H + 256 * (i - 1)), 256, 256, c, bp);
-            layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
+            layer(i, 256, 256, DwSource{c, 256, 256, s128}, DwSource{c, 256, 256, s128}, 256, 0, bp);
         }
     }
     const float* h8 = X(SEC_H + 256 * 7);
@@ -480,7 +755,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* bp = take(256);
         float* c = take(256 * 256);
         gemm<128>(bt, Y(DY_FIN), 256, 256, h8, 256, 256, c, bp);
-        layer(8, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0, bp);
+        layer(8, 256, 256, DwSource{c, 256, 256, s128}, DwSource{c, 256, 256, s128}, 256, 0, bp);
     }
     {   // dir_encoding.0 (L = 9): columns [0,256) from final, [256,283) from the view encoding
         float* bp = take(128);
@@ -488,7 +763,7 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* cd = take(128 * 32);
         gemm<128>(bt, Y(DY_DIR), 128, 128, X(SEC_FIN), 256, 256, cf, bp);
         gemm<32>(bt, Y(DY_DIR), 128, 128, X(SEC_DIRE), 32, 32, cd, nullptr);
-        layer(9, 128, 283, DwSource{cf, 256, 128, splits}, DwSource{cd, 32, 128, splits}, 256, 0, bp);
+        layer(9, 128, 283, DwSource{cf, 256, 128, s128}, DwSource{cd, 32, 128, splits}, 256, 0, bp);
     }
     DwSmallJobs SJ;
     int n_small = 0;
@@ -504,14 +779,14 @@ int launch_dw(const float* save_x, const float* dY, const float* g_sigma, long l
         float* bp = take(128);
         float* c = take(128 * 256);
         gemm<128>(bt, Y(DY_NRM1), 128, 128, h8, 256, 256, c, bp);
-        layer(12, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
+        layer(12, 128, 256, DwSource{c, 256, 128, s128}, DwSource{c, 256, 128, s128}, 256, 0, bp);
     }
     small(13, Y(DY_NRM2), 16, 3, X(SEC_HN), 128);               // normal_net.1
     {   // is_mirror_net.0 (L = 14)
         float* bp = take(128);
         float* c = take(128 * 256);
         gemm<128>(bt, Y(DY_MIR1), 128, 128, h8, 256, 256, c, bp);
-        layer(14, 128, 256, DwSource{c, 256, 128, splits}, DwSource{c, 256, 128, splits}, 256, 0, bp);
+        layer(14, 128, 256, DwSource{c, 256, 128, s128}, DwSource{c, 256, 128, s128}, 256, 0, bp);
     }
     small(15, Y(DY_MIR2), 16, 1, X(SEC_HM), 128);               // is_mirror_net.2
     if (p - ws > dw_workspace_floats(B)) return -1;
@@ -535,6 +810,8 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
     const int ssplits = dw_small_splits(B);
     DwBatch bt;
     bt.B = B; bt.splits = splits; bt.s = s;
+    bt.splits_p = dw_splits_rounds(B, 7 * 4);
+    const int s128 = bt.splits_of<128>(), s64 = bt.splits_of<64>();
     float* p = ws;
     auto take = [&](long long n) { float* r = p; p += n * splits; return r; };
     auto sec = [&](int off) { return so + (long long)off * B; };
@@ -557,17 +834,17 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
         if (i == 0) {
             float* c = take(256 * 64);
             gemm<64>(bt, b, 256, 256, sec(TA_ENC), 64, 64, c, nullptr);
-            layer(0, 256, 63, DwSource{c, 64, 256, splits}, DwSource{c, 64, 256, splits}, 63, 1);
+            layer(0, 256, 63, DwSource{c, 64, 256, s64}, DwSource{c, 64, 256, s64}, 63, 1);
         } else if (i == 4) {
             float* ce = take(256 * 64);
             float* ch = take(256 * 256);
             gemm<64>(bt, b, 256, 256, sec(TA_ENC), 64, 64, ce, nullptr);
             gemm<128>(bt, b, 256, 256, sec(TA_H + 256 * 3), 256, 256, ch, nullptr);
-            layer(4, 256, 319, DwSource{ce, 64, 256, splits}, DwSource{ch, 256, 256, splits}, 63, 1);
+            layer(4, 256, 319, DwSource{ce, 64, 256, s64}, DwSource{ch, 256, 256, s128}, 63, 1);
         } else {
             float* c = take(256 * 256);
             gemm<128>(bt, b, 256, 256, sec(TA_H + 256 * (i - 1)), 256, 256, c, nullptr);
-            layer(i, 256, 256, DwSource{c, 256, 256, splits}, DwSource{c, 256, 256, splits}, 256, 0);
+            layer(i, 256, 256, DwSource{c, 256, 256, s128}, DwSource{c, 256, 256, s128}, 256, 0);
         }
     }
     {   // sigma.weight: column sums of the masked tangent of h8 (A = a single 1.0 read with stride 0)

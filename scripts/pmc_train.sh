@@ -9,6 +9,8 @@ mkdir -p $OUT
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python scripts/bench_train.py --steps $STEPS --warmup 2 > $OUT/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM
+run tcc TCC_HIT_sum TCC_MISS_sum
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python scripts/bench_train.py --steps $STEPS --warmup 2 > $OUT/trace.log 2>&1
 python scripts/pmc_train_reduce.py $OUT $((STEPS + 2)) > $OUT/summary.json 2> $OUT/reduce.err

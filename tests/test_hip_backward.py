@@ -389,3 +389,18 @@ def test_optimizer_steps_are_seen_by_the_next_launch(fused):
         images.append(system.nerf_fine.__dict__["_mnrf_packed"].packed[:4096].clone())
     assert min(losses[6:]) < losses[0] - 5e-3, losses
     assert all(not torch.equal(images[i], images[i + 1]) for i in range(1, 11)), "the packed image does not follow the optimizer"
+
+
+def test_pipelined_weight_gradient_kernel_matches_autograd():
+    """MNRF_DW_PIPE=1 (the pipelined 128-wide weight-gradient GEMM, non-default: csrc/mnrf_dw.hip) is read once per
+    process, so the gradient tests run again in a child process with it set (ragged sizes: partial last stage, fewer
+    stages than the pipeline is deep, the second-order pass)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MNRF_DW_PIPE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "field_backward_matches_autograd or second_order or train_step_gradients_golden"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
