@@ -236,7 +236,8 @@ class NeRFSystem(nn.Module):
                                                 self.white_back, self.train_geometry_stage)
             for k, v in out.items():
                 results[k] += [v]
-        return {k: torch.cat(v, 0) for k, v in results.items()}
+        # (a single chunk -- every training batch -- needs no copy: torch.cat of one tensor is 27 copy kernels per step)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in results.items()}
 
 
 # ----------------------------------------------------------------------------- eval semantics
