@@ -126,9 +126,30 @@ constexpr int SPLIT_HBWD_PAIRS = padded_pairs(8 + 64 + 8 + 128 + 8 + 64 + 8 + 64
 constexpr int64_t OFF_SPLIT_FWD = PACKED_F32_FLOATS;
 constexpr int64_t OFF_SPLIT_BWD = OFF_SPLIT_FWD + (int64_t)SPLIT_FWD_PAIRS * (PAIR_BYTES / 4);
 constexpr int64_t OFF_SPLIT_HBWD = OFF_SPLIT_BWD + (int64_t)SPLIT_BWD_PAIRS * (PAIR_BYTES / 4);
+// ---- forward stream of the 32x32x16 tuning (mnrf_field_split32.inc; inference only).  One MFMA there contracts 16 columns
+//      for a block of 32 rows: a pair = [hi tile][lo tile] of a 32-row x 16-column block, half e (0..7) of lane l =
+//      W[32*nb + (l&31)][col32(T, l>>5, e)].  The accumulator of a 32x32 MFMA holds, in register r of lane half h = l>>5,
+//      row 8*(r>>2) + 4*h + (r&3) of its block, so registers 8c..8c+7 of block nb ARE the lane's 8 halves of k-step
+//      T = 2*nb + c of the next layer -- col32_h(T, h, e) = 16*T + 8*(e>>2) + 4*h + (e&3) -- and activations stay in
+//      their lanes exactly as in the 16x16 layout.  Same part sequence as the 16x16 stream (trunk layers in two halves of
+//      four 32-row blocks); 1- and 3-row heads are padded to 32 rows.  Positions (pairs): trunk as above (L1 0|16 ...
+//      L8 832|896), sigma 960, normal_net.0 976, normal_net.1 1040, is_mirror_net.0 1048, is_mirror_net.2 1112,
+//      xyz_encoding_final 1120, dir_encoding 1248 (final) 1312 (view), rgb 1320, end 1328.
+constexpr int SPLIT32_FWD_USED_SIGMA = 960 + 16;
+constexpr int SPLIT32_FWD_USED = SPLIT32_FWD_USED_SIGMA + 64 + 8 + 64 + 8 + 128 + 64 + 8 + 8;      // 1328
+constexpr int SPLIT32_FWD_PAIRS = padded_pairs(SPLIT32_FWD_USED);
+constexpr int64_t OFF_SPLIT32_FWD = OFF_SPLIT_HBWD + (int64_t)SPLIT_HBWD_PAIRS * (PAIR_BYTES / 4);
+// xyz encoding column held by lane half h at k-step T (0..3), half e of a 32x32x16 ENC part: pair P = 16*h + 4*T + (e>>1)
+__host__ __device__ inline int enc_col32(int T, int h, int e) {
+    const int P = 16 * h + 4 * T + (e >> 1);
+    const int s = e & 1;
+    if (P < 30) return 3 + 6 * (P / 3) + 3 * s + (P % 3);
+    if (P == 30) return s;
+    return s == 0 ? 2 : -1;
+}
 // tail pad: the split kernel's static LDS-DMA schedule reads two chunks (of up to 32 KiB) past the end of a stream
 constexpr int64_t SPLIT_TAIL_FLOATS = 2 * 16 * (PAIR_BYTES / 4);
-constexpr int64_t PACKED_FLOATS = OFF_SPLIT_HBWD + (int64_t)SPLIT_HBWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
+constexpr int64_t PACKED_FLOATS = OFF_SPLIT32_FWD + (int64_t)SPLIT32_FWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order
 constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)

@@ -89,8 +89,11 @@ def main():
     o, n2 = check_object("mnrf_field_split.o", "v_mfma_f32_16x16x32_f16", [
         (r"field_split_kernel", fwd16), (r"field_split_bwd2?_kernel", grad16)])
     ok &= o and n2 >= 10
-    if n < 9 or n2 < 10:
-        print(f"expected >= 9 fp32 and >= 10 split kernels, found {n} and {n2}")
+    # 32x32x16 tuning of the forward-only split kernels (same hand-placed scheme; two LDS-read waits per unit of 6 MFMAs)
+    o, n3 = check_object("mnrf_field_split32.o", "v_mfma_f32_32x32x16_f16", [(r"field_split32_kernel", fwd16)])
+    ok &= o and n3 >= 2
+    if n < 9 or n2 < 10 or n3 < 2:
+        print(f"expected >= 9 fp32, >= 10 split and 2 split32 kernels, found {n}, {n2} and {n3}")
     # weight-gradient GEMMs: no hand-placed scheme, but a spill there is a 2x slowdown nobody would notice
     for sym, body in disassemble(os.path.join(CSRC, "mnrf_dw.o")).items():
         s = sum("scratch_" in l for l in body)

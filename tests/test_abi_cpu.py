@@ -30,7 +30,7 @@ def test_exports_match_header(L):
 def test_packed_size_matches_layout(L):
     # fp32 streams: forward tiles 2640 + bias block 3072 floats + backward tiles 1920 + head-backward tiles 704;
     # split-f16 streams: 1312 forward + 960 trunk-backward + 352 head-backward hi/lo tile pairs of 2 KiB (mnrf_layout.h)
-    assert L.mnrf_packed_floats() == 2640 * 256 + 3072 + 1920 * 256 + 704 * 256 + (1312 + 960 + 352) * 512 + 16384   # + tail pad
+    assert L.mnrf_packed_floats() == 2640 * 256 + 3072 + 1920 * 256 + 704 * 256 + (1312 + 960 + 352 + 1328) * 512 + 16384   # + tail pad
     assert L.mnrf_version() >= 1
 
 
