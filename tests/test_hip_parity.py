@@ -10,6 +10,8 @@ Tolerances (stated once, used everywhere below):
     order-insensitive reductions (positions are not stable at 1e-4).
 In practice the HIP path agrees with the reference to ~1e-6 on the well-conditioned keys.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -164,6 +166,36 @@ def test_render_rays_golden(name):
         assert np.max(np.abs(got["weights_fine"].sum(1) - fx.outputs["weights_fine"].sum(1))) <= 1e-4
         # the multiset of fine depths moves by at most a few 1e-4 (bin flips), never wholesale
         assert np.max(np.abs(got["z_vals_fine"] - fx.outputs["z_vals_fine"])) <= 5e-3
+
+
+# --------------------------------------------------------------------------- G14: against the reference in float64
+def test_as_close_to_the_fp64_truth_as_the_reference(precision):
+    """Fixture G14 (tests/golden/make_golden_truth64.py): the reference evaluated in float64 on the inputs of
+    g3_coarse64_train.  The keys derived from the normalised autograd density gradient are noise-dominated in the
+    reference's own fp32 run (max-abs error against fp64: 8e-3 on surface_normal_grad, 1e-2 on normal_dif, 0.6 on single
+    samples of normal_coarse), which is why the plain fixture comparison carries a 2e-2 floor for them.  Here the sharper
+    question: the HIP result has to be as close to the TRUTH as the reference's fp32 result is -- max-abs error within twice
+    the reference's (plus fp32 roundoff of the key's scale), mean-abs error of the per-sample normals within twice the
+    reference's -- for both arithmetics."""
+    fx, got = _render_fixture("g3_coarse64_train")
+    z = np.load(os.path.join(os.path.dirname(FX.__file__), "g14_truth64_g3_coarse64_train.npz"))
+    checked = 0
+    for f in z.files:
+        if not f.startswith("out64__"):
+            continue
+        k = f[7:]
+        truth = z[f]
+        ref32 = fx.outputs[k].astype(np.float64)
+        hip = got[k].astype(np.float64)
+        scale = 8.0 if k.startswith(("depth", "x_surface", "z_vals")) else 1.0
+        e_ref, e_hip = np.abs(ref32 - truth), np.abs(hip - truth)
+        if k == "normal_coarse":       # per sample: a few samples with a vanishing gradient carry errors of O(1) in any fp32 run
+            assert e_hip.mean() <= 2.0 * e_ref.mean() + 1e-6, (k, e_hip.mean(), e_ref.mean())
+            assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-6, (k, np.median(e_hip), np.median(e_ref))
+        else:
+            assert e_hip.max() <= 2.0 * e_ref.max() + 2e-6 * scale, (k, e_hip.max(), e_ref.max())
+        checked += 1
+    assert checked >= 10
 
 
 # --------------------------------------------------------------------------- G13: without the optional heads
