@@ -143,7 +143,7 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     (void)hipMemsetAsync(packed + PACKED_FLOATS - 1, 0, sizeof(float), (hipStream_t)stream);   // range-guard word (mnrf.h)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
     launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
-    launch_split32_pack(params, packed, (hipStream_t)stream);   // forward stream of the 32x32x16 tuning, from the parameters
+    if (split32_enabled()) launch_split32_pack(params, packed, (hipStream_t)stream);   // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)
     return mnrf_check_launch("mnrf_pack_weights");
 }
 

@@ -4,6 +4,7 @@
 // Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mnrf_layout.h"
 #include "mnrf_field_args.h"
@@ -18,6 +19,12 @@ constexpr int CHUNK_PAIRS = 8;
 constexpr int RING_SLOTS = 4;
 #include "mnrf_field_split32.inc"
 }  // namespace h32
+
+// MNRF_SPLIT32=1 (read once): forward-only split launches take this tuning, and mnrf_pack_weights also builds its stream
+bool split32_enabled() {
+    static const bool v = [] { const char* e = getenv("MNRF_SPLIT32"); return e && atoi(e) != 0; }();
+    return v;
+}
 
 int launch_split32(const FieldArgs& A, bool sigma_only, hipStream_t s) { return h32::launch(A, sigma_only, s); }
 
