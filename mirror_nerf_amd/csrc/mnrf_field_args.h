@@ -71,6 +71,9 @@ void launch_split_pack(float* packed, hipStream_t s);
 int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s);
 // 32x32x16 tuning of the forward-only split kernels (mnrf_field_split32.hip) and the packer of its stream (from the
 // state_dict-ordered parameter pointers)
+// 48-samples-per-wave tuning of the forward-only split kernels (mnrf_field_split3.hip), MNRF_SPLIT48=1
+bool split48_enabled();
+int launch_split48(const FieldArgs& A, bool sigma_only, hipStream_t s);
 bool split32_enabled();      // MNRF_SPLIT32=1
 int launch_split32(const FieldArgs& A, bool sigma_only, hipStream_t s);
 void launch_split32_pack(const float* const* params, float* packed, hipStream_t s);

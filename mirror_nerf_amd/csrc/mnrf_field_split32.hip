@@ -4,6 +4,7 @@
 // Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "mnrf_layout.h"

@@ -92,6 +92,12 @@ def main():
     # 32x32x16 tuning of the forward-only split kernels (same hand-placed scheme; two LDS-read waits per unit of 6 MFMAs)
     o, n3 = check_object("mnrf_field_split32.o", "v_mfma_f32_32x32x16_f16", [(r"field_split32_kernel", fwd16)])
     ok &= o and n3 >= 2
+    # 48-samples-per-wave tuning (S = 3, forward only): the sigma-only kernel must not spill; the full kernel's heads spill a
+    # few B operands (safe: vmcnt waits only get stricter; reported and bounded)
+    o, n4 = check_object("mnrf_field_split3.o", "v_mfma_f32_16x16x32_f16", [
+        (r"field_split_kernelILb1ELb0", dict(fwd16, counted_re=r"s_waitcnt lgkmcnt\(0\)")),        # one unit of read-ahead: the unit's wait is lgkmcnt(0)
+        (r"field_split_kernelILb0ELb0", dict(fwd16, counted_re=r"s_waitcnt lgkmcnt\(0\)", scratch_inside_max=80, scratch_total_max=100))])
+    ok &= o and n4 >= 2
     if n < 9 or n2 < 10 or n3 < 2:
         print(f"expected >= 9 fp32, >= 10 split and 2 split32 kernels, found {n}, {n2} and {n3}")
     # weight-gradient GEMMs: no hand-placed scheme, but a spill there is a 2x slowdown nobody would notice

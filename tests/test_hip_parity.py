@@ -660,15 +660,18 @@ def test_verify_split_reports_range_problems(precision):
     assert MN.PRECISION == "split"
 
 
-def test_split32_tuning_passes_the_parity_suite():
+@pytest.mark.parametrize("switch", ["MNRF_SPLIT32", "MNRF_SPLIT48"])
+def test_split32_tuning_passes_the_parity_suite(switch):
     """MNRF_SPLIT32=1 routes the forward-only split launches to the 32x32x16 tuning (csrc/mnrf_field_split32.inc,
-    non-default: fewer cycles, lower clock -- DESIGN 9).  The switch is read once per process, so the field / render /
-    recursion parity tests, the random-shape schedule check and the range-guard tests run again in a child process."""
+    non-default: fewer cycles, lower clock -- DESIGN 9), MNRF_SPLIT48=1 to the 48-samples-per-wave tuning
+    (csrc/mnrf_field_split3.hip, non-default: a third less weight movement per sample, higher clock, spills in the heads).
+    The switches are read once per process, so the field / render / recursion parity tests, the random-shape schedule
+    check and the range-guard tests run again in a child process."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MNRF_SPLIT32="1")
+    env = dict(os.environ, **{switch: "1"})
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_hip_parity.py"),
                         os.path.join(root, "tests", "test_hip_guard.py"), "-k",
                         "split and not split32 or field_golden or render_rays_golden or recursion_eval or trained_weights_eval "
