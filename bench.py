@@ -36,7 +36,8 @@ N_SAMPLES, N_IMPORTANCE, CHUNK = 64, 128, 32768
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide, dense f16/bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 # MFMA FLOPs the split kernel EXECUTES per full sample: 1308 hi/lo tile pairs x 3 products x 2 groups x 4 waves x
-# 16384 FLOP per v_mfma_f32_16x16x32_f16 / 128 samples (= 3 x the padded fp32 count; algorithmic: MN.FLOP_FULL)
+# 16384 FLOP per v_mfma_f32_16x16x32_f16 / 128 samples (= 3 x the padded fp32 count; algorithmic: MN.FLOP_FULL); the same
+# per sample with 3 groups per wave and 192 samples per workgroup
 SPLIT_EXECUTED_FLOP_FULL = 1308 * 3 * 2 * 4 * 16384 // 128
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of THIS command
 # (scripts/pmc_passes.sh -> profiles/traffic.json, keyed by kernel name; FETCH_SIZE doubled per the guide's gfx950
@@ -416,7 +417,8 @@ def main():
     if rank == 0:
         split = a.precision == "split"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-        kernel = "mnrf::h2::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>"
+        h = "h2" if os.environ.get("MNRF_SPLIT48", "1") == "0" else "h3"     # 48 samples per wave is the default tuning
+        kernel = f"mnrf::{h}::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>"
         traffic, traffic_src = _traffic(kernel)
         res = {
             "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",

@@ -55,8 +55,10 @@ int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hi
     // 18.2 / 32.5 ms -- it hides the waits but issues twice the LDS-DMA per sample.  So was a 48-samples-per-wave tuning
     // (a third less LDS-DMA per sample): it needs all 512 registers, spills 200 bytes and ends up 1 % slower.
     // MNRF_SPLIT32=1: the forward-only launches on the 32x32x16 tuning (mnrf_field_split32.inc)
-    if (!grad && variant == 0 && !A.geo_feat && split48_enabled()) return launch_split48(A, sigma_only, s);
     if (!grad && variant == 0 && split32_enabled()) return launch_split32(A, sigma_only, s);
+    // default of the forward-only launches: 48 samples per wave (mnrf_field_split3.hip); geo_feat needs both halves of L8
+    // in registers, which that tuning cannot afford
+    if (!grad && variant == 0 && !A.geo_feat && split48_enabled()) return launch_split48(A, sigma_only, s);
     const bool big = variant == 0 ? grad : variant == 2;
     return big ? h2x::launch(A, sigma_only, grad, s) : h2::launch(A, sigma_only, grad, s);
 }

@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_split48
 mkdir -p $OUT
 : > $OUT/summary.txt
 if [ "${TESTS:-1}" = 1 ]; then
-MNRF_SPLIT48=1 timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_hip_guard.py -x -q -m gpu -k "not split32" > $OUT/tests.log 2>&1 < /dev/null
+timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_hip_guard.py -x -q -m gpu -k "not split32" > $OUT/tests.log 2>&1 < /dev/null
 echo "tests rc=$?" | tee -a $OUT/summary.txt
 tail -3 $OUT/tests.log | tee -a $OUT/summary.txt
 fi

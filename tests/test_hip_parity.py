@@ -660,18 +660,19 @@ def test_verify_split_reports_range_problems(precision):
     assert MN.PRECISION == "split"
 
 
-@pytest.mark.parametrize("switch", ["MNRF_SPLIT32", "MNRF_SPLIT48"])
+@pytest.mark.parametrize("switch", ["MNRF_SPLIT32=1", "MNRF_SPLIT48=0"])
 def test_split32_tuning_passes_the_parity_suite(switch):
-    """MNRF_SPLIT32=1 routes the forward-only split launches to the 32x32x16 tuning (csrc/mnrf_field_split32.inc,
-    non-default: fewer cycles, lower clock -- DESIGN 9), MNRF_SPLIT48=1 to the 48-samples-per-wave tuning
-    (csrc/mnrf_field_split3.hip, non-default: a third less weight movement per sample, higher clock, spills in the heads).
-    The switches are read once per process, so the field / render / recursion parity tests, the random-shape schedule
-    check and the range-guard tests run again in a child process."""
+    """The forward-only split launches run on the 48-samples-per-wave tuning by default (csrc/mnrf_field_split3.hip, DESIGN
+    9.2).  MNRF_SPLIT48=0 puts them back on the 32-samples-per-wave kernels (still the ones a geo_feat request gets),
+    MNRF_SPLIT32=1 on the 32x32x16 tuning (csrc/mnrf_field_split32.inc: fewer cycles, lower clock -- DESIGN 9.1).  The
+    switches are read once per process, so the field / render / recursion parity tests, the random-shape schedule check and
+    the range-guard tests run again in a child process for each."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **{switch: "1"})
+    name, val = switch.split("=")
+    env = dict(os.environ, **{name: val})
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_hip_parity.py"),
                         os.path.join(root, "tests", "test_hip_guard.py"), "-k",
                         "split and not split32 or field_golden or render_rays_golden or recursion_eval or trained_weights_eval "
