@@ -11,6 +11,7 @@ mnrf_reflect_compact and mnrf_blend_scatter.  One 4-byte device->host read per l
 whether (and how many) reflected rays are traced -- the reference syncs at the same place
 through `mirror_mask.bool().any()` (train.py:175, eval.py:315).
 """
+import os
 from collections import defaultdict
 from types import SimpleNamespace
 
@@ -38,6 +39,25 @@ def _threshold_(mask, want_any=True):
         _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), n, _lib.ptr(flag), _lib.stream()),
                    "mnrf_threshold_mask")
     return bool(flag.item()) if want_any else False
+
+
+def _threshold_async(mask, host_flags, slot):
+    """_threshold_ without the stream sync: the flag travels to pinned host memory behind the kernel and an event marks its
+    arrival; `_flag_ready` waits for THAT event only, so launches queued meanwhile (the next chunk's primary pass) keep
+    the GPU busy."""
+    flag = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), mask.shape[0], _lib.ptr(flag), _lib.stream()), "mnrf_threshold_mask")
+    host = host_flags[slot:slot + 1]
+    host.copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev, flag     # (flag: kept alive until the copy has run)
+
+
+def _flag_ready(pending):
+    host, ev, _ = pending
+    ev.synchronize()
+    return bool(host.item())
 
 
 def _reflect(rays, x_surface, normal, mask, compact, normal_noise=None, noise_std=0.0, want_dir=True):
@@ -275,15 +295,15 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
             return next(noise_iter).to(dev).float().contiguous()
         return torch.randn(n, 3, device=dev)
 
-    def recurse(rays_chunk, level):
+    # Level 0 runs in two stages so that chunk k+1's primary pass can be queued BEFORE the host waits for chunk k's
+    # "any mirror pixel" flag (eval.py:303-312 branches on it): the GPU then never idles on that read.  Not used with the
+    # roughness jitters, whose random draws would change order against the primary passes.
+    def stage_a(rays_chunk, level, host_flags=None, slot=0):
         r = render_rays(models, embeddings, rays_chunk, N_samples, use_disp, 0, 0, N_importance, chunk,
                         white_back, test_time=test_time,
                         compute_normal=trace_flag and (not args.predict_normal),
                         only_one_field=one_field, only_one_field_fine_epoch=fine_epoch,
                         current_epoch=fine_epoch + 1, _guard=False)
-        N = rays_chunk.shape[0]
-        dev = rays_chunk.device
-        only_in = not (level < 1)                                         # eval.py:159
         r[f"rgb_{sel}_reflect"] = torch.zeros_like(r[f"rgb_{sel}"])
         r[f"depth_{sel}_reflect"] = torch.zeros_like(r[f"depth_{sel}"])
         mask = None
@@ -294,7 +314,24 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
         # in place (eval.py:303-307); at the last level nothing branches on "any mirror pixel": no host read, so the next
         # chunk's launches queue behind this pass without a stream sync
         last = level >= args.max_recursive_level or not trace_flag
-        any_mirror = _threshold_(mask, want_any=not last) if mask is not None else False
+        pending, any_mirror = None, False
+        if mask is not None:
+            if host_flags is not None and not last and rays_chunk.shape[0]:
+                pending = _threshold_async(mask, host_flags, slot)
+            else:
+                any_mirror = _threshold_(mask, want_any=not last)
+        return r, rays_chunk, level, mask, any_mirror, pending
+
+    def recurse(rays_chunk, level):
+        return stage_b(stage_a(rays_chunk, level))
+
+    def stage_b(state):
+        r, rays_chunk, level, mask, any_mirror, pending = state
+        if pending is not None:
+            any_mirror = _flag_ready(pending)
+        N = rays_chunk.shape[0]
+        dev = rays_chunk.device
+        only_in = not (level < 1)                                         # eval.py:159
         trace = bool(mask is not None and any_mirror and trace_flag)
         if level >= args.max_recursive_level:
             trace = False
@@ -352,8 +389,18 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
         return r
 
     results = defaultdict(list)
-    for i in range(0, rays.shape[0], chunk):
-        out = recurse(rays[i:i + chunk].contiguous(), 0)
+    starts = list(range(0, rays.shape[0], chunk))
+    pipelined = rays.is_cuda and not rough and len(starts) > 1 and os.environ.get("MNRF_EVAL_PIPELINE", "1") != "0"
+    host_flags = torch.zeros(2, dtype=torch.int32).pin_memory() if pipelined else None
+    ahead = stage_a(rays[:chunk].contiguous(), 0, host_flags, 0) if (pipelined and starts) else None
+    for n_c, i in enumerate(starts):
+        if pipelined:
+            state = ahead
+            ahead = stage_a(rays[starts[n_c + 1]:starts[n_c + 1] + chunk].contiguous(), 0, host_flags, (n_c + 1) % 2) \
+                if n_c + 1 < len(starts) else None
+            out = stage_b(state)
+        else:
+            out = recurse(rays[i:i + chunk].contiguous(), 0)
         for k, v in out.items():
             if to_cpu == "maps":
                 if v.dim() <= 2 and (v.dim() == 1 or v.shape[1] <= 3):     # per-ray maps only
