@@ -460,6 +460,36 @@ __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
     if (tid == 0) *A.count = s_base;
 }
 
+// Without compaction (eval level 0 traces every ray, eval.py:159) ray i lands in row i: no ordering to preserve, one thread
+// per ray over the whole chip instead of one workgroup walking the chunk (158 us per 32768-ray chunk, 3 ms per frame).
+__global__ __launch_bounds__(256) void reflect_all_kernel(ReflArgs A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *A.count = (int)A.n;
+    if (i >= A.n) return;
+    float nv[3], wvv[3], r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        nv[k] = A.normal[i * 3 + k];
+        if (A.normal_noise) nv[k] = nv[k] + A.normal_noise[i * 3 + k] * A.noise_std;   // eval.py:506-511
+        wvv[k] = -A.rays[i * 8 + 3 + k];
+    }
+    // the same expressions, in the same order, as reflect_compact_kernel
+    const float ninv = 1.f / sqrtf(fmaxf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2], EPS32));
+    const float winv = 1.f / sqrtf(fmaxf(wvv[0] * wvv[0] + wvv[1] * wvv[1] + wvv[2] * wvv[2], EPS32));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nv[k] = nv[k] * ninv; wvv[k] = wvv[k] * winv; }
+    const float c = wvv[0] * nv[0] + wvv[1] * nv[1] + wvv[2] * nv[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = 2.f * c * nv[k] - wvv[k];
+    if (A.reflect_dir) { for (int k = 0; k < 3; ++k) A.reflect_dir[i * 3 + k] = r[k]; }
+    float* o = A.sec + i * 8;
+    o[0] = A.x_surface[i * 3]; o[1] = A.x_surface[i * 3 + 1]; o[2] = A.x_surface[i * 3 + 2];
+    o[3] = r[0]; o[4] = r[1]; o[5] = r[2];
+    o[6] = A.near2;
+    o[7] = A.rays[i * 8 + 7];
+    A.index[i] = (int)i;
+}
+
 // ------------------------------------------------------------------ blend / scatter
 // train.py:261-296, eval.py:676-697
 __global__ void blend_all_kernel(const float* __restrict__ base, const float* __restrict__ sec, const float* __restrict__ mask,
@@ -679,7 +709,10 @@ extern "C" int mnrf_reflect_compact(const float* rays, const float* x_surface, c
     if (compact && n_rays > 0 && !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: compaction needs the mask");
     ReflArgs A{rays, x_surface, normal, normal_noise, noise_std, mask, (long long)n_rays, compact, near2,
                sec_rays, index, count, reflect_dir};
-    hipLaunchKernelGGL(reflect_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    if (!compact && n_rays > 0)
+        hipLaunchKernelGGL(reflect_all_kernel, dim3(blocks_for(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    else
+        hipLaunchKernelGGL(reflect_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_reflect_compact");
 }
 
