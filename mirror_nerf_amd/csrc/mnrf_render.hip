@@ -302,6 +302,51 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompBwdArgs A) 
 // cdf is accumulated in double and rounded per entry, as ATen's CPU cumsum does.
 constexpr int SF_MAX = 512;   // S + n_importance <= 512, S <= 256
 
+// ascending bitonic sort of 64*NE values held as v[e] = element (lane + 64 e); compare-exchange semantics of the LDS version
+// (lower index gets the smaller value in an ascending block)
+template <int NE>
+__device__ __forceinline__ void sort_store(const float* srt, int lane, float* out, int T) {
+    float v[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = srt[lane + 64 * e];
+#pragma unroll
+    for (int k = 2; k <= 64 * NE; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            if (jj >= 64) {
+                const int je = jj / 64;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if ((e ^ je) > e) {
+                        const bool up = ((lane + 64 * e) & k) == 0;
+                        const float a = v[e], b = v[e ^ je];
+                        const bool sw = (a > b) == up;
+                        v[e] = sw ? b : a;
+                        v[e ^ je] = sw ? a : b;
+                    }
+                }
+            } else {
+                const bool lower = (lane & jj) == 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const bool up = ((lane + 64 * e) & k) == 0;
+                    const float mine = v[e];
+                    const float other = __shfl_xor(mine, jj);
+                    // the pair (lo, hi): lo keeps min when ascending; "a > b swaps" leaves equal values in place
+                    const float lo = lower ? mine : other, hi = lower ? other : mine;
+                    const bool sw = (lo > hi) == up;
+                    v[e] = lower ? (sw ? hi : lo) : (sw ? lo : hi);
+                }
+            }
+        }
+    }
+    if (out) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < T) out[lane + 64 * e] = v[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
                                                           long long n_rays, int S, const float* __restrict__ u, int u_per_ray,
                                                           int n_imp, float* __restrict__ z_fine) {
@@ -345,7 +390,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     int P2 = 1;
     while (P2 < T) P2 <<= 1;
     for (int i = lane; i < S; i += 64) srt[i] = zc[i];
-    for (int i = T + lane; i < P2; i += 64) srt[i] = __builtin_inff();
+    for (int i = T + lane; i < (P2 < 64 ? 64 : P2); i += 64) srt[i] = __builtin_inff();      // the sort works on >= 64 values
     __syncthreads();
     // inverse CDF
     for (int j = lane; j < n_imp; j += 64) {
@@ -365,22 +410,13 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
         srt[S + j] = b0 + (uj - c0) / denom * (b1 - b0);
     }
     __syncthreads();
-    // bitonic sort of P2 values
-    for (int k = 2; k <= P2; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int i = lane; i < P2; i += 64) {
-                const int ixj = i ^ jj;
-                if (ixj > i) {
-                    const float a = srt[i], b = srt[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (live)
-        for (int i = lane; i < T; i += 64) z_fine[ray * T + i] = srt[i];
+    // bitonic sort of P2 values, in REGISTERS: lane l holds elements l, l + 64, ...; a partner at distance < 64 is another
+    // lane's register of the same slot (one __shfl_xor), a partner at distance >= 64 another slot of the same lane.  (In
+    // LDS, with a barrier per step, the 36 steps of a 256-value sort were a chain of dependent LDS round trips.)
+    if (P2 <= 64) sort_store<1>(srt, lane, live ? z_fine + ray * T : nullptr, T);
+    else if (P2 == 128) sort_store<2>(srt, lane, live ? z_fine + ray * T : nullptr, T);
+    else if (P2 == 256) sort_store<4>(srt, lane, live ? z_fine + ray * T : nullptr, T);
+    else sort_store<8>(srt, lane, live ? z_fine + ray * T : nullptr, T);
 }
 
 // ------------------------------------------------------------------ mask threshold
