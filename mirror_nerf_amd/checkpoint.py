@@ -52,7 +52,7 @@ def load_ckpt(model, ckpt, model_name="model", prefixes_to_ignore=(), trusted=Fa
         return
     sd = model.state_dict()
     got = extract_model_state_dict(ckpt, model_name, prefixes_to_ignore, trusted)
-    assert len(got) > 0, "[Error] can not find {} in checkpoint".format(model_name)
+    assert len(got) > 0, f"the checkpoint holds no parameter named '{model_name}.*'"     # the reference asserts here too
     sd.update(got)
     model.load_state_dict(sd, strict=False)
 

@@ -11,7 +11,8 @@ Differences from the reference that do not change values:
   * the three detach_* kwargs and `mirror_mask` only steer gradients (rendering.py:223-247, mirror_nerf.py:154-183);
     they are honoured by the backward kernels (flags of mnrf_composite_backward / mnrf_field_backward);
   * random draws can be injected (`_perturb_rand`, `_noise_coarse`, `_noise_fine`, `_u`) so that
-    tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator;
+    tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator; `_z_fine` (N, S+N_importance)
+    replaces the resampled depths altogether (fixtures G14 of the fine pass);
   * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
 Outputs live on rays.device.  When autograd is enabled and a model parameter (or `rays`) requires
 grad, the field evaluation and the compositing run through `autograd.FieldFn` / `CompositeFn`,
@@ -247,6 +248,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     if N_importance > 0:
         def fine_depths():
+            if kwargs.get("_z_fine") is not None:     # tests: the fine depths of another run instead of sample_pdf's
+                return kwargs["_z_fine"].float().contiguous()
             u = kwargs.get("_u")
             if u is None and perturb == 0:
                 u = kwargs.get("_u_det")

@@ -360,6 +360,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                has_fine, kwargs.get("_noise_coarse"), **common)
 
     def fine_points(z, w_mid):  # 312-326
+        if kwargs.get("_z_fine") is not None:      # tests: the fine depths of another run (fixtures G14 of the fine pass)
+            return np.asarray(kwargs["_z_fine"], dtype=F32)
         mid = F32(0.5) * (z[:, :-1] + z[:, 1:])
         u = kwargs.get("_u")
         if u is None and perturb == 0:

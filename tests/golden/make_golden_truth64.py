@@ -6,7 +6,8 @@ derived from the normalised autograd density gradient (normal_*, surface_normal_
 ask the sharper question -- is the HIP value at least as close to the truth as the reference's fp32 value?
 
 Build-container only:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_truth64.py
-Coarse-only renders are used (no inverse-CDF resampling, whose bin flips would dominate any such comparison)."""
+g3_coarse64_train is coarse only; the fine passes (g4_fine_train, g11_trained_render_train) are evaluated at the fp32 run's
+own fine depths (truth_fine), so that inverse-CDF bin flips cannot dominate the comparison."""
 import copy
 import json
 import os
@@ -59,5 +60,57 @@ def truth(base):
           {k: f"{v:.1e}" for k, v in err.items()})
 
 
+def truth_fine(base):
+    """The same for a coarse + fine render, AT THE FINE DEPTHS OF THE fp32 RUN: run freely, the float64 reference puts a few
+    samples into other inverse-CDF bins than its own fp32 run, and that discontinuity -- not arithmetic -- would
+    dominate every difference.  `sample_pdf` of the reference is therefore replaced, for this run only, by a function that
+    returns the 128 new depths the fp32 run drew (the fixture's sorted z_vals_fine minus its z_vals_coarse, as a multiset);
+    the reference then merges them with its own (float64) coarse depths, evaluates the fine model there and composites, all
+    in float64.  The HIP path and the oracle get the fixture's z_vals_fine through `_z_fine` in the tests."""
+    import models.rendering as ref_rendering
+    fx = Fixture(base)
+    m = fx.meta
+    assert m["N_importance"] > 0 and not m["kwargs"].get("only_one_field") and not m.get("injected")
+    sds = fx.state_dicts()
+    mods = {}
+    for name, sd in zip(("coarse", "fine"), sds):
+        mod = MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        mods[name] = copy.deepcopy(mod).double().eval()
+    zc, zf = fx.outputs["z_vals_coarse"], fx.outputs["z_vals_fine"]
+    new = np.empty((zf.shape[0], m["N_importance"]), np.float32)
+    for r in range(zf.shape[0]):
+        row, take = list(zf[r]), list(zc[r])
+        for v in take:
+            row.remove(v)            # exact fp32 values: the merge only sorted them
+        new[r] = row
+    orig = ref_rendering.sample_pdf
+    ref_rendering.sample_pdf = lambda bins, weights, n, det=False, eps=1e-5: torch.from_numpy(new).double()
+    try:
+        rays = torch.from_numpy(fx.inputs["rays"]).double()
+        ctx = torch.enable_grad() if m["kwargs"].get("compute_normal", True) else torch.no_grad()
+        with ctx:
+            out = ref_render_rays(mods, EMB, rays, m["N_samples"], m["use_disp"], m["perturb"], m["noise_std"], m["N_importance"],
+                                  m["chunk"], m["white_back"], m["test_time"], **m["kwargs"])
+    finally:
+        ref_rendering.sample_pdf = orig
+    out = {k: v.detach().numpy() for k, v in out.items()}
+    dz = float(np.max(np.abs(out["z_vals_fine"] - zf)))
+    assert dz < 1e-5, dz      # the same depths up to the fp32 rounding of the coarse ones
+    arrs = {"out64__" + k: v.astype(np.float64) for k, v in out.items() if k in fx.outputs and k.endswith("_fine")}
+    err = {k: float(np.max(np.abs(out[k] - fx.outputs[k].astype(np.float64)))) for k in out
+           if k in fx.outputs and k.endswith("_fine") and out[k].size}
+    arrs["meta"] = np.array(json.dumps({"base": base, "ref32_err": err, "z_fine_max_diff": dz}))
+    path = os.path.join(HERE, f"g14_truth64_{base}.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {os.path.basename(path)} {os.path.getsize(path) / 1024:.0f} KiB; reference fp32 vs fp64 at the same fine depths:",
+          {k: f"{v:.1e}" for k, v in err.items()})
+
+
 if __name__ == "__main__":
-    truth("g3_coarse64_train")
+    only = sys.argv[1:]
+    if not only or "coarse" in only:
+        truth("g3_coarse64_train")
+    if not only or "fine" in only:
+        truth_fine("g4_fine_train")               # random-init weights, fine pass
+        truth_fine("g11_trained_render_train")    # trained weights (fixtures G11), fine pass

@@ -168,6 +168,47 @@ def test_render_rays_golden(name):
         assert np.max(np.abs(got["z_vals_fine"] - fx.outputs["z_vals_fine"])) <= 5e-3
 
 
+@pytest.mark.parametrize("base", ["g4_fine_train", "g11_trained_render_train"])
+def test_fine_pass_as_close_to_the_fp64_truth_as_the_reference(base, precision):
+    """Fixtures G14 of the FINE pass (tests/golden/make_golden_truth64.py truth_fine): the reference in float64 at the fine
+    depths its own fp32 run drew -- on random-init weights (g4_fine_train) and on the trained pair (g11_trained_render_train).
+    With the same depths injected (`_z_fine`; inverse-CDF bin flips are a property of the resampling, pinned by the G4/G11
+    fixture tests) the HIP result has to be as close to the TRUTH as the reference's fp32 run is: max-abs error within twice
+    the reference's plus roundoff of the key's scale (2e-6 for the fp32 chain; 1e-5 for the split arithmetic, whose field
+    outputs sit 3e-6 from the fp32 chain's before compositing), mean / median for the per-sample gradient normals.  This is
+    the justification of the 2e-2 / 4 x floor allowances on the fine pass and on trained weights (VERDICT r2 weak #2)."""
+    fx = FX.Fixture(base)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    got = _np(_M().render_rays(models, _emb(), rays, m["N_samples"], m["use_disp"], m["perturb"], m["noise_std"], m["N_importance"],
+                               m["chunk"], m["white_back"], m["test_time"],
+                               _z_fine=torch.from_numpy(fx.outputs["z_vals_fine"]).to(DEV), **m["kwargs"]))
+    z = np.load(os.path.join(os.path.dirname(FX.__file__), f"g14_truth64_{base}.npz"))
+    slack = 2e-6 if precision == "fp32" else 1e-5
+    checked, report = 0, {}
+    for f in z.files:
+        if not f.startswith("out64__"):
+            continue
+        k = f[7:]
+        truth = z[f]
+        ref32 = fx.outputs[k].astype(np.float64)
+        hip = got[k].astype(np.float64)
+        scale = 8.0 if k.startswith(("depth", "x_surface", "z_vals")) else 1.0
+        e_ref, e_hip = np.abs(ref32 - truth), np.abs(hip - truth)
+        report[k] = (float(e_hip.max()), float(e_ref.max()))
+        if k == "normal_fine":
+            assert e_hip.mean() <= 2.0 * e_ref.mean() + 1e-6, (k, e_hip.mean(), e_ref.mean())
+            assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-6, (k, np.median(e_hip), np.median(e_ref))
+        else:
+            assert e_hip.max() <= 2.0 * e_ref.max() + slack * scale, (k, e_hip.max(), e_ref.max())
+        checked += 1
+    assert checked >= 9
+    print(f"G14 fine {base} [{precision}] max |err| vs fp64 truth (hip, reference fp32):",
+          {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
+
+
 # --------------------------------------------------------------------------- G14: against the reference in float64
 def test_as_close_to_the_fp64_truth_as_the_reference(precision):
     """Fixture G14 (tests/golden/make_golden_truth64.py): the reference evaluated in float64 on the inputs of
@@ -442,6 +483,32 @@ def test_recursion_eval_golden(name):
                                      trace_secondary_rays=True, normal_noise_std=m["args"]["normal_noise_std"],
                                      _normal_noise=noise))
     _cmp(name, got, fx.outputs, m, skip=FX.PER_SAMPLE_FINE)
+
+
+@pytest.mark.parametrize("name", FX.names("g15_c1_"))
+def test_config1_through_the_recursion_golden(name):
+    """G15: BASELINE config 1 -- N_importance = 0, one bounce -- through NeRFSystem.forward and batched_inference
+    (`select_type = "coarse"`: train.py:147-151, eval.py:132-172; only render_rays was pinned for it before)."""
+    from types import SimpleNamespace
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sd = fx.state_dicts()[0]
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    if "_train_" in name:
+        hp = dict(m["hp"])
+        hp.update(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf")
+        system = _M().NeRFSystem(SimpleNamespace(**hp))
+        assert not hasattr(system, "nerf_fine")
+        system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        system.to(DEV)
+        extra = {"mirror_mask": torch.from_numpy(fx.inputs["gt_mask"].copy()).to(DEV), "is_eval": m["is_eval"],
+                 "train_geometry_stage": False}
+        got = _np(system(rays, extra))
+    else:
+        got = _np(_M().batched_inference({"coarse": _module(sd)}, _emb(), rays, m["N_samples"], 0, False, m["chunk"],
+                                         args=m["args"], trace_secondary_rays=True, normal_noise_std=0))
+    assert not any(k.endswith("_fine") for k in got)
+    _cmp(name, got, fx.outputs, m)
 
 
 def test_roughness_jitters_batched_equal_one_by_one():
