@@ -234,27 +234,12 @@ def _respawn(a):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def _smi_sample(device_index, delay_s, out):
-    """Board power and shader clock of this rank's GPU while the timed frames run (rocm-smi, one sample `delay_s` after
-    the start): the dominant kernel runs at the package power limit, so the clock it gets -- not the 2.4 GHz the MFMA peak
-    is quoted at -- sets its speed.  Best effort: any failure leaves the fields null."""
-    import re
-    import subprocess
-    time.sleep(delay_s)
+def _build_commit():
     try:
-        txt = subprocess.run(["rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"],
-                             capture_output=True, text=True, timeout=10).stdout
-        m = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
-        if m:
-            out["sclk_mhz"] = int(m.group(1))
-        m = re.search(r"(?:Current Socket|Average) Graphics Package Power \(W\):\s*([\d.]+)", txt)
-        if m:
-            out["power_w"] = float(m.group(1))
-        m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", txt)
-        if m:
-            out["power_cap_w"] = float(m.group(1))
-    except Exception:      # noqa: BLE001  (no rocm-smi, no permission, timeout: the bench line does not depend on it)
-        pass
+        with open(os.path.join(ROOT, "mirror_nerf_amd", "BUILD_COMMIT")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def _traffic(kernel):
@@ -262,9 +247,9 @@ def _traffic(kernel):
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
         e = t.get(kernel)
-        return (e["hbm_bytes_per_launch"], e.get("source")) if e else (None, None)
+        return (e["hbm_bytes_per_launch"], e.get("source"), e.get("commit")) if e else (None, None, None)
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def main():
@@ -318,18 +303,17 @@ def main():
         out = render(rays)
     sync()
     MN.LAUNCH_LOG = []
-    smi, smi_thread = {}, None
-    if rank == 0:
-        import threading
-        smi_thread = threading.Thread(target=_smi_sample, args=(dev.index or 0, 1.0, smi), daemon=True)
-        smi_thread.start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = render(rays)
-    sync()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
-    if smi_thread is not None:
-        smi_thread.join(timeout=15)
+    # clock / power / temperature / throttle state of this rank's GPU, sampled every 200 ms THROUGH the timed frames
+    # (mirror_nerf_amd/telemetry.py): the dominant kernel runs at the package power limit, so the clock the box grants sets
+    # its speed -- the line must be able to tell a slow box from slow code
+    from mirror_nerf_amd.telemetry import SmiSampler
+    smi_main = SmiSampler(dev.index or 0, 0.2)
+    with smi_main:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = render(rays)
+        sync()
+        dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
 
     n_mirror = int((out["mirror_mask_fine"] != 0).sum().item())
@@ -374,17 +358,19 @@ def main():
 
     # the other arithmetic on ONE whole frame of the same workload, for the record: rays/s and the dominant kernel's rate
     other = "fp32" if a.precision == "split" else "split"
-    other_tf = other_rays = other_ms = None
+    other_tf = other_rays = other_ms = smi_other = None
     host_maps = None
     if world == 1:
         MN.set_precision(other)
         render(rays)                 # warm-up (first launches of the other kernels)
         torch.cuda.synchronize()
         MN.LAUNCH_LOG = []
-        t1 = time.perf_counter()
-        render(rays)
-        torch.cuda.synchronize()
-        dt_o = time.perf_counter() - t1
+        smi_other = SmiSampler(dev.index or 0, 0.2)
+        with smi_other:
+            t1 = time.perf_counter()
+            render(rays)
+            torch.cuda.synchronize()
+            dt_o = time.perf_counter() - t1
         t_o = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG if not (flags & 1)]
         other_tf = sum(B for B, _ in t_o) * MN.FLOP_FULL / (sum(t for _, t in t_o) * 1e-3) / 1e12
         other_rays = (H * W * 2) / dt_o
@@ -419,14 +405,18 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         h = "h2" if os.environ.get("MNRF_SPLIT48", "1") == "0" else "h3"     # 48 samples per wave is the default tuning
         kernel = f"mnrf::{h}::field_split_kernel<false,false>" if split else "mnrf::s2::field_kernel<false,false>"
-        traffic, traffic_src = _traffic(kernel)
+        traffic, traffic_src, traffic_commit = _traffic(kernel)
+        tele = smi_main.summary()
+        sclk = smi_main.median_sclk()
+        # the peak the kernel could reach at the clock this box granted it (peak is quoted at 2.4 GHz)
+        granted_peak = peak * sclk / 2400.0 if sclk else None
         res = {
             "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 carried as hi/lo f16 pairs (f16 MFMA, f32 accumulate; max |diff| to the fp32 chain 3e-6)"
                      if split else "f32",
-            "data": "synthetic",
+            "data": "synthetic", "code_commit": _build_commit(),
             "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
                                    "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
                                    "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
@@ -442,16 +432,25 @@ def main():
                          "executed_tflops": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL),
                          "executed_frac": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL) / peak,
                          "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_at_granted_clock": achieved / granted_peak if granted_peak else None,
+                         "granted_clock_note": "frac with `peak` scaled to the median shader clock sampled through the timed frames "
+                                               "(telemetry.sclk_mhz.median / 2400 MHz): separates what the box granted from what the code does",
                          "traffic": traffic,
-                         "traffic_note": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this "
-                                          f"command: {traffic_src}; algorithmic bytes are 36 B/sample") if traffic is not None
-                                         else "no PMC pass on record for this kernel (profiles/traffic.json)",
+                         "traffic_source": (f"static profile: profiles/traffic.json, measured at commit {traffic_commit or 'unrecorded'} "
+                                            f"by {traffic_src}") if traffic is not None else None,
+                         "traffic_note": ("HBM bytes per launch = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE from separate rocprofv3 "
+                                          "--pmc passes over one chunk of this workload (PMC counters cannot be read inside this run; "
+                                          "scripts/profile_round.sh regenerates the file); algorithmic bytes are 36 B/sample")
+                                         if traffic is not None else "no PMC pass on record for this kernel (profiles/traffic.json)",
+                         "telemetry": tele,
                          "kernel": kernel + " (full 4-head evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
                          "flop_per_sample": MN.FLOP_FULL,
-                         "sclk_mhz_under_load": smi.get("sclk_mhz"), "board_power_w_under_load": smi.get("power_w"),
-                         "board_power_cap_w": smi.get("power_cap_w"),
-                         "power_note": "rocm-smi sample taken 1 s into the timed frames; the split-f16 kernels run at the package power "
+                         "sclk_mhz_under_load": (tele["sclk_mhz"] or {}).get("median"),
+                         "board_power_w_under_load": (tele["power_w"] or {}).get("median"),
+                         "board_power_cap_w": tele["power_cap_w"],
+                         "power_note": "medians of the 200 ms samples taken through the timed frames (`telemetry` has min/median/max, "
+                                       "throttle bits and the power-limit residency); the split-f16 kernels run at the package power "
                                        "limit and get ~2.1-2.2 GHz instead of the 2.4 GHz `peak` assumes (DESIGN.md 9.1)",
                          "sigma_only_kernel_tflops": sig_tf,
                          "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
@@ -460,7 +459,10 @@ def main():
             res["roofline"]["other_precision"] = {
                 "precision": other, "achieved": other_tf, "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
                 "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
-                "avg_launch_ms": other_ms, "rays_per_s": other_rays, "note": "one frame of the same workload with the other arithmetic"}
+                "avg_launch_ms": other_ms, "rays_per_s": other_rays, "note": "one frame of the same workload with the other arithmetic",
+                "telemetry": smi_other.summary() if smi_other is not None else None,
+                "frac_at_granted_clock": (other_tf / ((PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS) * smi_other.median_sclk() / 2400.0)
+                                          if (smi_other is not None and smi_other.median_sclk()) else None)}
         if strong is not None:
             res["strong_scaling"] = strong
         if host_maps is not None:

@@ -134,7 +134,11 @@ class FieldFn(torch.autograd.Function):
         ctx.param_shapes = [tuple(t.shape) for t in params]
         from .weights import param_refs
         ctx.param_names = [full for _, _, full in param_refs(module)]     # same order as `params` (weights.params_of)
-        # how many evaluations of this module await their backward (primary + reflected rays: see backward)
+        # how many evaluations of this module await their backward (primary + reflected rays: see backward).  A gradient
+        # buffer still pending at FORWARD time belongs to a backward pass that died (an exception skips the engine's
+        # end-of-pass callbacks): drop it together with its count
+        if module.__dict__.pop("_mnrf_pending", None) is not None:
+            module.__dict__["_mnrf_uses"] = 0
         module.__dict__["_mnrf_uses"] = module.__dict__.get("_mnrf_uses", 0) + 1
         if normal is None:
             normal = f(0, 3)
@@ -156,17 +160,18 @@ class FieldFn(torch.autograd.Function):
         g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
         # A module evaluated several times in one step (primary rays, then reflected rays: train.py:253-259) gets one
         # gradient per evaluation and autograd would add them with one kernel per parameter (64 launches per step).
-        # Instead the FIRST backward of a pass allocates the gradient tensors and hands them to autograd; the following
-        # ones ADD into those same tensors in the finish kernel (MNRF_DW_ACCUMULATE) and return None.  The tensors are
-        # remembered on the module only until the backward pass ends (engine callback) or the last pending evaluation has
-        # run -- dropping our reference then lets AccumulateGrad adopt them without a copy.  A mis-count can only cost that
-        # copy or fall back to autograd's additions, never a wrong sum.
+        # Instead the evaluations of a pass add into ONE private set of tensors in the finish kernel (MNRF_DW_ACCUMULATE)
+        # and return None; the LAST pending evaluation (count from the forwards) hands the complete tensors to autograd,
+        # which sums them with whatever other consumers of the parameters contribute (a weight regulariser ...).  Nothing
+        # is handed over before it is complete, so autograd never holds a tensor that is still being added into.  An
+        # end-of-pass callback, registered by the first evaluation of every pass, covers a mis-count (an evaluation whose
+        # outputs never reached the loss): gradients still pending then are added to `.grad` directly.
         mod = ctx.module
         uses = max(0, mod.__dict__.get("_mnrf_uses", 1) - 1)
         mod.__dict__["_mnrf_uses"] = uses
         pending = mod.__dict__.get("_mnrf_pending") if FOLD_GRADS else None
-        accumulate = pending is not None and [tuple(t.shape) for t in pending] == ctx.param_shapes
-        d_params = pending if accumulate else [f(*s) for s in ctx.param_shapes]
+        accumulate = pending is not None and [tuple(t.shape) for t in pending[0]] == ctx.param_shapes
+        d_params = pending[0] if accumulate else [f(*s) for s in ctx.param_shapes]
         from .weights import PARAM_NAMES, PARAM_SHAPES
         by_name = dict(zip(ctx.param_names, d_params))
         # the kernels write all 32 gradients in state_dict order; an absent optional head gets scratch buffers
@@ -194,17 +199,29 @@ class FieldFn(torch.autograd.Function):
         elif not accumulate:
             for t in d_params:
                 t.zero_()
-        if FOLD_GRADS and B:
+        hand_over = True
+        if FOLD_GRADS:
             if accumulate:
-                if uses == 0:
+                hand_over = uses == 0         # the last pending evaluation: the private tensors are complete
+                if hand_over:
                     mod.__dict__.pop("_mnrf_pending", None)
-            elif uses > 0:
-                mod.__dict__["_mnrf_pending"] = d_params
+            elif pending is None and uses > 0:
+                # first evaluation of the pass with more to come: keep the tensors private
+                mod.__dict__["_mnrf_pending"] = (d_params, ctx.param_names)
 
                 def _end_of_pass(m=mod):
-                    m.__dict__.pop("_mnrf_pending", None)
+                    left = m.__dict__.pop("_mnrf_pending", None)
                     m.__dict__["_mnrf_uses"] = 0
+                    if left is not None:      # never handed over (mis-count): deliver the sum ourselves
+                        by = dict(zip(left[1], left[0]))
+                        from .weights import param_refs
+                        for sub, pname, full in param_refs(m):
+                            q, gq = sub._parameters[pname], by.get(full)
+                            if gq is not None and q is not None and q.requires_grad:
+                                q.grad = gq if q.grad is None else q.grad.add_(gq)
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
+                hand_over = False
+            # else: a single evaluation (or tensors of another shape pending): the fresh tensors go to autograd
         g_xyz = g_rays = g_de = None
         if d_xyz is not None:
             if xyz is not None:
@@ -218,7 +235,7 @@ class FieldFn(torch.autograd.Function):
                 g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
         if d_dir is not None:
             g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
-        return (None, None, g_xyz, g_rays, None, g_de, None, *([None] * len(d_params) if accumulate else d_params))
+        return (None, None, g_xyz, g_rays, None, g_de, None, *(d_params if hand_over else [None] * len(d_params)))
 
 
 class EmbedFn(torch.autograd.Function):

@@ -10,8 +10,13 @@ gets the same from Lightning DDP, train.py:577-584).
 """
 import os
 
-import torch
-import torch.distributed as dist
+# The host driver of the MI355X boxes only supports dmabuf IPC: RCCL (and any CUDA-tensor sharing between processes) fails
+# with `hipIpcGetMemHandle: invalid argument` unless this is set BEFORE the HIP/HSA runtime initialises -- i.e. before
+# the first torch.cuda call of the process, which init_from_env() itself makes.  Hence at import time, not there.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 TILE = 4096
 
@@ -39,7 +44,6 @@ def init_from_env(device=None):
     if want_group and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver
         if device.type == "cuda":
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=device)
         else:

@@ -283,6 +283,12 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     white_back = kwargs.get("white_back", False)
     noise_std = kwargs.get("normal_noise_std", 0)
     noise_iter = kwargs.get("_normal_noise")
+    if noise_iter is not None and not isinstance(noise_iter, (list, tuple)):
+        # injected draws are kept as a list in kwargs so that a range-guard retry (below) replays the SAME draws
+        kwargs = dict(kwargs, _normal_noise=list(noise_iter))
+        noise_iter = kwargs["_normal_noise"]
+    if noise_iter is not None:
+        noise_iter = iter(noise_iter)
     to_cpu = kwargs.get("to_cpu", True)
     rough = getattr(args, "app_control_mirror_roughness", False)
     batch_jitter = kwargs.get("batch_jitter", noise_iter is None)   # see the roughness branch of recurse()
@@ -388,6 +394,9 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
                 r[f"depth_{sel}_reflect"] = r2[f"depth_{sel}"]
         return r
 
+    # MNRF_EVAL_PIPELINE (default on): chunk k+1's primary pass is queued before chunk k's reflected pass, so the
+    # per-sample tensors of TWO chunks are alive at once (~2 x 3 KB/ray x chunk: 200 MB at chunk 32768) -- set it to 0 on a
+    # memory-tight device.  With random roughness draws (no injection) a guard retry draws afresh, as any re-render would.
     results = defaultdict(list)
     starts = list(range(0, rays.shape[0], chunk))
     pipelined = rays.is_cuda and not rough and len(starts) > 1 and os.environ.get("MNRF_EVAL_PIPELINE", "1") != "0"

@@ -3,6 +3,7 @@ HIP kernels, one flat gradient all-reduce, Adam.  The Lightning loop of the refe
 (train.py:386-458) is out of scope; this is the arithmetic a `training_step` performs, used by
 bench.py and scripts/bench_train.py with synthetic batches (1024 rays, perturb = noise_std = 1,
 train.py defaults)."""
+import os
 import time
 from types import SimpleNamespace
 
@@ -55,14 +56,34 @@ def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
             "detach_density_for_normal_loss": getattr(hp, "detach_density_for_normal_loss", False)}
 
 
+GUARD_SYNC = os.environ.get("MNRF_GUARD_SYNC", "0") == "1"
+
+
 def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
-    from .mirror_nerf import guard_async_begin, guard_async_end
-    guard_async_end(system.__dict__.pop("_mnrf_guard_token", None))    # the previous step's range-guard words (no queue drain)
-    res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
-    loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    system.__dict__["_mnrf_guard_token"] = guard_async_begin(system)   # forward + backward flags of THIS step, read at the next
+    """One optimisation step.  Range guard of the split arithmetic (mirror_nerf.check_guard): by default its flag is read
+    ASYNCHRONOUSLY and a trip is learnt one step late -- the update of the tripping step, computed from saturated
+    operands, has then been applied (a RuntimeWarning says so; every later step runs on the fp32 kernels).  With
+    MNRF_GUARD_SYNC=1 the flag is read before the optimizer step (a queue drain, ~6 % of the step): a tripped step is
+    recomputed on the fp32 kernels and nothing tainted ever reaches the weights."""
+    from .mirror_nerf import check_guard, guard_async_begin, guard_async_end
+    if guard_async_end(system.__dict__.pop("_mnrf_guard_token", None)):    # the previous step's range-guard words (no queue drain)
+        import warnings
+        warnings.warn("mirror_nerf_amd: the PREVIOUS optimizer update was computed with operands outside the range of the "
+                      "split-f16 arithmetic and has been applied (asynchronous guard); set MNRF_GUARD_SYNC=1 to recompute such a "
+                      "step on the fp32 kernels before it reaches the weights", RuntimeWarning, stacklevel=2)
+
+    def fwd_bwd():
+        res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
+        loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+    loss = fwd_bwd()
+    if GUARD_SYNC:
+        if check_guard(system):          # the models are pinned to fp32 now: this step again, exactly
+            loss = fwd_bwd()
+    else:
+        system.__dict__["_mnrf_guard_token"] = guard_async_begin(system)   # forward + backward flags of THIS step, read at the next
     D.allreduce_gradients(params_of(system))                  # RCCL over xGMI when world_size > 1
     optimizer.step()
     return loss
@@ -113,7 +134,11 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
     # second-order pass adds a tangent pass, the density-gradient chain once more and the trunk weight gradients
     # (3 x 982 528).  Priced against the dense f16 MFMA peak (the split path; the dW GEMMs run bf16 x 6 on the same pipe).
     from .mirror_nerf import FLOP_FULL, FLOP_GRAD
-    samples = (batch * steps + refl) * (64 + 128)
+    hp = system.hparams
+    # field evaluations per ray of a training render: N_samples coarse + (N_samples + N_importance) fine, all full 4-head
+    # evaluations (rendering.py:304-360).  run.sh:266 trains with --N_importance 64 (default_hparams): 64 + 128 = 192
+    spr = hp.N_samples + (hp.N_samples + hp.N_importance if hp.N_importance > 0 else 0)
+    samples = (batch * steps + refl) * spr
     flop_sample = 3 * FLOP_FULL + FLOP_GRAD + (3 * FLOP_GRAD if loss_name == "total" else 0)
     achieved = samples * flop_sample / dt / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": 2516.6, "unit": "TFLOP/s", "frac": achieved / 2516.6,
@@ -124,6 +149,7 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
     return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)",
             "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
-            "samples_per_ray": 64 + 128, "steps": steps, "loss": float(loss.item()),
+            "samples_per_ray": spr, "N_samples": hp.N_samples, "N_importance": hp.N_importance, "steps": steps,
+            "loss": float(loss.item()),
             "loss_fn": "losses.TotalLoss (colour, mask, normal, normal_reg; fused HIP kernels; second-order pass on)" if loss_name == "total"
                        else "colour + mirror-mask loss (no normal_* key read: the second-order pass is skipped)"}

@@ -11,6 +11,11 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+try:      # the commit the measured library was built from (__graft_entry__.build writes it; the GPU box has no .git)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mirror_nerf_amd", "BUILD_COMMIT")) as fh:
+        commit = fh.read().strip()
+except OSError:
+    commit = None
 per = defaultdict(lambda: defaultdict(dict))      # kernel -> counter -> dispatch id -> sum
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
@@ -25,7 +30,8 @@ for k, counters in per.items():
     out[k] = {c: v[max(v)] for c, v in counters.items()}
     if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
         hbm = (2 * out[k]["FETCH_SIZE"] + out[k]["WRITE_SIZE"]) * 1024
-        traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": out[k]["FETCH_SIZE"], "write_kib": out[k]["WRITE_SIZE"]}
+        traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": out[k]["FETCH_SIZE"], "write_kib": out[k]["WRITE_SIZE"],
+                      "commit": commit}
     o = out[k]
     if "SQ_WAVE_CYCLES" in o and "SQ_VALU_MFMA_BUSY_CYCLES" in o:
         o["mfma_busy_frac"] = o["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * o["SQ_WAVE_CYCLES"])

@@ -404,3 +404,67 @@ def test_pipelined_weight_gradient_kernel_matches_autograd():
                         "field_backward_matches_autograd or second_order or train_step_gradients_golden"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def _two_evals(model, x1, x2, d):
+    """Two evaluations of one module in one graph (the primary / reflected pattern of a training step)."""
+    from mirror_nerf_amd.autograd import FieldFn
+    from mirror_nerf_amd.weights import params_of
+    o1 = FieldFn.apply(model, 1, x1, None, None, d[: x1.shape[0]], False, *params_of(model))
+    o2 = FieldFn.apply(model, 1, x2, None, None, d[: x2.shape[0]], False, *params_of(model))
+    return o1, o2
+
+
+def test_folded_gradient_accumulation_with_other_consumers_of_the_parameters():
+    """the evaluations of a module fold their weight gradients into one private set of tensors that is
+    handed to autograd only when complete.  With ANOTHER consumer of the parameters in the graph (a weight regulariser)
+    the sums must equal what autograd's own accumulation gives (fold off); an evaluation whose outputs never reach the
+    loss must not lose gradients (end-of-pass callback); a backward pass that raises must not poison the next one."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import autograd as AG
+    from mirror_nerf_amd.weights import params_of
+    torch.manual_seed(11)
+    model = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True).to(DEV)
+    x1 = (torch.rand(300, 3, device=DEV) * 4 - 2).contiguous()
+    x2 = (torch.rand(200, 3, device=DEV) * 4 - 2).contiguous()
+    d = M.Embedding(4)(torch.nn.functional.normalize(torch.randn(300, 3, device=DEV), dim=1))
+
+    def loss_fn(use_second=True, reg=True):
+        o1, o2 = _two_evals(model, x1, x2, d)
+        loss = o1[0].sum() + (o1[1] ** 2).sum()
+        if use_second:
+            loss = loss + 0.5 * o2[0].sum() + o2[3].sum()
+        if reg:
+            loss = loss + 1e-2 * sum((q ** 2).sum() for q in params_of(model))
+        return loss
+
+    def grads(fold, **kw):
+        old = AG.FOLD_GRADS
+        AG.FOLD_GRADS = fold
+        try:
+            for q in model.parameters():
+                q.grad = None
+            loss_fn(**kw).backward()
+            return [q.grad.clone() for q in params_of(model)]
+        finally:
+            AG.FOLD_GRADS = old
+
+    for kw in (dict(use_second=True, reg=True), dict(use_second=False, reg=True), dict(use_second=True, reg=False)):
+        want, got = grads(False, **kw), grads(True, **kw)
+        for a, b in zip(got, want):
+            assert _rel(a, b) <= 2e-6, kw
+        assert model.__dict__.get("_mnrf_pending") is None and model.__dict__.get("_mnrf_uses", 0) == 0
+
+    # a backward pass that dies between two evaluations leaves state behind; the next forward clears it
+    o1, o2 = _two_evals(model, x1, x2, d)
+    model.__dict__["_mnrf_pending"] = ([torch.zeros_like(q) for q in params_of(model)], [])     # as after an exception
+    want, got = grads(False), grads(True)
+    for a, b in zip(got, want):
+        assert _rel(a, b) <= 2e-6
+    # gradient accumulation over two backward passes without zero_grad (p.grad += ...)
+    for q in model.parameters():
+        q.grad = None
+    loss_fn().backward()
+    loss_fn().backward()
+    for q, b in zip(params_of(model), want):
+        assert _rel(q.grad, 2 * b) <= 2e-6

@@ -200,6 +200,20 @@ def test_frame_driver_and_training_step_fall_back():
         assert (p.grad is None) == (q.grad is None)
         if p.grad is not None:
             assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
+    # MNRF_GUARD_SYNC=1: the tripping step ITSELF is recomputed on the exact kernels before the optimizer sees it
+    s4 = system()
+    for k, v in hp.items():
+        setattr(s4.hparams, k, v)
+    old_sync, training.GUARD_SYNC = training.GUARD_SYNC, True
+    try:
+        with pytest.warns(RuntimeWarning, match="affected work is repeated"):
+            l4 = training.train_step(s4, NoStep(s4.parameters()), *batch)
+    finally:
+        training.GUARD_SYNC = old_sync
+    assert float(l4) == float(l2) and MN.precision_of(s4.nerf_fine) == "fp32"
+    for (n, p), q in zip(s4.named_parameters(), s2.parameters()):
+        if p.grad is not None:
+            assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
     # NeRFSystem.forward on its own (validation, custom loops) checks synchronously and repeats the forward
     s3 = system()
     for k, v in hp.items():
