@@ -193,7 +193,7 @@ int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, i
                              const float* rays, const float* z_vals, int spr, const float* dir_emb,
                              int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                              float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                             float* save_inv, float* save_invj, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
+                             float* save_inv, float* save_invj, unsigned flags /* 0 or MNRF_SPLIT_F16 [| MNRF_TRAIN_PLANES] */, void* stream);
 
 /* Backward of the field MLP: given dL/d{sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B)},
  * writes the gradient of every parameter (d_params: HOST array of MNRF_N_PARAMS device pointers,
@@ -225,6 +225,35 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* rays, const float* z_vals, int spr, const float* g_normal,
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
+
+/* ---- training, round 3: operand planes (split arithmetic only) --------------------------------------------------------
+ * The weight gradients dW = dY^T X contract over samples.  With MNRF_TRAIN_PLANES the training forward keeps the inputs X
+ * of every Linear -- and mnrf_field_backward_planes the pre-activation gradients dY -- not as fp32 rows but as the hi/lo
+ * f16 operand tiles the GEMM consumes directly (layout: mirror_nerf_amd/csrc/mnrf_dwp.h), and ONE call of mnrf_dw_planes
+ * computes the gradients of all 32 parameters over ALL evaluations of a module in a backward pass (primary rays, reflected
+ * rays ...: train.py:253-259 evaluates the same models at every recursion level).
+ * Autograd equivalent: loss.backward() through models/mirror_nerf.py:101-212, .grad accumulated over the evaluations. */
+#define MNRF_TRAIN_PLANES 256u     /* mnrf_field_forward_train: `save_x` is a planes buffer of mnrf_train_planes_bytes(B) bytes */
+int64_t mnrf_train_planes_bytes(int64_t B);      /* X planes of B samples (bytes) */
+int64_t mnrf_train_dy_planes_bytes(int64_t B);   /* dY planes of B samples (bytes) */
+
+/* Activation gradients only (no weight gradients): mnrf_field_backward's first half on the split arithmetic.  dy_planes
+ * (mnrf_train_dy_planes_bytes(B)) receives dY under one power-of-two scale for the whole call, derived from the largest seed
+ * magnitude, whose float bits are left in *seedmax (a device word, overwritten) for mnrf_dw_planes. */
+int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                               const float* rays, const float* z_vals, int spr,
+                               const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                               const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                               const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
+                               void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir, const float* keep_mirror,
+                               unsigned flags /* MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD */, void* stream);
+
+/* Weight gradients of n_eval (1..8) evaluations of one module: x_planes[e] from mnrf_field_forward_train, dy_planes[e] and
+ * seedmax[e] from mnrf_field_backward_planes, B[e] their sample counts (HOST arrays).  d_params: HOST array of MNRF_N_PARAMS
+ * device pointers, overwritten (accumulate = 0) or added to.  workspace: mnrf_dw_planes_workspace_floats(n_eval, B) floats. */
+int64_t mnrf_dw_planes_workspace_floats(int n_eval, const int64_t* B);
+int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                   const uint32_t* const* seedmax, float* workspace, float* const* d_params, int accumulate, void* stream);
 
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);

@@ -30,6 +30,7 @@ MNRF_TCNN_VALU = 8
 MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128
+MNRF_TRAIN_PLANES = 256
 MNRF_DETACH_W_MASK = 1
 MNRF_DETACH_W_NORMAL = 2
 N_PARAMS = 32
@@ -59,6 +60,13 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_void_p), _c_f, _u32, _str]),
     "mnrf_field_backward": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 11 +
                             [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f, _u32, _str]),
+    "mnrf_train_planes_bytes": (_i64, [_i64]),
+    "mnrf_train_dy_planes_bytes": (_i64, [_i64]),
+    "mnrf_field_backward_planes": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 9 +
+                                   [ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, _c_f, _u32, _str]),
+    "mnrf_dw_planes_workspace_floats": (_i64, [_int, ctypes.POINTER(ctypes.c_int64)]),
+    "mnrf_dw_planes": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                              ctypes.POINTER(ctypes.c_void_p), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),

@@ -9,6 +9,9 @@ import os
 
 # MNRF_FOLD_GRADS=0: leave the accumulation of a module's parameter gradients over its evaluations to autograd
 FOLD_GRADS = os.environ.get("MNRF_FOLD_GRADS", "1") != "0"
+# MNRF_DW_PLANES=0: the round-1/2 weight-gradient route of the split arithmetic (fp32 rows of saved activations and of dY, one
+# set of bf16 x 6 GEMM launches per evaluation) instead of operand planes + ONE GEMM launch per module and pass (mnrf_dwp.h)
+DW_PLANES = os.environ.get("MNRF_DW_PLANES", "1") != "0"
 
 
 def _c(t):
@@ -116,7 +119,12 @@ class FieldFn(torch.autograd.Function):
         xyz, rays, z_vals, dir_emb = _c(xyz), _c(rays), _c(z_vals), _c(dir_emb)
         sigma, rgb, pn, mir = f(B), f(B, 3), f(B, 3), f(B)
         normal = f(B, 3) if want_normal else None
-        save_x = f(max(1, L.mnrf_train_save_floats(B)))
+        split = _mn.precision_of(module).startswith("split")
+        planes = split and DW_PLANES
+        if planes:     # the inputs of every Linear as hi/lo f16 operand tiles of the weight-gradient GEMM (mnrf_dwp.h)
+            save_x = torch.empty(max(16, L.mnrf_train_planes_bytes(B)), dtype=torch.uint8, device=dev)
+        else:
+            save_x = f(max(1, L.mnrf_train_save_floats(B)))
         save_mask = torch.empty(max(1, L.mnrf_train_mask_words(B)), dtype=torch.int64, device=dev)
         save_inv = f(max(1, B))
         save_invj = f(max(1, B)) if want_normal else None
@@ -126,8 +134,9 @@ class FieldFn(torch.autograd.Function):
             _lib.check(L.mnrf_field_forward_train(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
                 p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj),
-                _lib.MNRF_SPLIT_F16 if _mn.precision_of(module).startswith("split") else 0, _lib.stream()), "mnrf_field_forward_train")
-        ctx.split = _mn.precision_of(module).startswith("split")    # the backward follows the arithmetic of ITS forward
+                (_lib.MNRF_SPLIT_F16 if split else 0) | (_lib.MNRF_TRAIN_PLANES if planes else 0), _lib.stream()),
+                "mnrf_field_forward_train")
+        ctx.split, ctx.planes = split, planes    # the backward follows the arithmetic (and the save format) of ITS forward
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.set_materialize_grads(False)   # an unused `normal` must arrive as None, not as zeros: it gates the second-order pass
         ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj)
@@ -149,7 +158,6 @@ class FieldFn(torch.autograd.Function):
     def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal):
         import ctypes
         from .weights import packed_of
-        from . import mirror_nerf as _mn
         L = _lib.lib()
         xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj = ctx.saved_tensors
         B, spr = ctx.B, ctx.spr
@@ -160,68 +168,82 @@ class FieldFn(torch.autograd.Function):
         g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
         # A module evaluated several times in one step (primary rays, then reflected rays: train.py:253-259) gets one
         # gradient per evaluation and autograd would add them with one kernel per parameter (64 launches per step).
-        # Instead the evaluations of a pass add into ONE private set of tensors in the finish kernel (MNRF_DW_ACCUMULATE)
-        # and return None; the LAST pending evaluation (count from the forwards) hands the complete tensors to autograd,
-        # which sums them with whatever other consumers of the parameters contribute (a weight regulariser ...).  Nothing
-        # is handed over before it is complete, so autograd never holds a tensor that is still being added into.  An
+        # Instead the evaluations of a pass work on ONE private set of gradient tensors (views of one flat buffer) and
+        # return None; the LAST pending evaluation (count from the forwards) hands the complete tensors to autograd, which
+        # sums them with whatever other consumers of the parameters contribute (a weight regulariser ...).  Nothing is
+        # handed over before it is complete, so autograd never holds a tensor that is still being added into.  An
         # end-of-pass callback, registered by the first evaluation of every pass, covers a mis-count (an evaluation whose
         # outputs never reached the loss): gradients still pending then are added to `.grad` directly.
+        #   planes route (split arithmetic, default): an evaluation only runs its activation-gradient kernel and leaves
+        #   its operand planes on the module's TAPE; the last one launches the weight-gradient GEMM once over the whole tape;
+        #   rows route (fp32 arithmetic, MNRF_DW_PLANES=0): every evaluation runs its own GEMMs, adding into the tensors.
         mod = ctx.module
         uses = max(0, mod.__dict__.get("_mnrf_uses", 1) - 1)
         mod.__dict__["_mnrf_uses"] = uses
-        pending = mod.__dict__.get("_mnrf_pending") if FOLD_GRADS else None
-        accumulate = pending is not None and [tuple(t.shape) for t in pending[0]] == ctx.param_shapes
-        d_params = pending[0] if accumulate else [f(*s) for s in ctx.param_shapes]
-        from .weights import PARAM_NAMES, PARAM_SHAPES
-        by_name = dict(zip(ctx.param_names, d_params))
-        # the kernels write all 32 gradients in state_dict order; an absent optional head gets scratch buffers
-        all32 = [by_name[n] if n in by_name else f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+        fold = FOLD_GRADS or ctx.planes
+        st = mod.__dict__.get("_mnrf_pending") if fold else None
+        if st is not None and st.shapes != ctx.param_shapes:
+            st = None                        # (tensors of another parameter set pending: this evaluation stands alone)
+            fold = False
+        first = st is None
+        if first:
+            st = _Pending(ctx.param_names, ctx.param_shapes, dev)
+        all32 = st.all32()
         arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in all32])
         need = ctx.needs_input_grad
         want_xyz = (xyz is not None and need[2]) or (rays is not None and need[3])
         d_xyz = f(B, 3) if want_xyz else None
         d_dir = f(B, 32) if need[5] else None
-        ws = f(max(1, L.mnrf_train_workspace_floats(B)))
         p = _lib.ptr
         xs = xyz.shape[1] if xyz is not None else 3
-        if B:
+        if B and ctx.planes:
+            dy = torch.empty(max(16, L.mnrf_train_dy_planes_bytes(B)), dtype=torch.uint8, device=dev)
+            seed = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.check(L.mnrf_field_backward_planes(
+                p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
+                p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut,
+                _lib.stream()), "mnrf_field_backward_planes")
+            st.tape.append((save_x, dy, B, seed))
+        elif B:
+            ws = f(max(1, L.mnrf_train_workspace_floats(B)))
             _lib.check(L.mnrf_field_backward(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_x), p(save_mask), p(save_inv), p(ws), arr, p(d_xyz), p(d_dir), p(ctx.keep_mirror),
-                (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut | (_lib.MNRF_DW_ACCUMULATE if accumulate else 0), _lib.stream()),
+                (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut | (_lib.MNRF_DW_ACCUMULATE if st.dirty else 0), _lib.stream()),
                 "mnrf_field_backward")
-            if g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
-                ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
-                _lib.check(L.mnrf_field_backward2(
-                    p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
-                    p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz),
-                    _lib.MNRF_SPLIT_F16 if ctx.split else 0, _lib.stream()), "mnrf_field_backward2")
-        elif not accumulate:
-            for t in d_params:
-                t.zero_()
+            st.dirty = True
+        if B and g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
+            if not st.dirty:         # it ADDS to the gradients (trunk weights, sigma.weight): they start from zero then
+                st.flat.zero_()
+                st.dirty = True
+            ws2 = f(max(1, L.mnrf_train_workspace2_floats(B)))
+            _lib.check(L.mnrf_field_backward2(
+                p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
+                p(save_invj), p(save_mask), p(ws2), arr, p(d_xyz),
+                _lib.MNRF_SPLIT_F16 if ctx.split else 0, _lib.stream()), "mnrf_field_backward2")
         hand_over = True
-        if FOLD_GRADS:
-            if accumulate:
-                hand_over = uses == 0         # the last pending evaluation: the private tensors are complete
-                if hand_over:
-                    mod.__dict__.pop("_mnrf_pending", None)
-            elif pending is None and uses > 0:
-                # first evaluation of the pass with more to come: keep the tensors private
-                mod.__dict__["_mnrf_pending"] = (d_params, ctx.param_names)
+        if fold and uses > 0:
+            hand_over = False                 # more evaluations of this module to come in this pass
+            if first:
+                mod.__dict__["_mnrf_pending"] = st
 
                 def _end_of_pass(m=mod):
                     left = m.__dict__.pop("_mnrf_pending", None)
                     m.__dict__["_mnrf_uses"] = 0
                     if left is not None:      # never handed over (mis-count): deliver the sum ourselves
-                        by = dict(zip(left[1], left[0]))
+                        by = dict(zip(left.names, left.finish()))
                         from .weights import param_refs
                         for sub, pname, full in param_refs(m):
                             q, gq = sub._parameters[pname], by.get(full)
                             if gq is not None and q is not None and q.requires_grad:
                                 q.grad = gq if q.grad is None else q.grad.add_(gq)
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
-                hand_over = False
-            # else: a single evaluation (or tensors of another shape pending): the fresh tensors go to autograd
+        d_params = None
+        if hand_over:
+            mod.__dict__.pop("_mnrf_pending", None)
+            d_params = st.finish()            # the weight-gradient GEMM over the tape (planes route); complete now
+            mod.__dict__["_mnrf_flat_grad"] = st.flat     # dist.allreduce_gradients reduces this buffer in place when .grad aliases it
+            st = None
         g_xyz = g_rays = g_de = None
         if d_xyz is not None:
             if xyz is not None:
@@ -235,7 +257,51 @@ class FieldFn(torch.autograd.Function):
                 g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
         if d_dir is not None:
             g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
-        return (None, None, g_xyz, g_rays, None, g_de, None, *(d_params if hand_over else [None] * len(d_params)))
+        n_par = len(ctx.param_shapes)
+        return (None, None, g_xyz, g_rays, None, g_de, None, *(d_params if hand_over else [None] * n_par))
+
+
+class _Pending:
+    """Gradient tensors of one module for one backward pass: views of ONE flat buffer in state_dict order of the 32 field
+    parameters (an absent optional head keeps its slots as scratch), plus the tape of the planes route."""
+
+    def __init__(self, names, shapes, dev):
+        from .weights import PARAM_NAMES, PARAM_SHAPES
+        self.names, self.shapes = list(names), list(shapes)
+        sizes = [int(torch.Size(PARAM_SHAPES[n]).numel()) for n in PARAM_NAMES]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self._views, off = {}, 0
+        for n, k in zip(PARAM_NAMES, sizes):
+            self._views[n] = self.flat[off:off + k].view(PARAM_SHAPES[n])
+            off += k
+        self.tape = []          # (x_planes, dy_planes, B, seedmax) per evaluation
+        self.dirty = False      # the tensors hold a partial sum already (rows route, second-order pass)
+
+    def all32(self):
+        from .weights import PARAM_NAMES
+        return [self._views[n] for n in PARAM_NAMES]
+
+    def finish(self):
+        """Complete the gradients (launch the weight-gradient GEMM over the tape) and return them in the module's order."""
+        import ctypes
+        L = _lib.lib()
+        p = _lib.ptr
+        tape, self.tape = self.tape, []
+        if tape:
+            arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in self.all32()])
+            for g0 in range(0, len(tape), 8):          # mnrf_dw_planes takes up to 8 evaluations per call
+                grp = tape[g0:g0 + 8]
+                n = len(grp)
+                xs = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in grp])
+                ys = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in grp])
+                bs = (ctypes.c_int64 * n)(*[t[2] for t in grp])
+                sm = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in grp])
+                ws = torch.empty(max(1, L.mnrf_dw_planes_workspace_floats(n, bs)), dtype=torch.float32, device=self.flat.device)
+                _lib.check(L.mnrf_dw_planes(n, xs, ys, bs, sm, p(ws), arr, 1 if self.dirty else 0, _lib.stream()), "mnrf_dw_planes")
+                self.dirty = True
+        elif not self.dirty:
+            self.flat.zero_()      # no samples at all in this pass
+        return [self._views[n] if n in self._views else torch.zeros(s, device=self.flat.device) for n, s in zip(self.names, self.shapes)]
 
 
 class EmbedFn(torch.autograd.Function):

@@ -1,0 +1,407 @@
+// mnrf_dwp.hip -- weight gradients of the field MLP from operand planes (see mnrf_dwp.h for the layout and the reasons).
+//
+//   dwp_gemm_kernel    persistent workgroups (one per CU, 8 waves): each owns a contiguous span of the cost line of
+//                      mnrf_dwp.h, i.e. consecutive 32-sample stages of one or a few (job, evaluation) pairs; per stage the
+//                      operand tiles of the job (up to 32 KiB of dY + 32 KiB of X, hi and lo planes) travel HBM -> LDS by
+//                      LDS-DMA into a double buffer, MFMA operands come out of LDS through ds_read_b64_tr_b16, three
+//                      v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block (hi.hi + hi.lo + lo.hi) into a 256 x 256 fp32 tile
+//                      held in registers (wave (wn, wk): rows 64 wn .., columns 128 wk ..); one partial tile per span piece.
+//   dwp_finish_kernel  sums the partial tiles of every Linear over workgroups and evaluations (each evaluation with its own
+//                      power-of-two scale) in a fixed order and writes -- or adds to -- the gradients in nn.Linear layout.
+// All GEMMs of all evaluations of a module in a backward pass are ONE launch (rounds 1-2: 5 launches per evaluation).
+// Autograd equivalent: the .grad accumulation of loss.backward() for models/mirror_nerf.py:59-99.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/mnrf.h"
+#include "mnrf_error.h"
+#include "mnrf_layout.h"
+#include "mnrf_dwp.h"
+#include "mnrf_dw.h"
+
+namespace mnrf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+extern __shared__ __attribute__((aligned(16))) char dwp_smem[];
+
+constexpr int DWP_BUF = 64 * 1024;         // one stage: [A tiles: 32 KiB][X tiles: 32 KiB]
+constexpr int DWP_XOFF = 32 * 1024;
+constexpr int DWP_LDS = 2 * DWP_BUF;
+
+struct DwpEval {
+    const char* X;            // X planes of the evaluation  [n_sb][PLX_FB][2][1 KiB]
+    const char* Y;            // dY planes                   [n_sb][PLY_FB][2][1 KiB]
+    const unsigned* seedmax;  // bits of the largest |seed| of the evaluation (float), see mnrf_dwp.h "scale"
+};
+struct DwpArgs {
+    DwpEval ev[DWP_MAX_EVAL];
+    DwpPlan plan;
+    float* part;              // [G + DWP_JOBS * n_eval slots][DWP_SLOT_FLOATS]
+};
+
+__device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// one MFMA operand = feature (lane & 15) of a tile, k slots 8 gg .. 8 gg + 7 = rows {4 gg .. 4 gg + 3} and {16 + 4 gg ..}:
+// two transposing reads with lane-linear addresses (tile + 8 lane, tile + 512 + 8 lane)
+__device__ __forceinline__ u32x4 read_operand(const char* tile, int lane8) {
+    typedef __attribute__((address_space(3))) h4 lds_h4;
+    const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(tile + lane8));
+    const h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(tile + 512 + lane8));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l.x, l.y, h.x, h.y};
+}
+
+// tile t (1 KiB, lane-linear) of a contiguous run of tiles: global -> LDS by LDS-DMA
+__device__ __forceinline__ void dma_tile(const char* src, char* dst, int lane16) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane16),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// MB: dY blocks per wave row (wn), KB: X blocks per wave column (wk); NA / NX: blocks of the job's operands
+template <int MB, int KB, int NA, int NX>
+__device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, const char* __restrict__ Xb, int s_lo, int s_hi,
+                                                bool bias, float* __restrict__ slot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wk = wave >> 2;
+    const int lane8 = lane * 8, lane16 = lane * 16;
+    const bool has_a = wn * MB < NA;         // NA = 1: only wn = 0 owns a row block
+    constexpr int NT = 2 * NA + 2 * NX;      // 1-KiB tiles per stage
+    char* const lds = dwp_smem;
+
+    f32x4 acc[MB][KB], bacc[MB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+        bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const u32x4 ones = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};      // f16 1.0 in every k slot
+
+    // the wave's share of a stage's tiles: t = wave, wave + 8, ...  (A tiles first, then X tiles at DWP_XOFF)
+    auto issue = [&](int s, int buf) {
+        const char* ya = Yb + (long long)s * PLY_SB_BYTES;
+        const char* xa = Xb + (long long)s * PLX_SB_BYTES;
+        char* base = lds + buf * DWP_BUF;
+#pragma unroll
+        for (int q = 0; q < (NT + 7) / 8; ++q) {
+            const int t = wave + 8 * q;
+            if (t < 2 * NA) dma_tile(ya + t * PL_TILE_BYTES, base + t * PL_TILE_BYTES, lane16);
+            else if (t < NT) dma_tile(xa + (t - 2 * NA) * PL_TILE_BYTES, base + DWP_XOFF + (t - 2 * NA) * PL_TILE_BYTES, lane16);
+        }
+    };
+
+    __syncthreads();                 // the previous segment's last stage has been read by every wave
+    issue(s_lo, 0);
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int buf = (s - s_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's tiles of stage s have landed ...
+        __syncthreads();                                      // ... and everybody's; buffer buf ^ 1 is free (stage s - 1 consumed)
+        if (s + 1 < s_hi) issue(s + 1, buf ^ 1);
+        const char* A = lds + buf * DWP_BUF;
+        const char* X = A + DWP_XOFF;
+        if (has_a) {
+            u32x4 ah[MB], al[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah[mb] = read_operand(A + (wn * MB + mb) * PL_FB_BYTES, lane8);
+                al[mb] = read_operand(A + (wn * MB + mb) * PL_FB_BYTES + PL_TILE_BYTES, lane8);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const u32x4 bh = read_operand(X + (wk * KB + kb) * PL_FB_BYTES, lane8);
+                const u32x4 bl = read_operand(X + (wk * KB + kb) * PL_FB_BYTES + PL_TILE_BYTES, lane8);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    f32x4 c = acc[mb][kb];
+                    c = mfma_h(al[mb], bh, c);      // lo . hi
+                    c = mfma_h(ah[mb], bl, c);      // hi . lo
+                    c = mfma_h(ah[mb], bh, c);      // hi . hi
+                    acc[mb][kb] = c;
+                }
+            }
+            if (bias && wk == 0) {                  // column sums of dY: the same operands against a row of ones
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    bacc[mb] = mfma_h(al[mb], ones, bacc[mb]);
+                    bacc[mb] = mfma_h(ah[mb], ones, bacc[mb]);
+                }
+            }
+        }
+    }
+    // partial tile, fragment order: block (nb, kb) = 1 KiB, lane-linear float4 (row 4 g + r, column lane & 15 of the block)
+    if (has_a) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                ((f32x4*)slot)[((wn * MB + mb) * NX + (wk * KB + kb)) * 64 + lane] = acc[mb][kb];
+        if (bias && wk == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) ((f32x4*)(slot + 256 * 256))[(wn * MB + mb) * 4 + (lane >> 4)] = bacc[mb];
+        }
+    }
+}
+
+__global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) {
+    const int g = blockIdx.x;
+    const DwpPlan& p = A.plan;
+    long long P = 0, c0, c1;
+    dwp_interval(p, g, c0, c1);
+    for (int j = 0; j < DWP_JOBS; ++j) {
+        const DwpJob jb = dwp_job(j);
+        const int w = dwp_weight(j);
+        for (int e = 0; e < p.n_eval; ++e) {
+            const int n = p.n_sb[e];
+            int s_lo, s_hi;
+            dwp_segment(c0, c1, P, w, n, s_lo, s_hi);
+            P += (long long)n * w;
+            if (s_hi <= s_lo) continue;
+            const char* Yb = A.ev[e].Y + (long long)jb.ya * PL_FB_BYTES;
+            const char* Xb = A.ev[e].X + (long long)jb.xa * PL_FB_BYTES;
+            float* slot = A.part + (long long)(g + j * p.n_eval + e) * DWP_SLOT_FLOATS;
+            switch (jb.shape) {
+            case 0: dwp_segment_run<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            case 1: dwp_segment_run<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            case 2: dwp_segment_run<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            case 3: dwp_segment_run<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            case 4: dwp_segment_run<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            default: dwp_segment_run<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA of this workgroup is still on its way
+}
+
+// ---------------------------------------------------------------------------------------------------------- finish
+// A parameter is assembled from up to two column ranges, each a window of one job's tile.
+struct DwpSource {
+    short job;       // -1: none
+    short row0;      // first row of the job's tile that belongs to this Linear
+    short col0;      // first column of the job's tile
+    short kind;      // 0: column c of the Linear = tile column col0 + c;  1: xyz-encoding pair order (encpos)
+};
+struct DwpLayer {
+    DwpSource src[2];    // columns [0, split_col) from src[0], the rest from src[1]
+    short split_col;
+    short out_f, in_f;
+    short bias_job, bias_row0;
+    float* d_w;
+    float* d_b;
+};
+struct DwpFinishArgs {
+    DwpLayer layer[16];
+    const float* part;
+    const unsigned* seedmax[DWP_MAX_EVAL];
+    short g_lo[DWP_JOBS * DWP_MAX_EVAL], g_hi[DWP_JOBS * DWP_MAX_EVAL];     // owners of virtual job v (g_lo > g_hi: none)
+    int n_eval;
+    int accumulate;
+    short encpos[64];
+};
+
+// scale exponent of an evaluation's dY planes: K puts the largest seed magnitude into [2^6, 2^7) (the backward kernel uses
+// the same K) plus the boost of mnrf_dwp.h
+__device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax) {
+    const int e = (int)((*seedmax >> 23) & 0xffu);
+    const int K = (e == 0 || e == 255) ? 0 : 6 - (e - 127);
+    return K + PL_BOOST_LOG2;
+}
+
+__global__ void dwp_finish_kernel(DwpFinishArgs F) {
+    const DwpLayer& ly = F.layer[blockIdx.y];
+    const int nw = ly.out_f * ly.in_f;
+    const int el = blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nw + ly.out_f) return;
+    int job, row, col;
+    bool is_bias = el >= nw;
+    if (!is_bias) {
+        const int n = el / ly.in_f, c = el % ly.in_f;
+        const bool first = c < ly.split_col;
+        const DwpSource s = first ? ly.src[0] : ly.src[1];
+        job = s.job;
+        row = s.row0 + n;
+        int cc = first ? c : c - ly.split_col;
+        if (s.kind == 1) cc = F.encpos[cc];
+        col = s.col0 + cc;
+    } else {
+        job = ly.bias_job;
+        row = ly.bias_row0 + (el - nw);
+        col = 0;
+    }
+    if (job < 0) return;
+    const DwpJob jb = dwp_job(job);
+    // position inside a partial slot (fragment order of dwp_segment_run)
+    long long idx;
+    if (!is_bias) idx = ((long long)((row >> 4) * jb.nx + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
+    else idx = 256 * 256 + row;
+    float total = 0.f;
+    for (int e = 0; e < F.n_eval; ++e) {
+        const int v = job * F.n_eval + e;
+        float sum = 0.f;
+        for (int g = F.g_lo[v]; g <= F.g_hi[v]; ++g) sum += F.part[(long long)(g + v) * DWP_SLOT_FLOATS + idx];
+        if (F.g_lo[v] <= F.g_hi[v]) total += ldexpf(sum, -dwp_scale_log2(F.seedmax[e]));      // (ldexp: K can exceed 126)
+    }
+    float* dst = is_bias ? ly.d_b + (el - nw) : ly.d_w + el;
+    *dst = F.accumulate ? *dst + total : total;
+}
+
+// ---------------------------------------------------------------------------------------------------------- seed maximum
+// The seeds (pre-activation gradients of the four output layers) exactly as field_split_bwd_kernel's prologue forms them --
+// same expressions, same order, -ffp-contract=off in both translation units -- reduced to the largest magnitude.
+__global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* __restrict__ g_rgb, const float* __restrict__ g_pn,
+                                const float* __restrict__ g_m, const float* __restrict__ rgb, const float* __restrict__ pn,
+                                const float* __restrict__ is_mirror, const float* __restrict__ save_inv, long long B,
+                                unsigned* __restrict__ out) {
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+        mx = fmaxf(mx, fabsf(g_sigma[i]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float y = rgb[i * 3 + c];
+            mx = fmaxf(mx, fabsf(g_rgb[i * 3 + c] * y * (1.f - y)));
+        }
+        {
+            const float inv = save_inv[i];
+            const float g0 = g_pn[i * 3], g1 = g_pn[i * 3 + 1], g2 = g_pn[i * 3 + 2];
+            float s0, s1, s2;
+            if (inv > 0.f) {
+                const float p0 = pn[i * 3], p1 = pn[i * 3 + 1], p2 = pn[i * 3 + 2];
+                const float dt = p0 * g0 + p1 * g1 + p2 * g2;
+                s0 = (g0 - p0 * dt) * inv; s1 = (g1 - p1 * dt) * inv; s2 = (g2 - p2 * dt) * inv;
+            } else {
+                s0 = -g0 * inv; s1 = -g1 * inv; s2 = -g2 * inv;
+            }
+            mx = fmaxf(mx, fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2))));
+        }
+        {
+            const float y = is_mirror[i];
+            mx = fmaxf(mx, fabsf(g_m[i] * y * (1.f - y)));
+        }
+    }
+    // non-negative floats order like their bit patterns; NaN (fmaxf drops it) never gets here, inf gives exponent 255 -> K = 0
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+}
+
+void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
+                     const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(unsigned), s);
+    long long blocks = (B + 1023) / 1024;       // four samples per thread
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
+                       save_inv, B, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------- driver
+static int dwp_cus() {
+    static const int v = [] {
+        const char* e = getenv("MNRF_DWP_G");
+        if (e && atoi(e) > 0) return atoi(e);
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return v;
+}
+
+static DwpPlan dwp_make_plan(int n_eval, const int64_t* B) {
+    DwpPlan p;
+    p.n_eval = n_eval;
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) p.n_sb[e] = 0;
+    for (int e = 0; e < n_eval; ++e) p.n_sb[e] = (int)(dwp_tiles128(B[e]) * 4);
+    p.T = dwp_total(p);
+    p.G = dwp_pick_G(p.T, dwp_cus());
+    return p;
+}
+
+long long dwp_workspace_floats(int n_eval, const int64_t* B) {
+    const DwpPlan p = dwp_make_plan(n_eval, B);
+    return (long long)(p.G + DWP_JOBS * n_eval) * DWP_SLOT_FLOATS;
+}
+
+int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+               const unsigned* const* seedmax, float* ws, float* const* d_params, int accumulate, hipStream_t s) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return -1;
+    DwpArgs A;
+    A.plan = dwp_make_plan(n_eval, B);
+    if (A.plan.T == 0) return accumulate ? 0 : -2;      // nothing to add; an overwrite of nothing is the caller's business
+    for (int e = 0; e < n_eval; ++e) A.ev[e] = DwpEval{(const char*)x_planes[e], (const char*)dy_planes[e], seedmax[e]};
+    for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr};
+    A.part = ws;
+    static const bool once = [] {
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(dwp_gemm_kernel, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+
+    DwpFinishArgs F;
+    F.part = ws;
+    F.n_eval = n_eval;
+    F.accumulate = accumulate;
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr;
+    // owners of every virtual job, from the same arithmetic the kernel uses
+    {
+        long long P = 0;
+        for (int j = 0; j < DWP_JOBS; ++j) {
+            const int w = dwp_weight(j);
+            for (int e = 0; e < n_eval; ++e) {
+                const int v = j * n_eval + e, n = A.plan.n_sb[e];
+                int lo = 1, hi = 0;
+                bool any = false;
+                for (int g = 0; g < A.plan.G; ++g) {
+                    int s_lo, s_hi;
+                    long long c0, c1;
+                    dwp_interval(A.plan, g, c0, c1);
+                    dwp_segment(c0, c1, P, w, n, s_lo, s_hi);
+                    if (s_hi > s_lo) {
+                        if (!any) lo = g;
+                        hi = g;
+                        any = true;
+                    }
+                }
+                F.g_lo[v] = (short)lo;
+                F.g_hi[v] = (short)hi;
+                P += (long long)n * w;
+            }
+        }
+    }
+    for (int e = 0; e < 64; ++e) F.encpos[e] = 0;
+    for (int gq = 0; gq < 4; ++gq)
+        for (int t = 0; t < 16; ++t) {
+            const int c = enc_col(t, gq);
+            if (c >= 0) F.encpos[c] = (short)(16 * (t >> 2) + 4 * gq + (t & 3));
+        }
+    auto layer = [&](int L, int out_f, int in_f, DwpSource s0, DwpSource s1, int split_col, int bias_job, int bias_row0) {
+        DwpLayer& ly = F.layer[L];
+        ly.src[0] = s0; ly.src[1] = s1; ly.split_col = (short)split_col;
+        ly.out_f = (short)out_f; ly.in_f = (short)in_f; ly.bias_job = (short)bias_job; ly.bias_row0 = (short)bias_row0;
+        ly.d_w = d_params[2 * L]; ly.d_b = d_params[2 * L + 1];
+    };
+    const DwpSource none{-1, 0, 0, 0};
+    layer(0, 256, 63, DwpSource{0, 0, 0, 1}, none, 63, 0, 0);                                  // xyz_encoding_1
+    for (int i = 1; i < 4; ++i) layer(i, 256, 256, DwpSource{(short)i, 0, 0, 0}, none, 256, i, 0);     // 2..4
+    layer(4, 256, 319, DwpSource{5, 0, 0, 1}, DwpSource{4, 0, 0, 0}, 63, 4, 0);                // xyz_encoding_5: encoding columns first
+    for (int i = 5; i < 8; ++i) layer(i, 256, 256, DwpSource{(short)(i + 1), 0, 0, 0}, none, 256, i + 1, 0);   // 6..8
+    layer(8, 256, 256, DwpSource{9, 0, 0, 0}, none, 256, 9, 0);                                // xyz_encoding_final
+    layer(9, 128, 283, DwpSource{11, 0, 0, 0}, DwpSource{12, 0, 0, 0}, 256, 11, 0);            // dir_encoding.0: final | view columns
+    layer(10, 1, 256, DwpSource{13, 0, 0, 0}, none, 256, 13, 0);                               // sigma
+    layer(11, 3, 128, DwpSource{14, 0, 0, 0}, none, 128, 14, 0);                               // rgb.0
+    layer(12, 128, 256, DwpSource{10, 0, 0, 0}, none, 256, 10, 0);                             // normal_net.0
+    layer(13, 3, 128, DwpSource{15, 0, 0, 0}, none, 128, 15, 0);                               // normal_net.1
+    layer(14, 128, 256, DwpSource{10, 128, 0, 0}, none, 256, 10, 128);                         // is_mirror_net.0
+    layer(15, 1, 128, DwpSource{16, 0, 0, 0}, none, 128, 16, 0);                               // is_mirror_net.2
+    hipLaunchKernelGGL(dwp_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
+    return 0;
+}
+
+}  // namespace mnrf

@@ -196,6 +196,9 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
                                         float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
                                         float* save_inv, float* save_invj, unsigned flags, void* stream) {
     if (!packed || !save_x || !save_mask || !save_inv) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: null pointer");
+    const bool planes = flags & MNRF_TRAIN_PLANES;
+    if (planes && !(flags & MNRF_SPLIT_F16))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: MNRF_TRAIN_PLANES needs MNRF_SPLIT_F16 (the planes are the split kernel's operands)");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: negative sample count");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: need xyz or rays+z_vals");
     if (spr < 1 || !dir_emb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: bad spr / dir_emb");
@@ -203,7 +206,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: the four head outputs are required (the backward reads them)");
     FieldArgs A{packed, MNRF_GRAD_NORMAL, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
-                save_x, (unsigned long long*)save_mask, save_inv, save_invj};
+                planes ? nullptr : save_x, (unsigned long long*)save_mask, save_inv, save_invj, planes ? (char*)save_x : nullptr};
     // always a 128-sample tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map.
     // MNRF_SPLIT_F16: the split-f16 tuning (same saved quantities, fp32 activations from its fp32 accumulators)
     const int rc = (flags & MNRF_SPLIT_F16) ? launch_split(A, false, true, 0, (hipStream_t)stream)
@@ -242,6 +245,59 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
     if (launch_dw(save_x, dY, g_sigma, (long long)B, ws, d_params, (flags & MNRF_DW_ACCUMULATE) ? 1 : 0, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: workspace accounting error");
     return mnrf_check_launch("mnrf_field_backward (weight gradients)");
+}
+
+// ---------------------------------------------------------------------- round 3: operand planes
+extern "C" int64_t mnrf_train_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLX_SB_BYTES; }
+extern "C" int64_t mnrf_train_dy_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLY_SB_BYTES; }
+
+extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                          const float* rays, const float* z_vals, int spr,
+                                          const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                          const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                                          const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
+                                          void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir,
+                                          const float* keep_mirror, unsigned flags, void* stream) {
+    if (!packed || !save_mask || !save_inv || !dy_planes || !seedmax)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: negative sample count");
+    if (!g_sigma || !g_rgb || !g_pred_normal || !g_is_mirror)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: all four upstream gradients are required (pass zeros)");
+    if (!rgb || !pred_normal || !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: forward outputs missing");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: need xyz or rays+z_vals");
+    hipStream_t s = (hipStream_t)stream;
+    launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s);
+    FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
+                   g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
+                   flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax};
+    if (launch_split_bwd(A, s) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
+    return mnrf_check_launch("mnrf_field_backward_planes");
+}
+
+extern "C" int64_t mnrf_dw_planes_workspace_floats(int n_eval, const int64_t* B) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL || !B) return 0;
+    return dwp_workspace_floats(n_eval, B);
+}
+
+extern "C" int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                              const uint32_t* const* seedmax, float* workspace, float* const* d_params, int accumulate,
+                              void* stream) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: 1..8 evaluations per call");
+    if (!x_planes || !dy_planes || !B || !seedmax || !workspace || !d_params) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: null pointer");
+    long long total = 0;
+    for (int e = 0; e < n_eval; ++e) {
+        if (B[e] <= 0 || !x_planes[e] || !dy_planes[e] || !seedmax[e])
+            return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: every evaluation needs B > 0 and its three buffers");
+        total += dwp_sample_blocks(B[e]);
+    }
+    if (total * 812 >= (1LL << 31)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: too many samples for one call (split the evaluations)");
+    for (int i = 0; i < MNRF_N_PARAMS; ++i)
+        if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: null gradient pointer");
+    if (launch_dwp(n_eval, x_planes, dy_planes, B, (const unsigned* const*)seedmax, workspace, d_params, accumulate ? 1 : 0,
+                   (hipStream_t)stream) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: bad plan");
+    return mnrf_check_launch("mnrf_dw_planes");
 }
 
 extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_FLOATS * B + dw2_workspace_floats(B); }

@@ -6,6 +6,7 @@
 
 #include "../../include/mnrf.h"
 #include "mnrf_layout.h"
+#include "mnrf_dwp.h"
 
 namespace mnrf {
 
@@ -33,6 +34,9 @@ struct FieldArgs {
     unsigned long long* save_mask; // [tiles][N_MASKS][S][256]
     float* save_inv;               // [B] 1/|v| of normal_net (negative when the eps clamp was active)
     float* save_invj;              // [B] 1/|d sigma/dx| of the density-gradient normal, same convention
+    // split arithmetic, round 3: instead of fp32 rows in save_x the inputs of every Linear are kept as the hi/lo f16 operand
+    // PLANES the weight-gradient GEMM consumes directly (mnrf_dwp.h): [sample blocks][PLX_FB][hi | lo][1 KiB]
+    char* save_planes;
 };
 
 // training backward (activation gradients): mnrf_field_bwd.inc (fp32) and mnrf_field_split_bwd.inc (split-f16)
@@ -43,13 +47,17 @@ struct FieldBwdArgs {
     const float* g_sigma; const float* g_rgb; const float* g_pn; const float* g_m;   // upstream, null = 0
     const float* rgb; const float* pn; const float* is_mirror;                        // forward outputs
     const unsigned long long* save_mask; const float* save_inv;
-    float* dY;
+    float* dY;                  // fp32 rows [DY_* sections][B][width] (null with dY_planes)
     float* d_xyz;
     float* d_dir;
     // gradient steering (models/mirror_nerf.py:154-183): heads that see geo_feat.detach() still get their own weight
     // gradients, but add nothing to dL/dh8
     unsigned cut;               // MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD
     const float* keep_mirror;   // per ray (per sample with xyz) or null: 0 = cut the mirror head for this ray's samples
+    // split arithmetic, round 3: the pre-activation gradients as operand planes (mnrf_dwp.h) under ONE power-of-two scale
+    // per launch, derived from the largest seed magnitude of the evaluation (*seedmax, float bits, filled by seed_max_kernel)
+    char* dY_planes;            // [sample blocks][PLY_FB][hi | lo][1 KiB]
+    const unsigned* seedmax;
 };
 // second-order pass (gradient through the density-gradient normal)
 struct FieldBwd2Args {

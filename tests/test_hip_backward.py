@@ -398,10 +398,25 @@ def test_pipelined_weight_gradient_kernel_matches_autograd():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MNRF_DW_PIPE="1")
+    env = dict(os.environ, MNRF_DW_PIPE="1", MNRF_DW_PLANES="0")      # (the rows route: planes have their own GEMM)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                         "field_backward_matches_autograd or second_order or train_step_gradients_golden"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_rows_route_of_the_weight_gradients_still_works():
+    """MNRF_DW_PLANES=0 (read at import): the round-1/2 route of the split arithmetic -- fp32 rows of saved activations and
+    dY, bf16 x 6 GEMMs per evaluation -- stays selectable; the gradient tests run on it in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MNRF_DW_PLANES="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "field_backward_matches_autograd or cut_heads or accumulates_over_samples or train_step_gradients_golden "
+                        "or folded_gradient"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
