@@ -12,7 +12,7 @@ activation-gradient and second-order kernels of both arithmetics):
   * the hand-placed reads and counted waits are present,
   * no scratch (spill) traffic at all in the forward kernels of the split arithmetic and inside the MFMA range of
     the fp32 forward kernels; the known phase-boundary spills of the gradient kernels are reported, and bounded,
-  * the weight-gradient GEMMs (mnrf_dw.o) do not spill.
+  * the weight-gradient GEMMs (mnrf_dw.o, mnrf_dwp.o) do not spill.
 """
 import os
 import re
@@ -106,6 +106,14 @@ def main():
         if "dw_gemm" in sym:
             print(f"{sym}: {sum('v_mfma' in l for l in body)} MFMA, {s} scratch ops")
             ok &= s == 0
+    # plane-fed weight-gradient GEMM (round 3): transposing LDS reads and LDS-DMA present, nothing spills
+    for sym, body in disassemble(os.path.join(CSRC, "mnrf_dwp.o")).items():
+        if "dwp_gemm" in sym:
+            s = sum("scratch_" in l for l in body)
+            tr = sum("ds_read_b64_tr_b16" in l for l in body)
+            dma = sum("global_load_lds_dwordx4" in l for l in body)
+            print(f"{sym}: {sum('v_mfma' in l for l in body)} MFMA, {tr} ds_read_b64_tr_b16, {dma} LDS-DMA tiles, {s} scratch ops")
+            ok &= s == 0 and tr > 0 and dma > 0
     if not ok:
         print("ISA CHECK FAILED")
         sys.exit(1)
