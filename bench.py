@@ -220,6 +220,52 @@ def roughness_leg(dev, models, emb):
     return out
 
 
+def clustered_balance(dev, models, rays, rank, world, sync):
+    """Load balance of the ray sharding when mirror pixels CLUSTER: one frame under train semantics
+    (NeRFSystem.forward, train.py:102-348) with a ground-truth mirror mask = the centred rectangle covering 25 % of the
+    pixels and only_trace_rays_in_mirrors -- each rank renders its interleaved 4096-ray tiles plus the reflections of the
+    mirror pixels among them.  Reports every rank's frame time and reflected-ray count, and max / mean of both; next to it
+    the reflected-ray counts a CONTIGUOUS stripe per rank would get (computed, not rendered): the reason for interleaving."""
+    import torch
+    import torch.distributed as dist
+    from mirror_nerf_amd import dist as D
+    from mirror_nerf_amd import training
+    from mirror_nerf_amd.recursion import NeRFSystem
+    hp = training.default_hparams(N_importance=N_IMPORTANCE, perturb=0.0, noise_std=0.0, chunk=CHUNK)
+    system = NeRFSystem(hp).to(dev)
+    system.nerf_coarse.load_state_dict(models["coarse"].state_dict())
+    system.nerf_fine.load_state_dict(models["fine"].state_dict())
+    gt = torch.zeros(H, W, device=dev)
+    gt[H // 4: H - H // 4, W // 4: W - W // 4] = 1.0
+    gt = gt.view(-1)
+    idx = D.shard_indices(rays.shape[0], rank, world, D.TILE, rays.device)
+    r, m = rays[idx].contiguous(), gt[idx].contiguous()
+    extra = {"mirror_mask": m, "is_eval": False, "train_geometry_stage": False}
+    with torch.no_grad():
+        system(r[:CHUNK], {k: (v[:CHUNK] if torch.is_tensor(v) else v) for k, v in extra.items()})      # warm-up
+        sync()
+        t0 = time.perf_counter()
+        system(r, extra)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    mine = torch.tensor([dt, float(m.sum().item()), float(idx.numel())], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    allr = torch.stack(allr).cpu()
+    times, refl = allr[:, 0].tolist(), allr[:, 1].tolist()
+    stripe = rays.shape[0] // world
+    contiguous = [float(gt[k * stripe: (k + 1) * stripe].sum().item()) for k in range(world)]
+
+    def imb(v):
+        mean = sum(v) / len(v)
+        return max(v) / mean if mean > 0 else None
+    return {"frame_s_per_rank": times, "reflected_rays_per_rank": refl, "primary_rays_per_rank": allr[:, 2].tolist(),
+            "time_imbalance_max_over_mean": imb(times), "reflected_imbalance_max_over_mean": imb(refl),
+            "contiguous_stripes_reflected_per_rank": contiguous, "contiguous_stripes_imbalance_max_over_mean": imb(contiguous),
+            "note": "train semantics, GT mirror mask = centred 25 % rectangle, only_trace_rays_in_mirrors; interleaved 4096-ray tiles "
+                    "(rendered) vs contiguous stripes (counted only)"}
+
+
 def _respawn(a):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
@@ -355,6 +401,7 @@ def main():
                   "note": "one 800x800 frame + its reflected rays over all ranks (interleaved 4096-ray tiles, no data-path "
                           "collective); gather = all_gather of rgb/depth/mask maps, outside ms_per_frame"}
         res = frame = None
+        strong["clustered_mask"] = clustered_balance(dev, models, common, rank, world, sync)
 
     # the other arithmetic on ONE whole frame of the same workload, for the record: rays/s and the dominant kernel's rate
     other = "fp32" if a.precision == "split" else "split"

@@ -122,12 +122,108 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
-def allreduce_gradients(params, average=True):
-    """One all-reduce of all gradients as a single flat buffer (direct reduce-scatter+all-gather
-    inside RCCL uses all 7 xGMI links; a 5.3 MB message is latency-, not bandwidth-bound)."""
+def _flat_bucket(module):
+    """The flat gradient buffer of `module` (autograd._Pending: 32 field parameters in state_dict order) IF every parameter's
+    .grad is still the view of it that FieldFn handed to autograd -- then the all-reduce runs on that one tensor in place and
+    nobody copies.  None when autograd had to copy (another consumer of a parameter, retain_graph, ...)."""
+    flat = module.__dict__.get("_mnrf_flat_grad")
+    if flat is None:
+        return None
+    from .weights import PARAM_NAMES, PARAM_SHAPES, param_refs
+    off, offs = 0, {}
+    for n in PARAM_NAMES:
+        offs[n] = off
+        off += int(torch.Size(PARAM_SHAPES[n]).numel())
+    base, item = flat.data_ptr(), flat.element_size()
+    for sub, pname, full in param_refs(module):
+        q = sub._parameters[pname]
+        if q is None or not q.requires_grad:
+            continue
+        g = q.grad
+        if g is None or full not in offs or not g.is_contiguous() or g.data_ptr() != base + offs[full] * item:
+            return None
+    return flat
+
+
+class _Overlap:
+    """All-reduce of a module's bucket issued from INSIDE the backward pass, as soon as the last of its parameters has
+    received its gradient (post-accumulate-grad hooks, what DDP's reducer does, train.py:577-584): the fine model's 2.65 MB
+    travel over xGMI while the coarse model's backward kernels still run."""
+
+    def __init__(self, module, average):
+        from .weights import params_of
+        self.module, self.average = module, average
+        self.params = [q for q in params_of(module) if q.requires_grad]
+        self.left = len(self.params)
+        self.work = None
+        self.handles = [q.register_post_accumulate_grad_hook(self._hook) for q in self.params]
+
+    def _hook(self, _param):
+        self.left -= 1
+        if self.left == 0:
+            self.left = len(self.params)
+            flat = _flat_bucket(self.module)
+            if flat is not None and dist.is_initialized():
+                self.work = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """-> True when this module's gradients have been reduced by the overlapped all-reduce."""
+        w, self.work = self.work, None
+        self.left = len(self.params)
+        if w is None:
+            return False
+        flat, work = w
+        work.wait()
+        if self.average:
+            flat /= dist.get_world_size()
+        return True
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+
+
+def attach_overlap(modules, average=True):
+    """Install the overlapped bucket all-reduce on field modules (MirrorNeRF).  Idempotent; no-op without a process group."""
+    out = []
+    for m in modules:
+        ov = m.__dict__.get("_mnrf_overlap")
+        if ov is None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced()):
+            ov = _Overlap(m, average)
+            m.__dict__["_mnrf_overlap"] = ov
+        if ov is not None:
+            out.append(ov)
+    return out
+
+
+def allreduce_gradients(params, average=True, modules=()):
+    """Sum (average) the gradients over the ranks.  Field modules passed in `modules` are reduced through their flat
+    gradient buffer -- ONE tensor per module whose views are the .grads (autograd._Pending): no torch.cat, no copy back; the
+    all-reduce of a module with attach_overlap() was already issued during the backward pass and is only waited for here.
+    Whatever is left (parameters outside those modules, or a module whose .grads autograd had to copy) goes the generic
+    way: one flat copy, one all-reduce, copied back.  RCCL over xGMI: direct reduce-scatter + all-gather inside RCCL uses
+    all 7 links; a 2.65 MB message is latency-, not bandwidth-bound."""
     rank, ws = world()
-    grads = [p.grad for p in params if p.grad is not None]
-    if (ws == 1 and not forced()) or not grads:
+    if ws == 1 and not forced():
+        return
+    done = set()
+    pending = []
+    for m in modules:
+        ov = m.__dict__.get("_mnrf_overlap")
+        reduced = ov.finish() if ov is not None else False
+        flat = _flat_bucket(m)
+        if flat is None:
+            continue
+        if not reduced:
+            pending.append((flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+        from .weights import params_of
+        done.update(id(q) for q in params_of(m))
+    for flat, work in pending:
+        work.wait()
+        if average:
+            flat /= ws
+    grads = [p.grad for p in params if p.grad is not None and id(p) not in done]
+    if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -84,7 +84,9 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
             loss = fwd_bwd()
     else:
         system.__dict__["_mnrf_guard_token"] = guard_async_begin(system)   # forward + backward flags of THIS step, read at the next
-    D.allreduce_gradients(params_of(system))                  # RCCL over xGMI when world_size > 1
+    # RCCL over xGMI when world_size > 1: per-model flat buckets, the all-reduce of a model issued from inside the backward
+    # pass as soon as its gradients are complete (dist.attach_overlap), only waited for here
+    D.allreduce_gradients(params_of(system), modules=list(system.models.values()))
     optimizer.step()
     return loss
 
@@ -105,6 +107,7 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
     loss_fn = total_loss_fn() if loss_name == "total" else color_mask_loss
+    D.attach_overlap(system.models.values())        # (no-op on one rank)
 
     def one():
         idx = torch.randint(0, all_rays.shape[0], (batch,), device=dev, generator=g)
@@ -146,7 +149,14 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
                 "note": "ALGORITHMIC fp32 FLOPs of forward + density-gradient normal + activation gradients + weight gradients"
                         + (" + second-order pass" if loss_name == "total" else "") + " over the whole step time (host, losses, "
                         "optimizer and all-reduce included); dense f16 MFMA peak"}
-    return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)",
+    models = list(system.models.values())
+    allreduce = None
+    if world > 1 or D.forced():
+        allreduce = {"buckets_in_place": sum(D._flat_bucket(m) is not None for m in models), "models": len(models),
+                     "overlapped_with_backward": sum(m.__dict__.get("_mnrf_overlap") is not None for m in models),
+                     "note": "one flat gradient buffer per model, all-reduced in place (no cat / copy); issued from inside the "
+                             "backward pass when a model's last gradient arrives"}
+    return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)", "allreduce": allreduce,
             "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
             "samples_per_ray": spr, "N_samples": hp.N_samples, "N_importance": hp.N_importance, "steps": steps,

@@ -78,3 +78,88 @@ def test_shard_count_matches_indices():
             for tile in (4096, 1000):
                 for r in range(ws):
                     assert D.shard_count(n, r, ws, tile) == D.shard_indices(n, r, ws, tile).numel(), (n, ws, tile, r)
+
+
+# ---- flat gradient buckets of the field modules (dist._flat_bucket / attach_overlap), world size 2 on gloo
+class _FakeFieldFn(torch.autograd.Function):
+    """Stands for autograd.FieldFn on the CPU: its backward hands autograd VIEWS of one flat buffer (32 parameters in
+    state_dict order) and leaves that buffer on the module, like autograd._Pending.finish does."""
+
+    @staticmethod
+    def forward(ctx, module, fill, *params):
+        ctx.module, ctx.fill, ctx.n = module, fill, len(params)
+        return sum(q.sum() for q in params) * 0.0
+
+    @staticmethod
+    def backward(ctx, g):
+        from mirror_nerf_amd.weights import PARAM_NAMES, PARAM_SHAPES
+        sizes = [int(torch.Size(PARAM_SHAPES[n]).numel()) for n in PARAM_NAMES]
+        flat = torch.full((sum(sizes),), ctx.fill)
+        views, off = [], 0
+        for n, k in zip(PARAM_NAMES, sizes):
+            views.append(flat[off:off + k].view(PARAM_SHAPES[n]))
+            off += k
+        ctx.module.__dict__["_mnrf_flat_grad"] = flat
+        return (None, None, *views)
+
+
+def _bucket_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MNRF_FORCE_COLLECTIVES"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import mirror_nerf_amd as M
+        from mirror_nerf_amd.weights import params_of
+        torch.manual_seed(0)
+        mods = [M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True) for _ in range(2)]
+        extra = torch.nn.Parameter(torch.zeros(3))          # a parameter outside the field modules: generic path
+        ov = D.attach_overlap(mods)
+        assert len(ov) == 2
+        res = []
+        for step in range(2):
+            for m in mods:
+                for p_ in m.parameters():
+                    p_.grad = None
+            extra.grad = None
+            loss = sum(_FakeFieldFn.apply(m, float(10 * i + rank + 1 + step), *params_of(m)) for i, m in enumerate(mods)) \
+                + (extra * float(rank + 1)).sum()
+            loss.backward()
+            started = [o.work is not None for o in ov]      # the hooks issued the all-reduces from inside the backward pass
+            flats = [m.__dict__["_mnrf_flat_grad"] for m in mods]
+            D.allreduce_gradients([q_ for m in mods for q_ in params_of(m)] + [extra], modules=mods)
+            alias = all(D._flat_bucket(m) is f for m, f in zip(mods, flats))
+            vals = [float(m.sigma.weight.grad[0, 0]) for m in mods] + [float(mods[1].xyz_encoding_5[0].weight.grad[3, 7])]
+            res.append((started, alias, vals, extra.grad.tolist()))
+        # a module whose .grads do not alias its flat buffer (autograd copied): generic path, still correct
+        m = mods[0]
+        for p_ in m.parameters():
+            p_.grad = torch.full_like(p_, float(rank))
+        D.allreduce_gradients(params_of(m), modules=[m])
+        res.append(float(m.sigma.bias.grad[0]))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_buckets_and_overlapped_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        res = out[rank]
+        for step in range(2):
+            started, alias, vals, eg = res[step]
+            assert started == [True, True]           # issued during backward (post-accumulate-grad hooks)
+            assert alias                             # reduced in place: every .grad is still a view of the flat buffer
+            # mean over ranks of (10 i + rank + 1 + step)
+            assert vals == [1.5 + step, 11.5 + step, 11.5 + step], vals
+            assert eg == [1.5] * 3
+        assert res[2] == 0.5

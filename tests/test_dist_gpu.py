@@ -52,6 +52,8 @@ WORKER = textwrap.dedent('''
     # the training step with the flat all-reduce: every rank ends with identical parameters
     r = training.synthetic_train_bench(dev, SY.device_rays(64, 64, dev), steps=2, warmup=1, batch=256)
     assert r["ms_per_step"] > 0
+    # both models reduced through their flat gradient buffer in place, the all-reduce issued from inside the backward pass
+    assert r["allreduce"] == dict(r["allreduce"], buckets_in_place=2, models=2, overlapped_with_backward=2), r["allreduce"]
     dist.barrier()
     dist.destroy_process_group()
     print("RANK_OK", rank)
@@ -106,3 +108,7 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["rccl_world_size"] == 1 and line["config"]["collective_backend"].startswith("nccl")
     assert line["strong_scaling"]["rays_per_s"] > 0 and line["train_step"]["ms_per_step"] > 0
+    cm = line["strong_scaling"]["clustered_mask"]          # load balance with a clustered (25 % rectangle) mirror mask
+    assert cm["reflected_rays_per_rank"] == [160000.0] and cm["primary_rays_per_rank"] == [640000.0]
+    assert cm["time_imbalance_max_over_mean"] == 1.0 and cm["frame_s_per_rank"][0] > 0
+    assert line["train_step"]["allreduce_bytes_per_step"] > 0 and line["train_step"]["allreduce"]["buckets_in_place"] == 2
