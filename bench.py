@@ -436,6 +436,33 @@ def main():
                              "memory chunk by chunk; the reference copies every dict entry incl. per-sample tensors (eval.py:735-736)"}
         hm = None
 
+    # the same frame with per-ray maps only, results left on the device: the final pass ray-fused (field evaluation +
+    # compositing in one kernel, head outputs in LDS, no per-sample tensor in HBM: SURVEY 3 "result-dict contract")
+    fused = None
+    if world == 1:
+        render_maps = lambda r: M.batched_inference(models, emb, r, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,  # noqa: E731
+                                                    trace_secondary_rays=True, to_cpu=False, maps_only=True)
+        render_maps(rays)
+        torch.cuda.synchronize()
+        MN.LAUNCH_LOG = []
+        t1 = time.perf_counter()
+        for _ in range(2):
+            render_maps(rays)
+        torch.cuda.synchronize()
+        dt_f = (time.perf_counter() - t1) / 2
+        t_f = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in MN.LAUNCH_LOG if flags & 0x2000]
+        MN.LAUNCH_LOG = None
+        fk = "mnrf::h3::field_split_kernel<false,false,false,true>"
+        ftr, fsrc, fcommit = _traffic(fk)
+        fused = {"rays_per_s": rays_per_frame / dt_f, "ms_per_frame": dt_f * 1e3,
+                 "kernel": fk + " (full evaluation + compositing of one 192-sample ray per workgroup)",
+                 "avg_launch_ms": sum(t for _, t in t_f) / max(1, len(t_f)), "launches": len(t_f),
+                 "achieved_tflops": sum(B for B, _ in t_f) * MN.FLOP_FULL / (sum(t for _, t in t_f) * 1e-3) / 1e12 if t_f else None,
+                 "traffic": ftr, "traffic_source": (f"static profile: profiles/traffic.json, commit {fcommit or 'unrecorded'}, {fsrc}") if ftr else None,
+                 "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * 4 + CHUNK * (32 + 48),
+                 "note": "batched_inference(..., to_cpu=False, maps_only=True): identical maps bit for bit (tests), the per-sample keys "
+                         "of the final pass are not produced; to_cpu=\"maps\" (with_host_maps) takes the same kernels"}
+
     train = None
     if not a.no_train:
         from mirror_nerf_amd import training
@@ -514,6 +541,8 @@ def main():
             res["strong_scaling"] = strong
         if host_maps is not None:
             res["with_host_maps"] = host_maps
+        if fused is not None:
+            res["maps_only_fused"] = fused
         if train is not None:
             res["train_step"] = train
         if hash_grid is not None:

@@ -226,6 +226,20 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
 
+/* ---- ray-fused fine pass (eval, per-ray maps only; round 3) ------------------------------------------------------------
+ * mnrf_field_forward (all four heads, split arithmetic) + mnrf_composite in ONE launch for rays of exactly
+ * mnrf_fused_samples_per_ray() (= 192 = 64 coarse + 128 importance) samples: a workgroup evaluates one ray, keeps the head
+ * outputs in LDS and composites them with the very body of mnrf_composite's kernel -- the maps are identical bit for bit, and
+ * no per-sample tensor (36 B per sample written and read back otherwise) touches HBM.  What the reference's eval caller
+ * copies to the CPU and nobody reads (eval.py:735-736, SURVEY 3 "result-dict contract") is simply never produced.
+ * noise_std = 0 (test_time), no density-gradient normal.  Null map pointers are skipped; weights (n_rays, 192) optional.
+ * Returns MNRF_ERR_UNSUPPORTED when the 48-samples-per-wave tuning is off (MNRF_SPLIT48=0 / MNRF_SPLIT32=1). */
+int mnrf_fused_samples_per_ray(void);
+int mnrf_field_composite_fused(const float* packed, int64_t n_rays, const float* rays, const float* z_vals,
+                               const float* dir_emb, int64_t dir_stride, int white_back,
+                               float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
+                               float* surf_normal, float* x_surface, void* stream);
+
 /* ---- training, round 3: operand planes (split arithmetic only) --------------------------------------------------------
  * The weight gradients dW = dY^T X contract over samples.  With MNRF_TRAIN_PLANES the training forward keeps the inputs X
  * of every Linear -- and mnrf_field_backward_planes the pre-activation gradients dY -- not as fp32 rows but as the hi/lo

@@ -60,6 +60,8 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_void_p), _c_f, _u32, _str]),
     "mnrf_field_backward": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 11 +
                             [ctypes.POINTER(ctypes.c_void_p), _c_f, _c_f, _c_f, _u32, _str]),
+    "mnrf_fused_samples_per_ray": (_int, []),
+    "mnrf_field_composite_fused": (_int, [_c_f, _i64, _c_f, _c_f, _c_f, _i64, _int] + [_c_f] * 7 + [_str]),
     "mnrf_train_planes_bytes": (_i64, [_i64]),
     "mnrf_train_dy_planes_bytes": (_i64, [_i64]),
     "mnrf_field_backward_planes": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 9 +

@@ -183,6 +183,30 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
     return mnrf_check_launch("mnrf_field_forward");
 }
 
+// ---------------------------------------------------------------------- ray-fused fine pass (eval, maps only)
+extern "C" int mnrf_fused_samples_per_ray(void) { return split48_ray_samples(); }
+
+extern "C" int mnrf_field_composite_fused(const float* packed, int64_t n_rays, const float* rays, const float* z_vals,
+                                          const float* dir_emb, int64_t dir_stride, int white_back,
+                                          float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
+                                          float* surf_normal, float* x_surface, void* stream) {
+    if (!packed || !rays || !z_vals || !dir_emb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_composite_fused: null pointer");
+    if (n_rays < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_composite_fused: negative ray count");
+    if (n_rays == 0) return MNRF_OK;
+    if (!split48_enabled() || split32_enabled())
+        return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_field_composite_fused: needs the 48-samples-per-wave tuning (MNRF_SPLIT48 != 0, MNRF_SPLIT32 unset)");
+    const int spr = split48_ray_samples();
+    FieldArgs A{packed, MNRF_SPLIT_F16, (long long)n_rays * spr, nullptr, 3, rays, z_vals, spr, dir_emb, (long long)dir_stride,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    A.fuse = 1;
+    A.white_back = white_back;
+    A.f_weights = weights; A.f_opacity = opacity; A.f_rgb_map = rgb_map; A.f_depth = depth; A.f_mirror_mask = mirror_mask;
+    A.f_surf_normal = surf_normal; A.f_x_surface = x_surface;
+    if (launch_split48(A, false, (hipStream_t)stream) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_composite_fused: too many samples for one launch");
+    return mnrf_check_launch("mnrf_field_composite_fused");
+}
+
 // ---------------------------------------------------------------------- training entry points
 static inline int64_t train_tiles(int64_t B) { return (B + s2::WG_SAMPLES - 1) / s2::WG_SAMPLES; }
 

@@ -37,6 +37,13 @@ struct FieldArgs {
     // split arithmetic, round 3: instead of fp32 rows in save_x the inputs of every Linear are kept as the hi/lo f16 operand
     // PLANES the weight-gradient GEMM consumes directly (mnrf_dwp.h): [sample blocks][PLX_FB][hi | lo][1 KiB]
     char* save_planes;
+    // ray-fused fine pass (eval, maps only: round 3).  spr == 192 samples of ONE ray per workgroup of the 48-samples-per-wave
+    // tuning: the four head outputs go to LDS instead of HBM and the workgroup composites its ray itself (mnrf_composite.inc,
+    // the body of composite_kernel: identical maps); sigma / rgb / pred_normal / is_mirror above are then unused.
+    int fuse;                      // 1: fused compositing on
+    int white_back;
+    float* f_weights;              // (n_rays, spr) or null
+    float* f_opacity; float* f_rgb_map; float* f_depth; float* f_mirror_mask; float* f_surf_normal; float* f_x_surface;
 };
 
 // training backward (activation gradients): mnrf_field_bwd.inc (fp32) and mnrf_field_split_bwd.inc (split-f16)
@@ -82,6 +89,7 @@ int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s);
 // 48-samples-per-wave tuning of the forward-only split kernels (mnrf_field_split3.hip), MNRF_SPLIT48=1
 bool split48_enabled();
 int launch_split48(const FieldArgs& A, bool sigma_only, hipStream_t s);
+int split48_ray_samples();      // samples of one workgroup of that tuning = samples per ray of the ray-fused fine pass (192)
 bool split32_enabled();      // MNRF_SPLIT32=1
 int launch_split32(const FieldArgs& A, bool sigma_only, hipStream_t s);
 void launch_split32_pack(const float* const* params, float* packed, hipStream_t s);

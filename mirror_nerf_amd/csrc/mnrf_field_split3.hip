@@ -40,10 +40,14 @@ int launch_split48(const FieldArgs& A, bool sigma_only, hipStream_t s) {
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   h3::LDS_BYTES_FUSE);
         return true;
     }();
     (void)once;
     return h3::launch(A, sigma_only, false, s);
 }
+
+int split48_ray_samples() { return h3::WG_SAMPLES; }
 
 }  // namespace mnrf

@@ -42,6 +42,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+#include "mnrf_composite.inc"
 
 // ------------------------------------------------------------------ Embedding.forward
 // models/mirror_nerf.py:20-38: out = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)]
@@ -98,82 +99,32 @@ struct CompArgs {
     float* surf_normal; float* surf_normal_grad; float* normal_dif; float* x_surface;
 };
 
+// per-sample inputs of one ray straight from the flat (n_rays * S) tensors in HBM
+struct CompGlobalSrc {
+    const CompArgs& A;
+    long long ray;
+    __device__ __forceinline__ bool has_noise() const { return A.noise != nullptr; }
+    __device__ __forceinline__ bool has_rgb() const { return A.rgb != nullptr; }
+    __device__ __forceinline__ bool has_mirror() const { return A.is_mirror != nullptr; }
+    __device__ __forceinline__ bool has_pn() const { return A.pred_normal != nullptr; }
+    __device__ __forceinline__ bool has_gn() const { return A.normal != nullptr; }
+    __device__ __forceinline__ float z(int s) const { return A.z[ray * A.S + s]; }
+    __device__ __forceinline__ float sigma(int s) const { return A.sigma[ray * A.S + s]; }
+    __device__ __forceinline__ float noise(int s) const { return A.noise[ray * A.S + s]; }
+    __device__ __forceinline__ float rgb(int s, int k) const { return A.rgb[(ray * A.S + s) * 3 + k]; }
+    __device__ __forceinline__ float mirror(int s) const { return A.is_mirror[ray * A.S + s]; }
+    __device__ __forceinline__ float pn(int s, int k) const { return A.pred_normal[(ray * A.S + s) * 3 + k]; }
+    __device__ __forceinline__ float gn(int s, int k) const { return A.normal[(ray * A.S + s) * 3 + k]; }
+};
+
 __global__ __launch_bounds__(256) void composite_kernel(CompArgs A) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= A.n_rays) return;
-    const int S = A.S;
-    const float* sg = A.sigma + ray * S;
-    const float* zz = A.z + ray * S;
-    float carry = 1.f;
-    float a_op = 0.f, a_d = 0.f, a_m = 0.f, a_nd = 0.f;
-    float a_c[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f}, a_g[3] = {0.f, 0.f, 0.f};
-    for (int base = 0; base < S; base += 64) {
-        const int s = base + lane;
-        const bool in = s < S;
-        float alpha = 0.f, zv = 0.f;
-        if (in) {
-            zv = zz[s];
-            const float delta = s + 1 < S ? zz[s + 1] - zv : 1e10f;   // rendering.py:182-186
-            float sv = sg[s];
-            if (A.noise) sv = sv + A.noise[ray * S + s];
-            alpha = 1.f - expf(-delta * fmaxf(sv, 0.f));                 // 190-192
-        }
-        const float t = in ? (1.f - alpha) + 1e-10f : 1.f;              // 195
-        float incl = t;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float up = __shfl_up(incl, o);
-            if (lane >= o) incl *= up;
-        }
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
-        const float w = alpha * (carry * excl);                         // 197-199
-        carry = carry * __shfl(incl, 63);
-        if (in) {
-            if (A.weights) A.weights[ray * S + s] = w;
-            a_op += w;
-            a_d += w * zv;
-            const long long i3 = (ray * S + s) * 3;
-            if (A.rgb) { a_c[0] += w * A.rgb[i3]; a_c[1] += w * A.rgb[i3 + 1]; a_c[2] += w * A.rgb[i3 + 2]; }
-            if (A.is_mirror) a_m += w * A.is_mirror[ray * S + s];
-            float pn[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
-            if (A.pred_normal) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { pn[k] = A.pred_normal[i3 + k]; a_n[k] += pn[k] * w; }
-            }
-            if (A.normal) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { gn[k] = A.normal[i3 + k]; a_g[k] += gn[k] * w; }
-            }
-            if (A.pred_normal && A.normal) {
-                const float d0 = gn[0] - pn[0], d1 = gn[1] - pn[1], d2 = gn[2] - pn[2];
-                a_nd += w * (d0 * d0 + d1 * d1 + d2 * d2);
-            }
-        }
-    }
-    a_op = wave_sum(a_op);
-    a_d = wave_sum(a_d);
-    a_m = wave_sum(a_m);
-    a_nd = wave_sum(a_nd);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { a_c[k] = wave_sum(a_c[k]); a_n[k] = wave_sum(a_n[k]); a_g[k] = wave_sum(a_g[k]); }
-    if (lane == 0) {
-        if (A.opacity) A.opacity[ray] = a_op;
-        if (A.rgb_map) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) A.rgb_map[ray * 3 + k] = A.white_back ? a_c[k] + (1.f - a_op) : a_c[k];
-        }
-        if (A.depth) A.depth[ray] = a_d;
-        if (A.mirror_mask) A.mirror_mask[ray] = a_m;
-        if (A.surf_normal) { for (int k = 0; k < 3; ++k) A.surf_normal[ray * 3 + k] = a_n[k]; }
-        if (A.surf_normal_grad) { for (int k = 0; k < 3; ++k) A.surf_normal_grad[ray * 3 + k] = a_g[k]; }
-        if (A.normal_dif) A.normal_dif[ray] = a_nd;
-        if (A.x_surface) {
-            const float* r = A.rays + ray * 8;
-            for (int k = 0; k < 3; ++k) A.x_surface[ray * 3 + k] = r[k] + r[3 + k] * a_d;   // 362-367
-        }
-    }
+    const CompGlobalSrc src{A, ray};
+    const CompMaps out{A.weights ? A.weights + ray * A.S : nullptr, A.opacity, A.rgb_map, A.depth, A.mirror_mask, A.surf_normal,
+                       A.surf_normal_grad, A.normal_dif, A.x_surface, A.rays, A.white_back};
+    composite_ray(src, A.S, lane, ray, out);
 }
 
 

@@ -115,8 +115,9 @@ def _blend_autograd(base, sec, index, mask, want_reflect, detach_sec=False):
 
 
 def _pick_normal(r, sel):
-    """train.py:194-215 / eval.py:338-360 -- composited predicted normal, else composited grad normal."""
-    if f"pred_normal_{sel}" in r:
+    """train.py:194-215 / eval.py:338-360 -- composited predicted normal, else composited grad normal.  (The reference keys
+    on `pred_normal_*`; `surface_normal_*` exists exactly when that does, and is all the ray-fused eval pass produces.)"""
+    if f"surface_normal_{sel}" in r:
         return r[f"surface_normal_{sel}"]
     return r[f"surface_normal_grad_{sel}"]
 
@@ -290,6 +291,10 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     if noise_iter is not None:
         noise_iter = iter(noise_iter)
     to_cpu = kwargs.get("to_cpu", True)
+    # per-ray maps only (the per-sample tensors are neither copied nor, in the final pass, produced at all: render_rays
+    # `_maps_only`): what to_cpu="maps" returns anyway; with to_cpu=False it is opt-in (maps_only=True), the full dict stays
+    # the default contract
+    maps_only = bool(kwargs.get("maps_only", to_cpu == "maps")) and os.environ.get("MNRF_FUSED_EVAL", "1") != "0"
     rough = getattr(args, "app_control_mirror_roughness", False)
     batch_jitter = kwargs.get("batch_jitter", noise_iter is None)   # see the roughness branch of recurse()
     one_field = getattr(args, "only_one_field", False)
@@ -309,7 +314,7 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
                         white_back, test_time=test_time,
                         compute_normal=trace_flag and (not args.predict_normal),
                         only_one_field=one_field, only_one_field_fine_epoch=fine_epoch,
-                        current_epoch=fine_epoch + 1, _guard=False)
+                        current_epoch=fine_epoch + 1, _guard=False, _maps_only=maps_only)
         r[f"rgb_{sel}_reflect"] = torch.zeros_like(r[f"rgb_{sel}"])
         r[f"depth_{sel}_reflect"] = torch.zeros_like(r[f"depth_{sel}"])
         mask = None
@@ -411,9 +416,9 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
         else:
             out = recurse(rays[i:i + chunk].contiguous(), 0)
         for k, v in out.items():
-            if to_cpu == "maps":
+            if to_cpu == "maps" or maps_only:
                 if v.dim() <= 2 and (v.dim() == 1 or v.shape[1] <= 3):     # per-ray maps only
-                    results[k] += [v.to("cpu", non_blocking=True)]
+                    results[k] += [v.to("cpu", non_blocking=True) if to_cpu == "maps" else (v.cpu() if to_cpu else v)]
             else:
                 results[k] += [v.cpu() if to_cpu else v]
     if to_cpu == "maps" and rays.is_cuda:

@@ -13,7 +13,10 @@ Differences from the reference that do not change values:
   * random draws can be injected (`_perturb_rand`, `_noise_coarse`, `_noise_fine`, `_u`) so that
     tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator; `_z_fine` (N, S+N_importance)
     replaces the resampled depths altogether (fixtures G14 of the fine pass);
-  * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached.
+  * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached;
+  * `_maps_only=True` (set by batched_inference for to_cpu="maps" / maps_only=True): in eval the final pass runs ray-fused --
+    field evaluation + compositing in one kernel -- and the per-sample keys nobody downstream of eval.py:735-736 reads
+    (weights_*, pred_normal_*) are not produced; the per-ray maps are identical bit for bit.
 Outputs live on rays.device.  When autograd is enabled and a model parameter (or `rays`) requires
 grad, the field evaluation and the compositing run through `autograd.FieldFn` / `CompositeFn`,
 whose backward passes are HIP kernels too (including the second-order term that reaches the
@@ -139,6 +142,41 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     has_fine = "fine" in models
     results = {}
 
+    def inference_fused(model, typ, z):
+        """Eval, per-ray maps only (`_maps_only`): field evaluation and compositing of the final pass in ONE kernel
+        (mnrf_field_composite_fused): a workgroup owns a ray, the four head outputs never leave LDS.  Same maps bit for bit
+        as the two-kernel path; the per-sample keys (weights_*, pred_normal_*) are not produced.  Returns False when the
+        launch class is not covered (the caller then takes the two-kernel path)."""
+        from . import mirror_nerf as _mn
+        from .weights import packed_of
+        if _mn.precision_of(model) != "split" or z.shape[1] != L.mnrf_fused_samples_per_ray():
+            return False
+        has_m, has_n = getattr(model, "predict_mirror_mask", True), getattr(model, "predict_normal", True)
+        opacity, rgb_map, depth, xs = f(N), f(N, 3), f(N), f(N, 3)
+        mask = f(N) if has_m else None
+        sn = f(N, 3) if has_n else None
+        if _mn.LAUNCH_LOG is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = L.mnrf_field_composite_fused(p(packed_of(model)), N, p(rays), p(z), p(dir_emb), dir_emb.shape[1], int(bool(white_back)),
+                                          None, p(opacity), p(rgb_map), p(depth), p(mask), p(sn), p(xs), _lib.stream())
+        if rc == -3:          # MNRF_ERR_UNSUPPORTED: the 48-samples-per-wave tuning is switched off
+            return False
+        _lib.check(rc, "mnrf_field_composite_fused")
+        if _mn.LAUNCH_LOG is not None:
+            e1.record()
+            _mn.LAUNCH_LOG.append((_lib.MNRF_SPLIT_F16 | 0x2000, N * z.shape[1], e0, e1))     # 0x2000: ray-fused launch
+        results[f"opacity_{typ}"] = opacity
+        results[f"z_vals_{typ}"] = z
+        results[f"rgb_{typ}"] = rgb_map
+        results[f"depth_{typ}"] = depth
+        if has_m:
+            results[f"mirror_mask_{typ}"] = mask
+        if has_n:
+            results[f"surface_normal_{typ}"] = sn
+        results[f"_x_surface_{typ}"] = xs
+        return True
+
     def inference(model, typ, z, noise_key):
         """rendering.py:108-264 for one pass.  In the sigma-only coarse pass the reference also
         evaluates (and discards) the normals; they are not computed here."""
@@ -147,6 +185,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         B = N * S
         if train and not sigma_only and N:
             return inference_train(model, typ, z, noise_key)
+        if (kwargs.get("_maps_only") and test_time and not sigma_only and N and not hashgrid and not compute_normal
+                and noise_std == 0 and kwargs.get(noise_key) is None and inference_fused(model, typ, z)):
+            return
         if N and hashgrid:
             o = model.field(B, rays=rays, z_vals=z, spr=S, dirs=dir_emb, sigma_only=sigma_only,
                             grad_normal=compute_normal and not sigma_only)

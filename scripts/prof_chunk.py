@@ -19,6 +19,7 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--rays", type=int, default=32768)
 ap.add_argument("--train", action="store_true", help="train-mode forward: full coarse pass + density-gradient normals")
 ap.add_argument("--tcnn", action="store_true", help="hash-grid field (config 5) instead of the 8x256 MLP")
+ap.add_argument("--fused", action="store_true", help="also render the chunk with the ray-fused fine pass (maps only)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 models, sds, emb = bench.build_models(dev)
@@ -47,8 +48,10 @@ for _ in range(a.reps + 1):
     else:
         with torch.no_grad():   # inference kernels (with autograd on, render_rays takes the training forward)
             M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False)
+            if a.fused:         # the same chunk, final pass ray-fused (field + compositing in one kernel, no per-sample output)
+                M.render_rays(models, emb, rays, 64, False, 0, 0, 128, test_time=True, compute_normal=False, _maps_only=True)
 torch.cuda.synchronize()
-for flags, B, e0, e1 in MN.LAUNCH_LOG[2:]:
+for flags, B, e0, e1 in MN.LAUNCH_LOG[(4 if a.fused else 2):]:
     ms = e0.elapsed_time(e1)
     flop = B * (MN.FLOP_SIGMA if flags & 1 else MN.FLOP_FULL) + (B * MN.FLOP_GRAD if flags & 2 else 0)
     print(f"flags={flags} B={B} {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s (algorithmic)")

@@ -746,3 +746,69 @@ def test_split32_tuning_passes_the_parity_suite(switch):
                         "or ragged or threshold or saturation or falls_back"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+# --------------------------------------------------------------------------- ray-fused eval pass (maps only)
+MAP_KEYS = ("rgb_fine", "depth_fine", "opacity_fine", "mirror_mask_fine", "surface_normal_fine", "x_surface_fine")
+
+
+@pytest.mark.parametrize("name", ["g4_fine_test", "g11_trained_render_test", "g11_rough_render_test"])
+def test_fused_fine_pass_gives_the_same_maps_bit_for_bit(name, precision):
+    """`_maps_only` (eval): field evaluation + compositing of the 192-sample fine pass in ONE kernel, head outputs in LDS
+    (mnrf_field_composite_fused).  The per-ray maps must equal the two-kernel path's bit for bit (the compositing is the same
+    code), meet the fixture like it does, and no per-sample key of the final pass may be produced.  Under the fp32
+    arithmetic the request falls back to the two-kernel path (same keys as maps-only would give are still present)."""
+    fx = FX.Fixture(name)
+    m = fx.meta
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+
+    def render(r, **kw):
+        with torch.no_grad():      # (with autograd on, render_rays takes the training forward: another kernel family)
+            return _np(_M().render_rays(models, _emb(), r, m["N_samples"], m["use_disp"], m["perturb"], m["noise_std"], m["N_importance"],
+                                        m["chunk"], m["white_back"], m["test_time"], **kw, **m["kwargs"]))
+    got = render(rays)
+    fused = render(rays, _maps_only=True)
+    for k in MAP_KEYS:
+        assert np.array_equal(fused[k], got[k]), k
+    if precision == "split":
+        assert "weights_fine" not in fused and "pred_normal_fine" not in fused
+    assert "weights_coarse" in fused and "z_vals_fine" in fused
+    if name.startswith("g11_"):
+        _cmp_trained(name, fused, fx, list(FX.PER_SAMPLE_FINE) + ["normal_coarse", "normal_fine", "pred_normal_coarse"])
+    else:
+        _cmp(name, fused, {k: v for k, v in fx.outputs.items() if k in fused}, m)
+    # ragged ray counts and an empty batch
+    for n in (1, 3, 0):
+        r = render(rays[:n].contiguous(), _maps_only=True)
+        assert r["rgb_fine"].shape == (n, 3)
+        if n:
+            assert np.array_equal(r["rgb_fine"], got["rgb_fine"][:n])
+
+
+def test_fused_eval_through_the_recursion(precision):
+    """batched_inference with maps_only=True / to_cpu="maps": the same per-ray maps as the full-dict frame, two bounces
+    (level-1 reflections are compacted: ragged ray counts go through the fused kernel too)."""
+    from tests.golden import weights as GW
+    sds = GW.make_state_dict(0, 2)
+    for sd in sds:
+        GW.apply_tweaks(sd, GW.STRADDLE)
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(O.synthetic_rays(40, 40)[::3][:500].copy()).to(DEV)
+    args = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=2)
+    M = _M()
+    full = M.batched_inference(models, _emb(), rays, 64, 128, False, 200, args=args, trace_secondary_rays=True, to_cpu=False)
+    maps = M.batched_inference(models, _emb(), rays, 64, 128, False, 200, args=args, trace_secondary_rays=True, to_cpu=False, maps_only=True)
+    host = M.batched_inference(models, _emb(), rays, 64, 128, False, 200, args=args, trace_secondary_rays=True, to_cpu="maps")
+    assert int((full["mirror_mask_fine"] != 0).sum()) > 0
+    for k in MAP_KEYS + ("rgb_fine_reflect", "depth_fine_reflect", "reflect_direction"):
+        assert torch.equal(maps[k], full[k]), k
+        assert torch.equal(host[k], full[k].cpu()), k
+    assert all(v.dim() <= 2 for v in maps.values())
+    if precision == "split":
+        assert "weights_fine" not in maps
+    # N_importance = 64 (128 samples per ray) is not the fused launch class: the request is honoured by the two-kernel path
+    a = M.batched_inference(models, _emb(), rays, 64, 64, False, 200, args=args, trace_secondary_rays=True, to_cpu=False)
+    b = M.batched_inference(models, _emb(), rays, 64, 64, False, 200, args=args, trace_secondary_rays=True, to_cpu=False, maps_only=True)
+    assert torch.equal(a["rgb_fine"], b["rgb_fine"]) and torch.equal(a["depth_fine"], b["depth_fine"])
