@@ -253,7 +253,8 @@ int64_t mnrf_train_dy_planes_bytes(int64_t B);   /* dY planes of B samples (byte
 
 /* Activation gradients only (no weight gradients): mnrf_field_backward's first half on the split arithmetic.  dy_planes
  * (mnrf_train_dy_planes_bytes(B)) receives dY under one power-of-two scale for the whole call, derived from the largest seed
- * magnitude, whose float bits are left in *seedmax (a device word, overwritten) for mnrf_dw_planes. */
+ * magnitude, whose float bits are left in *seedmax (a device word, overwritten) for mnrf_dw_planes.  A null upstream
+ * gradient means zero (no tensor of zeros needed for a head no loss reads). */
 int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                const float* rays, const float* z_vals, int spr,
                                const float* g_sigma, const float* g_rgb, const float* g_pred_normal,

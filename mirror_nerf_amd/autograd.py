@@ -165,7 +165,10 @@ class FieldFn(torch.autograd.Function):
         dev = packed.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         z = lambda t, *s: torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()  # noqa: E731
-        g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
+        if ctx.planes:      # a missing upstream gradient stays a null pointer there (no tensor of zeros, no memset)
+            g_sigma, g_rgb, g_pn, g_m = [None if t is None else t.contiguous().float() for t in (g_sigma, g_rgb, g_pn, g_m)]
+        else:
+            g_sigma, g_rgb, g_pn, g_m = z(g_sigma, B), z(g_rgb, B, 3), z(g_pn, B, 3), z(g_m, B)
         # A module evaluated several times in one step (primary rays, then reflected rays: train.py:253-259) gets one
         # gradient per evaluation and autograd would add them with one kernel per parameter (64 launches per step).
         # Instead the evaluations of a pass work on ONE private set of gradient tensors (views of one flat buffer) and
@@ -342,7 +345,7 @@ class ReflectFn(torch.autograd.Function):
         dev = rays.device
         sec = torch.empty(N, 8, dtype=torch.float32, device=dev)
         index = torch.empty(N, dtype=torch.int32, device=dev)
-        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        count = torch.full((1,), 0, dtype=torch.int32, device=dev)      # (torch.zeros is a memset: ~40 us of idle GPU each)
         rdir = torch.empty(N, 3, dtype=torch.float32, device=dev)
         p = _lib.ptr
         _lib.check(_lib.lib().mnrf_reflect_compact(

@@ -16,6 +16,7 @@
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
+#include "mnrf_fill.h"
 #include "mnrf_layout.h"
 #include "mnrf_dwp.h"
 #include "mnrf_dw.h"
@@ -262,13 +263,15 @@ __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* 
                                 unsigned* __restrict__ out) {
     float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
-        mx = fmaxf(mx, fabsf(g_sigma[i]));
+        if (g_sigma) mx = fmaxf(mx, fabsf(g_sigma[i]));
+        if (g_rgb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float y = rgb[i * 3 + c];
-            mx = fmaxf(mx, fabsf(g_rgb[i * 3 + c] * y * (1.f - y)));
+            for (int c = 0; c < 3; ++c) {
+                const float y = rgb[i * 3 + c];
+                mx = fmaxf(mx, fabsf(g_rgb[i * 3 + c] * y * (1.f - y)));
+            }
         }
-        {
+        if (g_pn) {
             const float inv = save_inv[i];
             const float g0 = g_pn[i * 3], g1 = g_pn[i * 3 + 1], g2 = g_pn[i * 3 + 2];
             float s0, s1, s2;
@@ -281,7 +284,7 @@ __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* 
             }
             mx = fmaxf(mx, fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2))));
         }
-        {
+        if (g_m) {
             const float y = is_mirror[i];
             mx = fmaxf(mx, fabsf(g_m[i] * y * (1.f - y)));
         }
@@ -294,7 +297,7 @@ __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* 
 
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s) {
-    (void)hipMemsetAsync(out, 0, sizeof(unsigned), s);
+    zero_fill(s, out, sizeof(unsigned));
     long long blocks = (B + 1023) / 1024;       // four samples per thread
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,

@@ -123,6 +123,7 @@ __global__ void pack_kernel(PackArgs P, PartTable T) {
 #include "../../include/mnrf.h"
 #include "mnrf_dw.h"
 #include "mnrf_error.h"
+#include "mnrf_fill.h"
 
 using namespace mnrf;
 
@@ -140,7 +141,7 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     build_parts(T);
     const int threads = 256;
     const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
-    (void)hipMemsetAsync(packed + PACKED_FLOATS - 1, 0, sizeof(float), (hipStream_t)stream);   // range-guard word (mnrf.h)
+    mnrf::zero_fill((hipStream_t)stream, packed + PACKED_FLOATS - 1, sizeof(float));   // range-guard word (mnrf.h)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
     launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
     if (split32_enabled()) launch_split32_pack(params, packed, (hipStream_t)stream);   // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)
@@ -285,8 +286,6 @@ extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const 
     if (!packed || !save_mask || !save_inv || !dy_planes || !seedmax)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: negative sample count");
-    if (!g_sigma || !g_rgb || !g_pred_normal || !g_is_mirror)
-        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: all four upstream gradients are required (pass zeros)");
     if (!rgb || !pred_normal || !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: forward outputs missing");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: need xyz or rays+z_vals");
     hipStream_t s = (hipStream_t)stream;

@@ -19,6 +19,7 @@
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
+#include "mnrf_fill.h"
 
 namespace {
 
@@ -404,9 +405,7 @@ extern "C" int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void*
         } else {
             // term switched off (or no per-sample inputs): the gradients of the per-sample tensors are zero
             const size_t per = (size_t)n * (size_t)(A.n_samples[typ] > 0 ? A.n_samples[typ] : 0) * sizeof(float);
-            if (A.g_pred_normal[typ] && per) (void)hipMemsetAsync(A.g_pred_normal[typ], 0, per * 3, s);
-            if (A.g_weights[typ] && per) (void)hipMemsetAsync(A.g_weights[typ], 0, per, s);
-            if (typ == 1 && A.g_normal_fine && per) (void)hipMemsetAsync(A.g_normal_fine, 0, per * 3, s);
+            if (per) mnrf::zero_fill(s, A.g_pred_normal[typ], per * 3, A.g_weights[typ], per, typ == 1 ? A.g_normal_fine : nullptr, per * 3);
         }
     }
     // losses.py:124: "fine" first

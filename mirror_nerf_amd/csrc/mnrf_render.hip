@@ -12,6 +12,7 @@
 
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
+#include "mnrf_fill.h"
 
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -728,9 +729,7 @@ extern "C" int mnrf_reflect_backward(const float* rays, const float* normal, con
     if (!rays || !normal || !g_x_surface || !g_normal || !g_rays || (n_sec > 0 && !g_sec))
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(g_x_surface, 0, n_rays * 3 * sizeof(float), s);
-    (void)hipMemsetAsync(g_normal, 0, n_rays * 3 * sizeof(float), s);
-    (void)hipMemsetAsync(g_rays, 0, n_rays * 8 * sizeof(float), s);
+    mnrf::zero_fill(s, g_x_surface, n_rays * 3 * sizeof(float), g_normal, n_rays * 3 * sizeof(float), g_rays, n_rays * 8 * sizeof(float));
     if (n_sec > 0)
         hipLaunchKernelGGL(reflect_backward_kernel, dim3(blocks_for(n_sec, 256)), dim3(256), 0, s, rays, normal, index, (long long)n_sec,
                            g_sec, g_x_surface, g_normal, g_rays);

@@ -34,7 +34,7 @@ def _threshold_(mask, want_any=True):
     """In place m[m>0.5]=1, m[m<0.5]=0 (exactly 0.5 untouched); returns any(m != 0) as a bool.
     want_any=False skips the device->host read of the flag (a stream sync) when the caller does not branch on it."""
     n = mask.shape[0]
-    flag = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    flag = torch.full((1,), 0, dtype=torch.int32, device=mask.device)      # (not torch.zeros: that is a memset, ~40 us of idle GPU)
     if n:
         _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), n, _lib.ptr(flag), _lib.stream()),
                    "mnrf_threshold_mask")
@@ -45,7 +45,7 @@ def _threshold_async(mask, host_flags, slot):
     """_threshold_ without the stream sync: the flag travels to pinned host memory behind the kernel and an event marks its
     arrival; `_flag_ready` waits for THAT event only, so launches queued meanwhile (the next chunk's primary pass) keep
     the GPU busy."""
-    flag = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    flag = torch.full((1,), 0, dtype=torch.int32, device=mask.device)      # (not torch.zeros: that is a memset, ~40 us of idle GPU)
     _lib.check(_lib.lib().mnrf_threshold_mask(_lib.ptr(mask), mask.shape[0], _lib.ptr(flag), _lib.stream()), "mnrf_threshold_mask")
     host = host_flags[slot:slot + 1]
     host.copy_(flag, non_blocking=True)
@@ -66,7 +66,7 @@ def _reflect(rays, x_surface, normal, mask, compact, normal_noise=None, noise_st
     dev = rays.device
     sec = _f(dev, N, 8)
     index = torch.empty(N, dtype=torch.int32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    count = torch.full((1,), 0, dtype=torch.int32, device=dev)
     rdir = _f(dev, N, 3) if want_dir else None
     p = _lib.ptr
     _lib.check(_lib.lib().mnrf_reflect_compact(
@@ -155,8 +155,14 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     if (not only_in) and recur_level > 0:
         mask = mask * mirror_mask_prev.float()
         any_mirror = None
+    assumed_mirror = False
     if any_mirror is None:
-        any_mirror = bool((mask != 0).any().item()) if (N and can_trace) else False
+        if N and can_trace and only_in and not hp.for_vis:
+            # compacted reflections: "any mirror pixel" is "the compaction found a ray" -- ONE device->host read (the count the
+            # reflect kernel returns) instead of two stream syncs per level
+            any_mirror = assumed_mirror = True
+        else:
+            any_mirror = bool((mask != 0).any().item()) if (N and can_trace) else False
 
     # -- trace decision (train.py:170-178)
     trace = bool(hp.trace_secondary_rays and (not train_geometry_stage) and (any_mirror or hp.for_vis))
@@ -196,6 +202,8 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
                     r[f"depth_{sel}_reflect"] = r2[f"depth_{sel}"]
                 r["secondary_rays_o"] = r[f"x_surface_{sel}"]
                 r["reflect_direction"] = rdir
+        elif assumed_mirror:
+            trace = False       # the compaction found no mirror pixel: what mask.any() would have said up front
     if not trace and is_eval:                                            # train.py:325-346
         for typ in ("coarse", "fine"):
             if f"rgb_{typ}" in r:

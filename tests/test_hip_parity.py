@@ -772,7 +772,8 @@ def test_fused_fine_pass_gives_the_same_maps_bit_for_bit(name, precision):
     fused = render(rays, _maps_only=True)
     for k in MAP_KEYS:
         assert np.array_equal(fused[k], got[k]), k
-    if precision == "split":
+    fusable = precision == "split" and os.environ.get("MNRF_SPLIT32", "0") != "1" and os.environ.get("MNRF_SPLIT48", "1") != "0"
+    if fusable:      # (other tunings of the field kernel: the request falls back to the two-kernel path, keys and all)
         assert "weights_fine" not in fused and "pred_normal_fine" not in fused
     assert "weights_coarse" in fused and "z_vals_fine" in fused
     if name.startswith("g11_"):
@@ -806,7 +807,7 @@ def test_fused_eval_through_the_recursion(precision):
         assert torch.equal(maps[k], full[k]), k
         assert torch.equal(host[k], full[k].cpu()), k
     assert all(v.dim() <= 2 for v in maps.values())
-    if precision == "split":
+    if precision == "split" and os.environ.get("MNRF_SPLIT32", "0") != "1" and os.environ.get("MNRF_SPLIT48", "1") != "0":
         assert "weights_fine" not in maps
     # N_importance = 64 (128 samples per ray) is not the fused launch class: the request is honoured by the two-kernel path
     a = M.batched_inference(models, _emb(), rays, 64, 64, False, 200, args=args, trace_secondary_rays=True, to_cpu=False)
