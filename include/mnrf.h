@@ -304,7 +304,12 @@ int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
                        int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                        const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
-                       float* d_weights, float* d_xyz, float* d_dir, void* stream);
+                       float* d_weights, float* d_xyz, float* d_dir,
+                       const float* keep_mirror /* (B/spr) per ray [(B) with xyz] or null: 0 = the mirror head of this ray's samples
+                                                   sees geo_feat.detach() (models/mirror_nerf_tcnn.py:200-215) */,
+                       unsigned flags /* MNRF_CUT_NORMAL_HEAD / MNRF_CUT_MIRROR_HEAD: that head sees geo_feat.detach()
+                                         (mirror_nerf_tcnn.py:186-190, 196-199) */,
+                       void* stream);
 
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,

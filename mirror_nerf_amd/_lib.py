@@ -73,7 +73,7 @@ SIGNATURES = {
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
     "mnrf_tcnn_backward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _i64,
-                                  _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 10 + [_str]),
+                                  _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 11 + [_u32, _str]),
     "mnrf_tcnn_backward_workspace_floats": (_i64, [ctypes.POINTER(ctypes.c_int64)]),
     "mnrf_sample_fine": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _str]),
     "mnrf_threshold_mask": (_int, [_c_f, _i64, _c_i, _str]),

@@ -767,6 +767,10 @@ struct TcnnBwdArgs {
     long long cp_off[NL];                        // float offset of the level's first copy in `copies`
     int agg_levels;                              // levels [0, agg_levels) sum runs of equal cells inside the wave first
     int exp_noscatter;                           // experiment (MNRF_EXP_TCNN_NOSCATTER): skip the table atomics
+    // gradient steering (models/mirror_nerf_tcnn.py:186-215, the --detach_density_* options): a head that sees geo_feat.detach()
+    // still gets its own weight gradients but adds nothing to dL/d geo_feat
+    unsigned cut;                                // MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD
+    const float* keep_mirror;                    // per ray (per sample with xyz) or null: 0 = cut the mirror head for this ray's samples
 };
 
 __device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
@@ -924,6 +928,9 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             g_pn[a] = (live && P.g_pn) ? P.g_pn[i * 3 + a] : 0.f;
         }
         const float g_m = (live && P.g_m) ? P.g_m[i] : 0.f;
+        const float keep_n = (P.cut & MNRF_CUT_NORMAL_HEAD) ? 0.f : 1.f;
+        float keep_mh = (P.cut & MNRF_CUT_MIRROR_HEAD) ? 0.f : 1.f;
+        if (P.keep_mirror && P.keep_mirror[A.xyz ? i : i / A.spr] == 0.f) keep_mh = 0.f;
         float u[3];
         bool oob = false;
 #pragma unroll
@@ -1001,7 +1008,12 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                 for (int k = 0; k < 32; ++k) GR(k) = hn[32 * h + k];
                 __syncthreads();
                 if (wave < 2) dw_tile(t_n0[h], 16 * wave, 0);   // normal_net.0 (64 x 16): row block 2h + wave
-                back_rows<16>(32, W_N0 + 32 * h * 16, g_geo);
+                float g_head[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) g_head[k] = 0.f;
+                back_rows<16>(32, W_N0 + 32 * h * 16, g_head);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) g_geo[k] += keep_n * g_head[k];      // (detach_density_for_normal_loss: 0)
                 __syncthreads();
             }
         }
@@ -1033,7 +1045,12 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             for (int k = 0; k < 32; ++k) GR(k) = hm[k];
             __syncthreads();
             if (wave < 2) dw_tile(t_m0, 16 * wave, 0);          // is_mirror_net.0 (32 x 16): row block = wave
-            back_rows<16>(32, W_M0, g_geo);                     // (column 15 of the padded weights is zero)
+            float g_head[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g_head[k] = 0.f;
+            back_rows<16>(32, W_M0, g_head);                    // (column 15 of the padded weights is zero)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g_geo[k] += keep_mh * g_head[k];         // (detach_density_*_for_mask_loss: 0)
             __syncthreads();
         }
         // ---- colour head: [SH4(d), geo] -> c1 (ReLU) -> c2 (ReLU) -> sigmoid
@@ -1517,7 +1534,8 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
                                   int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                   const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
-                                  float* d_weights, float* d_xyz, float* d_dir, void* stream) {
+                                  float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
+                                  void* stream) {
     if (!table || !offsets17_host || !weights || !d_table || !d_weights)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: null pointer");
     if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: negative sample count");
@@ -1540,6 +1558,8 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
     P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror; P.g_normal = g_normal;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
+    P.cut = flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD);
+    P.keep_mirror = keep_mirror;
     P.copies = workspace;
     P.exp_noscatter = getenv("MNRF_EXP_TCNN_NOSCATTER") != nullptr;
     P.agg_levels = 0;

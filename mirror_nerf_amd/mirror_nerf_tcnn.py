@@ -59,6 +59,12 @@ class TcnnFieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *params):
+        # `want_normal` may be a tuple (want_normal, cut_flags, keep_mirror) like FieldFn's: the --detach_density_* options
+        # (models/mirror_nerf_tcnn.py:186-215) make normal_net / is_mirror_net see geo_feat.detach()
+        ctx.cut, ctx.keep_mirror = 0, None
+        if isinstance(want_normal, tuple):
+            want_normal, ctx.cut, km = want_normal[0], int(want_normal[1]), want_normal[2]
+            ctx.keep_mirror = None if km is None else km.detach().float().contiguous()
         B = xyz6.shape[0] if xyz6 is not None else rays.shape[0] * spr
         c = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
         xyz6, rays, z_vals, dirs = c(xyz6), c(rays), c(z_vals), c(dirs)
@@ -96,7 +102,8 @@ class TcnnFieldFn(torch.autograd.Function):
             _lib.check(_lib.lib().mnrf_tcnn_backward(
                 p(table), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
-                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), _lib.stream()), "mnrf_tcnn_backward")
+                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut,
+                _lib.stream()), "mnrf_tcnn_backward")
         grads, off = [], 0
         for _name, rows, used, padded in _BLOB:
             if padded:
@@ -223,7 +230,16 @@ class MirrorNeRFTcnn(nn.Module):
         if (not sigma_only and x.shape[1] == 6 and torch.is_grad_enabled()
                 and (x.requires_grad or any(q.requires_grad for q in self.parameters()))):
             # training route (geo_feat is a constant of the graph; the density-gradient normal carries its second-order term)
-            sigma, rgb, pn, mir, normal, geo = TcnnFieldFn.apply(self, 1, x, None, None, None, bool(compute_normal),
+            # the --detach_density_* options (models/mirror_nerf_tcnn.py:186-215): that head sees geo_feat.detach()
+            cut, keep = 0, None
+            if detach_density_for_normal_loss:
+                cut |= _lib.MNRF_CUT_NORMAL_HEAD
+            if detach_density_for_mask_loss:
+                cut |= _lib.MNRF_CUT_MIRROR_HEAD
+            elif detach_density_outside_mirror_for_mask_loss and mirror_mask is not None and not bool((mirror_mask < 0).any()):
+                keep = mirror_mask.bool().float().contiguous()          # per sample: inside the mirror the gradient flows
+            want = (bool(compute_normal), cut, keep) if (cut or keep is not None) else bool(compute_normal)
+            sigma, rgb, pn, mir, normal, geo = TcnnFieldFn.apply(self, 1, x, None, None, None, want,
                                                                  self.encoder.embeddings, *self.mlp_params())
             out = {"normal": normal} if compute_normal else {}
             out.update(sigma=sigma, geo_feat=geo, pred_normal=pn, rgb=rgb, is_mirror=mir.view(B, 1))

@@ -117,8 +117,6 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if kwargs.get("detach_density_for_normal_loss", False):
             comp_detach |= _lib.MNRF_DETACH_W_NORMAL
             cut_heads |= _lib.MNRF_CUT_NORMAL_HEAD
-        if hashgrid and (comp_detach or cut_heads or keep_mirror is not None):
-            raise NotImplementedError("the detach_density_* options are not implemented for the hash-grid field")
 
     # rendering.py:275-277 -- view encoding once per ray
     view = kwargs.get("view_dir", rays[:, 3:6])
@@ -249,7 +247,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         S = z.shape[1]
         if hashgrid:
             from .mirror_nerf_tcnn import TcnnFieldFn
-            sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, bool(compute_normal),
+            want = bool(compute_normal)
+            if cut_heads or keep_mirror is not None:
+                want = (want, cut_heads, keep_mirror)
+            sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, want,
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:
             want = bool(compute_normal)

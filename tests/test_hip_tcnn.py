@@ -151,6 +151,55 @@ def test_tcnn_backward_matches_torch_autograd(bound, B, which):
     assert int((got["encoder.embeddings"] != 0).sum()) <= B * 16 * 8 * 2
 
 
+@pytest.mark.parametrize("mode", ["normal", "mask", "outside"])
+def test_tcnn_backward_detach_density_options(mode):
+    """--detach_density_for_normal_loss / _for_mask_loss / _outside_mirror_for_mask_loss on the hash-grid field
+    (models/mirror_nerf_tcnn.py:186-215): the head evaluated on geo_feat.detach() keeps its own weight gradients but sends
+    nothing into sigma_net / the table / the positions.  Against torch autograd (fp64) with the same .detach()s; the option
+    must move some gradient by an amount no tolerance could hide."""
+    m, _w, cfg = _model(1.0, seed=5, table_scale=0.3)
+    B = 600
+    g = torch.Generator().manual_seed(17)
+    xyz = (torch.rand(B, 3, generator=g) * 2 - 1)
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    x6 = torch.cat([xyz, d], 1).to(DEV)
+    seeds = {"sigma": torch.randn(B, generator=g).to(DEV), "rgb": torch.randn(B, 3, generator=g).to(DEV),
+             "pred_normal": torch.randn(B, 3, generator=g).to(DEV), "is_mirror": torch.randn(B, generator=g).to(DEV)}
+    if mode != "normal":       # the random-init mirror head sends little into geo_feat: weigh its seed so that the cut shows
+        seeds["is_mirror"] = seeds["is_mirror"] * 300.0
+    gt_mask = (torch.rand(B, generator=g) < 0.4).float().to(DEV)
+    kw = dict(detach_density_for_normal_loss=mode == "normal", detach_density_for_mask_loss=mode == "mask",
+              detach_density_outside_mirror_for_mask_loss=mode == "outside", mirror_mask=gt_mask if mode == "outside" else None)
+
+    def hip(**k):
+        m.zero_grad()
+        x = x6.clone().requires_grad_(True)
+        out = m(x, compute_normal=False, **k)
+        outs = {"sigma": out["sigma"], "rgb": out["rgb"], "pred_normal": out["pred_normal"], "is_mirror": out["is_mirror"][:, 0]}
+        sum((outs[q] * seeds[q]).sum() for q in outs).backward()
+        gr = {q: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for q, v in m.named_parameters()}
+        gr["x6"] = x.grad.clone()
+        return gr
+    got, plain = hip(**kw), hip()
+    from tests import torch_ref as R
+    w = {q: v.detach().double().clone().requires_grad_(True) for q, v in m.state_dict().items()}
+    x = x6.detach().double().clone().requires_grad_(True)
+    sigma, rgb, pn, mm = R.tcnn_field(w, x, cfg, detach_normal=mode == "normal",
+                                      detach_mirror=True if mode == "mask" else ((gt_mask == 0) if mode == "outside" else None))
+    outs = {"sigma": sigma, "rgb": rgb, "pred_normal": pn, "is_mirror": mm}
+    sum((outs[q] * seeds[q].double()).sum() for q in outs).backward()
+    moved = 0.0
+    for q, wv in w.items():
+        wv = (wv.grad if wv.grad is not None else torch.zeros_like(wv)).float()
+        scale = float(wv.abs().max()) + 1e-12
+        assert float((got[q] - wv).abs().max()) <= 2e-5 * scale + 1e-7, (mode, q)
+        moved = max(moved, float((got[q] - plain[q]).abs().max()) / scale)
+    assert moved > 0.05, (mode, moved)       # the option changed some gradient by more than 5 % of its tensor's largest entry
+    # the cut head's own weights are unaffected
+    head = "normal_net.1.weight" if mode == "normal" else "is_mirror_net.2.weight"
+    assert torch.equal(got[head], plain[head])
+
+
 def test_tcnn_training_step_through_render_rays():
     """render_rays with hash-grid models under autograd: gradients reach the table and every MLP of both models and
     agree with torch.autograd through the restated field + compositing on the same sample positions."""

@@ -106,7 +106,7 @@ def tcnn_field_with_normal(w, x6, cfg):
     return sigma, rgb, pn, m, l2n(-grad[:, :3])
 
 
-def tcnn_field(w, x6, cfg):
+def tcnn_field(w, x6, cfg, detach_normal=False, detach_mirror=None):
     """MirrorNeRFTcnn.forward (models/mirror_nerf_tcnn.py:220-259) with torch ops: the hash-grid cells and interpolation
     weights follow the oracle (`hashgrid_encode` / `_grid_index`), the table look-up is a differentiable gather.
     w: dict of torch tensors (state_dict names), x6 (B,6) = [xyz, raw direction].  Returns sigma (B), rgb, pred_normal,
@@ -144,7 +144,10 @@ def tcnn_field(w, x6, cfg):
     enc = torch.cat(feats, -1)
     h = torch.relu(enc @ w["sigma_net.0.weight"].T) @ w["sigma_net.1.weight"].T
     sigma, geo = h[:, 0], h[:, 1:]
-    pn = l2n(torch.relu(geo @ w["normal_net.0.weight"].T) @ w["normal_net.1.weight"].T)
+    # the --detach_density_* options (models/mirror_nerf_tcnn.py:186-215): detach_mirror = True (all samples) or a (B,) bool
+    # tensor of the samples whose mirror head sees geo_feat.detach()
+    geo_n = geo.detach() if detach_normal else geo
+    pn = l2n(torch.relu(geo_n @ w["normal_net.0.weight"].T) @ w["normal_net.1.weight"].T)
     X, Y, Z = d[:, 0], d[:, 1], d[:, 2]
     xy, xz, yz, x2, y2, z2 = X * Y, X * Z, Y * Z, X * X, Y * Y, Z * Z
     sh = torch.stack([
@@ -157,6 +160,12 @@ def tcnn_field(w, x6, cfg):
     hc = torch.relu(torch.cat([sh, geo], -1) @ w["color_net.0.weight"].T)
     hc = torch.relu(hc @ w["color_net.1.weight"].T)
     rgb = torch.sigmoid(hc @ w["color_net.2.weight"].T)
-    hm = torch.nn.functional.leaky_relu(geo @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
+    if detach_mirror is None:
+        geo_m = geo
+    elif detach_mirror is True:
+        geo_m = geo.detach()
+    else:
+        geo_m = torch.where(detach_mirror[:, None], geo.detach(), geo)
+    hm = torch.nn.functional.leaky_relu(geo_m @ w["is_mirror_net.0.weight"].T + w["is_mirror_net.0.bias"], 0.01)
     m = torch.sigmoid(hm @ w["is_mirror_net.2.weight"].T + w["is_mirror_net.2.bias"])[:, 0]
     return sigma, rgb, pn, m
