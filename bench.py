@@ -152,6 +152,23 @@ def hash_grid_leg(dev, rays):
     # the dominant kernel of this variant is gather-bound: 16 levels x 8 corners x 8 B (float2) = 1 KiB of table reads per
     # sample, from a 53 MB table (Infinity-Cache resident: the HBM peak is the contract's yardstick, not the binding limit)
     gbs = sum(B for B, _ in full) * 1024 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
+    # the binding limit: random gathers out of the Infinity Cache, measured on this very table (mnrf_bench_gather)
+    from mirror_nerf_amd import _lib
+    table = models["fine"].encoder.embeddings.detach()
+    sink = torch.zeros(4, device=dev)
+    ceil = {}
+    for nbytes in (8, 4):
+        n_thr, iters = 256 * 4096, 256
+        _lib.check(_lib.lib().mnrf_bench_gather(_lib.ptr(table), table.numel() * 4, nbytes, n_thr, iters, _lib.ptr(sink), _lib.stream()), "gather")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            _lib.check(_lib.lib().mnrf_bench_gather(_lib.ptr(table), table.numel() * 4, nbytes, n_thr, iters, _lib.ptr(sink), _lib.stream()), "gather")
+        e1.record()
+        torch.cuda.synchronize()
+        ceil[nbytes] = 3 * n_thr * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9       # G gathers / s
+    gathers_per_s = sum(B for B, _ in full) * 128 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
     opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4)
     target = torch.rand(1024, 3, device=dev)
 
@@ -174,6 +191,12 @@ def hash_grid_leg(dev, rays):
     n = rays.shape[0]
     return {"rays_per_s": n / dt_f, "samples_per_s": n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": 1024 / dt_t,
+            "gather_roofline": {"bound": "random 8-byte gathers out of the Infinity Cache (measured ceiling, mnrf_bench_gather on the same "
+                                         "53 MB table: independent loads, 1 M threads x 256)", "achieved": gathers_per_s,
+                                "peak": ceil[8], "unit": "G gathers/s", "frac": gathers_per_s / ceil[8] if ceil[8] else None,
+                                "ceiling_4_byte_gathers": ceil[4],
+                                "note": "the field kernel issues 128 float2 gathers per sample (16 levels x 8 corners); `frac` says how close "
+                                        "to the chip's random-gather rate it runs -- the yardstick that matters, not HBM bytes"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
                          "kernel": "mf::tcnn_mfma_kernel<false,false> (full evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024,

@@ -226,6 +226,12 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
 
+/* Measurement aid for the hash-grid field: the rate of independent random gathers of 8 B (a float2 table entry) or 4 B (what
+ * an fp16 table would fetch) from a table of `table_bytes` -- the ceiling that bounds that field's kernels once the table is
+ * Infinity-Cache resident (bench.py `hash_grid_variant.roofline`).  n_threads (multiple of 256) threads x iters gathers. */
+int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gather, int64_t n_threads, int iters, float* out,
+                      void* stream);
+
 /* ---- ray-fused fine pass (eval, per-ray maps only; round 3) ------------------------------------------------------------
  * mnrf_field_forward (all four heads, split arithmetic) + mnrf_composite in ONE launch for rays of exactly
  * mnrf_fused_samples_per_ray() (= 192 = 64 coarse + 128 importance) samples: a workgroup evaluates one ray, keeps the head

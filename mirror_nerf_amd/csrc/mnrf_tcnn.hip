@@ -1581,3 +1581,47 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     return mnrf_check_launch("mnrf_tcnn_backward");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------- gather ceiling
+// What bounds the hash-grid field is not HBM bandwidth (the 53 MB table lives in the 256 MB Infinity Cache) but the RATE of
+// random small gathers.  This micro-benchmark measures that ceiling on the very table: every thread issues `iters`
+// independent loads of `bytes` (8 = one float2 entry, 4 = what an fp16 table would fetch) at pseudo-random entries and
+// folds them into a checksum.  bench.py prices the field kernel's 128 gathers per sample against it.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bench_kernel(const T* __restrict__ table, unsigned n_entries, int iters, float* __restrict__ out) {
+    unsigned state = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it += 8) {
+        unsigned idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            state = state * 1664525u + 1013904223u;
+            idx[u] = (unsigned)(((unsigned long long)(state >> 4) * n_entries) >> 28);      // uniform in [0, n_entries)
+        }
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = table[idx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if constexpr (sizeof(T) == 8) acc += v[u].x + v[u].y;
+            else acc += __builtin_bit_cast(float, v[u]) * 1e-30f;
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;      // keep the loads alive
+}
+
+extern "C" int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gather, int64_t n_threads, int iters,
+                                 float* out, void* stream) {
+    if (!table || !out || table_bytes < 64 || n_threads < 256 || iters < 8 || (bytes_per_gather != 4 && bytes_per_gather != 8))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_gather: bad argument");
+    const unsigned blocks = (unsigned)(n_threads / 256);
+    iters = iters / 8 * 8;
+    if (bytes_per_gather == 8)
+        hipLaunchKernelGGL(gather_bench_kernel<float2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float2*)table,
+                           (unsigned)(table_bytes / 8), iters, out);
+    else
+        hipLaunchKernelGGL(gather_bench_kernel<unsigned>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)table,
+                           (unsigned)(table_bytes / 4), iters, out);
+    return mnrf_check_launch("mnrf_bench_gather");
+}
