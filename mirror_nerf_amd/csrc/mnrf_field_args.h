@@ -41,6 +41,13 @@ struct FieldArgs {
     // tuning: the four head outputs go to LDS instead of HBM and the workgroup composites its ray itself (mnrf_composite.inc,
     // the body of composite_kernel: identical maps); sigma / rgb / pred_normal / is_mirror above are then unused.
     int fuse;                      // 1: fused compositing on
+    // dynamic tile queue (48-samples-per-wave kernels, round 3): one resident workgroup per CU takes 192-sample tiles from a
+    // global counter instead of one workgroup per tile -- the hardware deals workgroup ids to the 8 XCDs round robin, so a
+    // static grid ends when the SLOWEST XCD has worked off its eighth (the XCDs of one package run up to 9 % apart under
+    // this kernel's power draw); with the queue a faster XCD simply takes more tiles.
+    int* tile_queue;               // {next, done}, both zero between launches (the last workgroup out resets them); null: static grid
+    int n_tiles;                   // ceil(B / 192)
+    int resident;                  // workgroups launched (<= n_tiles): what the chip holds at once
     int white_back;
     float* f_weights;              // (n_rays, spr) or null
     float* f_opacity; float* f_rgb_map; float* f_depth; float* f_mirror_mask; float* f_surf_normal; float* f_x_surface;

@@ -36,7 +36,45 @@ bool split48_enabled() {
     return v;
 }
 
-int launch_split48(const FieldArgs& A, bool sigma_only, hipStream_t s) {
+// Dynamic tile queue of the h3 kernels (FieldArgs::tile_queue): a ring of {next, done} pairs per device, zeroed once -- every
+// launch leaves its pair at zero again (the last workgroup out resets it), so a pair can be handed out again as soon as the
+// launch that used it has finished; launches on one stream are ordered anyway, and 512 launches are never in flight at once.
+// MNRF_TILE_QUEUE=0 (read once) keeps the static one-workgroup-per-tile grid.
+namespace {
+constexpr int TQ_SLOTS = 512, TQ_DEVICES = 16;
+struct TileQueues { int* base = nullptr; int resident = 0; unsigned next = 0; };
+TileQueues g_tq[TQ_DEVICES];
+bool tile_queue_enabled() {
+    static const bool v = [] { const char* e = getenv("MNRF_TILE_QUEUE"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+}  // namespace
+
+static bool tile_queue_slot(FieldArgs& A) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_DEVICES) return false;
+    TileQueues& q = g_tq[dev];
+    if (!q.base) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        int* p = nullptr;
+        if (hipMalloc(&p, TQ_SLOTS * 2 * sizeof(int)) != hipSuccess) return false;
+        if (hipMemset(p, 0, TQ_SLOTS * 2 * sizeof(int)) != hipSuccess) return false;      // (synchronous, once per device)
+        q.resident = prop.multiProcessorCount;      // 150 KB of LDS and 512 registers per lane: one workgroup per CU
+        q.base = p;
+    }
+    const long long tiles = (A.B + h3::WG_SAMPLES - 1) / h3::WG_SAMPLES;
+    if (tiles <= q.resident || tiles > 0x7fffffff) return false;      // everything is resident at once: nothing to deal
+    A.tile_queue = q.base + 2 * (__atomic_fetch_add(&q.next, 1u, __ATOMIC_RELAXED) % TQ_SLOTS);
+    A.n_tiles = (int)tiles;
+    A.resident = q.resident;
+    return true;
+}
+
+int launch_split48(const FieldArgs& A0, bool sigma_only, hipStream_t s) {
+    FieldArgs A = A0;
+    A.tile_queue = nullptr;
+    if (tile_queue_enabled()) (void)tile_queue_slot(A);
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);

@@ -421,6 +421,73 @@ def test_rows_route_of_the_weight_gradients_still_works():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("B,n_eval", [(200, 1), (4096 + 77, 2)])
+def test_planes_route_agrees_with_rows_route(B, n_eval, precision):
+    """Through the C ABI on the same samples and seeds (eight orders of magnitude apart): mnrf_field_forward_train with
+    MNRF_TRAIN_PLANES gives bit-identical outputs and ReLU masks, mnrf_field_backward_planes bit-identical dL/dxyz and
+    dL/d(view encoding), and mnrf_dw_planes -- one launch over n_eval evaluations -- the 32 parameter gradients of
+    mnrf_field_backward to 1e-5 of each tensor's largest entry (measured 5e-6: hi/lo f16 operands with one power-of-two
+    scale per evaluation against fp32 rows split into bf16 x 3)."""
+    import ctypes
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import _lib
+    from mirror_nerf_amd.weights import PARAM_NAMES, PARAM_SHAPES, packed_of
+    if precision != "split":
+        pytest.skip("the plane route belongs to the split arithmetic")
+    L, p = _lib.lib(), _lib.ptr
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=DEV)  # noqa: E731
+    torch.manual_seed(B)
+    model = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True).to(DEV)
+    with torch.no_grad():
+        model.sigma.weight.mul_(20.0)
+    packed = packed_of(model)
+    xyz = (torch.rand(B, 3, device=DEV) * 6 - 3).contiguous()
+    de = M.Embedding(4)(torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=1))
+    outs, saves = {}, {}
+    for mode in ("rows", "planes"):
+        o = (f(B), f(B, 3), f(B, 3), f(B), f(B, 3))
+        sx = f(L.mnrf_train_save_floats(B)) if mode == "rows" else \
+            torch.zeros(L.mnrf_train_planes_bytes(B), dtype=torch.uint8, device=DEV)
+        sm = torch.zeros(L.mnrf_train_mask_words(B), dtype=torch.int64, device=DEV)
+        si, sj = f(B), f(B)
+        flags = _lib.MNRF_SPLIT_F16 | (_lib.MNRF_TRAIN_PLANES if mode == "planes" else 0)
+        _lib.check(L.mnrf_field_forward_train(p(packed), B, p(xyz), 3, None, None, 1, p(de), 27, *[p(t) for t in o], p(sx), p(sm),
+                                              p(si), p(sj), flags, _lib.stream()), "forward " + mode)
+        outs[mode], saves[mode] = o, (sx, sm, si, sj)
+    for a, b in zip(outs["rows"], outs["planes"]):
+        assert torch.equal(a, b)
+    assert torch.equal(saves["rows"][1], saves["planes"][1])
+    scale = 10.0 ** (torch.rand(B, device=DEV) * 8 - 8)
+    g_sigma = torch.randn(B, device=DEV) * scale
+    g_rgb, g_pn, g_m = (torch.randn(B, 3, device=DEV) * scale[:, None], torch.randn(B, 3, device=DEV) * scale[:, None],
+                        torch.randn(B, device=DEV) * scale)
+    _, rgb, pn, mir, _ = outs["rows"]
+    ws = f(L.mnrf_train_workspace_floats(B))
+    d_r = [f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+    dx_r, dd_r = f(B, 3), f(B, 32)
+    _lib.check(L.mnrf_field_backward(p(packed), B, p(xyz), 3, None, None, 1, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
+                                     p(mir), p(saves["rows"][0]), p(saves["rows"][1]), p(saves["rows"][2]), p(ws),
+                                     (ctypes.c_void_p * 32)(*[t.data_ptr() for t in d_r]), p(dx_r), p(dd_r), None,
+                                     _lib.MNRF_SPLIT_F16, _lib.stream()), "backward rows")
+    dy = torch.zeros(L.mnrf_train_dy_planes_bytes(B), dtype=torch.uint8, device=DEV)
+    seedmax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dx_p, dd_p = f(B, 3), f(B, 32)
+    _lib.check(L.mnrf_field_backward_planes(p(packed), B, p(xyz), 3, None, None, 1, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb),
+                                            p(pn), p(mir), p(saves["planes"][1]), p(saves["planes"][2]), p(dy), p(seedmax),
+                                            p(dx_p), p(dd_p), None, 0, _lib.stream()), "backward planes")
+    assert torch.equal(dx_r, dx_p) and torch.equal(dd_r, dd_p)
+    d_p = [f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+    bs = (ctypes.c_int64 * n_eval)(*[B] * n_eval)
+    wsp = f(L.mnrf_dw_planes_workspace_floats(n_eval, bs))
+    _lib.check(L.mnrf_dw_planes(n_eval, (ctypes.c_void_p * n_eval)(*[saves["planes"][0].data_ptr()] * n_eval),
+                                (ctypes.c_void_p * n_eval)(*[dy.data_ptr()] * n_eval), bs,
+                                (ctypes.c_void_p * n_eval)(*[seedmax.data_ptr()] * n_eval), p(wsp),
+                                (ctypes.c_void_p * 32)(*[t.data_ptr() for t in d_p]), 0, _lib.stream()), "dw planes")
+    torch.cuda.synchronize()
+    for n, a, b in zip(PARAM_NAMES, d_p, d_r):
+        assert _rel(a, n_eval * b) <= 1e-5, n
+
+
 def _two_evals(model, x1, x2, d):
     """Two evaluations of one module in one graph (the primary / reflected pattern of a training step)."""
     from mirror_nerf_amd.autograd import FieldFn

@@ -678,6 +678,50 @@ def test_split_agrees_with_fp32_chain_full_chunk(precision):
         assert err <= tol * scale, f"{k}: split vs fp32 {err:.3e} > {tol * scale:.1e}"
 
 
+def test_dynamic_tile_queue_of_the_48_sample_kernels(precision):
+    """Round 3: launches of the 48-samples-per-wave kernels with more tiles than CUs run one resident workgroup per CU that
+    takes its tiles from a global counter (FieldArgs::tile_queue; the last workgroup out resets the counter pair).  A tile
+    handed out twice, skipped, or a counter left dirty for the next launch would show as samples that differ from the
+    32-samples-per-wave kernels (static grid; launches that ask for geo_feat take those): ragged sizes around multiples of
+    192 x 256, the same launch repeated five times (the ring hands every launch another counter pair; all must be clean), two
+    launches in flight on two streams, sigma-only and full."""
+    if precision != "split":
+        pytest.skip("the queue belongs to the split-f16 kernels")
+    from mirror_nerf_amd import mirror_nerf as MN
+    from tests.golden import weights as GW
+    m = _module(GW.apply_tweaks(GW.make_state_dict(0, 2)[1], GW.STRADDLE))
+    e = _emb()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for B in (192 * cus + 1, 192 * cus * 3 - 7, 192 * (2 * cus + 5)):
+        torch.manual_seed(B)
+        xyz = (torch.rand(B, 3, device=DEV) * 6 - 3).contiguous()
+        de = e["dir"](torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=1))
+        want = MN.field_forward(m, B, xyz=xyz, dir_emb=de, dir_stride=27, want_geo=True)      # 32-sample kernels, static grid
+        KEYS = ("sigma", "rgb", "is_mirror", "pred_normal")
+
+        def same(got, what):
+            for k in KEYS if "rgb" in got else ("sigma",):
+                scale = max(1.0, float(want[k].abs().max()))
+                assert float((got[k] - want[k]).abs().max()) <= 1e-6 * scale, (B, what, k)
+        first = MN.field_forward(m, B, xyz=xyz, dir_emb=de, dir_stride=27)
+        same(first, "first launch")
+        for rep in range(5):
+            got = MN.field_forward(m, B, xyz=xyz, dir_emb=de, dir_stride=27)
+            for k in KEYS:
+                assert torch.equal(got[k], first[k]), (B, rep, k)
+        same(MN.field_forward(m, B, xyz=xyz, sigma_only=True), "sigma-only")
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        s1.wait_stream(torch.cuda.current_stream())
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s1):
+            a = MN.field_forward(m, B, xyz=xyz, dir_emb=de, dir_stride=27)
+        with torch.cuda.stream(s2):
+            b = MN.field_forward(m, B, xyz=xyz, dir_emb=de, dir_stride=27)
+        torch.cuda.synchronize()
+        for k in KEYS:
+            assert torch.equal(a[k], first[k]) and torch.equal(b[k], first[k]), (B, "two streams", k)
+
+
 def test_split_kernel_random_shapes_against_fp32(precision):
     """Race / schedule check of the split kernels (static LDS-DMA schedule, counted waits, in-place operand overwrite):
     eight random sizes and sample counts, forward-only and with the density-gradient pass, against the bit-exact
