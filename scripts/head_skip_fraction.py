@@ -27,14 +27,27 @@ def module(sd):
 
 def measure(models, rays, tag):
     out = {}
-    tot = zero = neg = 0
+    tot = zero = 0
+    g16 = g48 = g192 = n16 = n48 = n192 = 0
     for c in range(0, rays.shape[0], 32768):
         with torch.no_grad():
             r = M.render_rays(models, emb, rays[c:c + 32768].contiguous(), 64, False, 0, 0, 128, test_time=True, compute_normal=False)
         w = r["weights_fine"]
         tot += w.numel()
-        zero += int((w == 0).sum().item())
-    out = {"rays": int(rays.shape[0]), "fine_samples": tot, "weight_exactly_zero": zero, "fraction": zero / tot}
+        z = w == 0
+        zero += int(z.sum().item())
+        # the granularities a kernel could skip at: 16 consecutive samples of a ray (one MFMA column group), 48 (one wave of
+        # the 48-samples-per-wave kernel), the whole 192-sample ray (one workgroup of the ray-fused kernel)
+        for width in (16, 48, 192):
+            a = z.view(z.shape[0], -1, width).all(dim=2)
+            if width == 16:
+                g16 += int(a.sum().item()); n16 += a.numel()
+            elif width == 48:
+                g48 += int(a.sum().item()); n48 += a.numel()
+            else:
+                g192 += int(a.sum().item()); n192 += a.numel()
+    out = {"rays": int(rays.shape[0]), "fine_samples": tot, "weight_exactly_zero": zero, "fraction": zero / tot,
+           "groups_of_16_all_zero": g16 / n16, "waves_of_48_all_zero": g48 / n48, "rays_of_192_all_zero": g192 / n192}
     print(tag, json.dumps(out))
     return out
 
