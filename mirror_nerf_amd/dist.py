@@ -122,27 +122,99 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
+def _field_layout(module):
+    """{qualified parameter name: (offset, numel)} of the flat gradient buffer of a FIELD module (autograd._Pending: the 32
+    parameters of weights.PARAM_NAMES in state_dict order, absent optional heads included as zero slots), total size --
+    or (None, 0) when `module` is something else (e.g. the hash-grid model)."""
+    from .weights import PARAM_NAMES, PARAM_SHAPES, param_refs
+    names = {full for _, _, full in param_refs(module)}
+    if not names or not names <= set(PARAM_NAMES):
+        return None, 0
+    off, lay = 0, {}
+    for n in PARAM_NAMES:
+        k = int(torch.Size(PARAM_SHAPES[n]).numel())
+        lay[n] = (off, k)
+        off += k
+    return lay, off
+
+
 def _flat_bucket(module):
-    """The flat gradient buffer of `module` (autograd._Pending: 32 field parameters in state_dict order) IF every parameter's
-    .grad is still the view of it that FieldFn handed to autograd -- then the all-reduce runs on that one tensor in place and
-    nobody copies.  None when autograd had to copy (another consumer of a parameter, retain_graph, ...)."""
+    """The flat gradient buffer of `module` (autograd._Pending) IF every parameter's .grad is still the view of it that
+    FieldFn handed to autograd -- then the all-reduce runs on that one tensor in place and nobody copies.  None when
+    autograd had to copy (another consumer of a parameter, retain_graph, ...) or a parameter has no gradient."""
     flat = module.__dict__.get("_mnrf_flat_grad")
     if flat is None:
         return None
-    from .weights import PARAM_NAMES, PARAM_SHAPES, param_refs
-    off, offs = 0, {}
-    for n in PARAM_NAMES:
-        offs[n] = off
-        off += int(torch.Size(PARAM_SHAPES[n]).numel())
+    lay, total = _field_layout(module)
+    if lay is None or flat.numel() != total:
+        return None
+    from .weights import param_refs
     base, item = flat.data_ptr(), flat.element_size()
     for sub, pname, full in param_refs(module):
         q = sub._parameters[pname]
         if q is None or not q.requires_grad:
             continue
         g = q.grad
-        if g is None or full not in offs or not g.is_contiguous() or g.data_ptr() != base + offs[full] * item:
+        if g is None or not g.is_contiguous() or g.data_ptr() != base + lay[full][0] * item:
             return None
     return flat
+
+
+def _module_message(module):
+    """-> (flat tensor to all-reduce, copied?).  EVERY rank sends one message of the same size and element order per module
+    and step, whatever happened to its .grads locally: the in-place bucket when they still alias it, else a flat copy in
+    the same layout (zeros where this rank has no gradient) -- ranks may take different branches, the collective matches."""
+    flat = _flat_bucket(module)
+    if flat is not None:
+        return flat, False
+    from .weights import param_refs, params_of
+    lay, total = _field_layout(module)
+    ps = [q for q in params_of(module) if q is not None and q.requires_grad]
+    ref = next((q.grad for q in ps if q.grad is not None), ps[0] if ps else None)
+    if ref is None:
+        return None, False
+    if lay is None:      # not a field module: parameters() order
+        total = sum(q.numel() for q in ps)
+        flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for q in ps:
+            if q.grad is not None:
+                flat[off:off + q.numel()].copy_(q.grad.reshape(-1))
+            off += q.numel()
+        return flat, True
+    flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+    for sub, pname, full in param_refs(module):
+        q = sub._parameters[pname]
+        if q is not None and q.requires_grad and q.grad is not None:
+            o, k = lay[full]
+            flat[o:o + k].copy_(q.grad.reshape(-1))
+    return flat, True
+
+
+def _scatter_message(module, flat):
+    """Reduced flat copy -> the module's .grads (a parameter without a local gradient receives the other ranks' mean)."""
+    from .weights import param_refs, params_of
+    lay, _ = _field_layout(module)
+    if lay is None:
+        off = 0
+        for q in (q for q in params_of(module) if q is not None and q.requires_grad):
+            v = flat[off:off + q.numel()].view_as(q)
+            q.grad = v.clone() if q.grad is None else q.grad.copy_(v)
+            off += q.numel()
+        return
+    for sub, pname, full in param_refs(module):
+        q = sub._parameters[pname]
+        if q is not None and q.requires_grad:
+            o, k = lay[full]
+            v = flat[o:o + k].view_as(q)
+            q.grad = v.clone() if q.grad is None else q.grad.copy_(v)
+
+
+# The fixed order in which the module buckets go out.  Collectives must be issued in the SAME order on every rank; readiness
+# is not the same on every rank (a rank whose batch holds no mirror pixel builds a different graph; a parameter may receive
+# no gradient at all; autograd may have copied a .grad on one rank only), so the order is the order of attach_overlap() --
+# code, not data -- and a bucket goes out from inside the backward pass only when all buckets before it have gone out.
+_SEQ = []
 
 
 class _Overlap:
@@ -155,44 +227,67 @@ class _Overlap:
         self.module, self.average = module, average
         self.params = [q for q in params_of(module) if q.requires_grad]
         self.left = len(self.params)
-        self.work = None
+        self.ready = False
+        self.work = None          # (flat, handle, copied?) once issued in this step
         self.handles = [q.register_post_accumulate_grad_hook(self._hook) for q in self.params]
 
     def _hook(self, _param):
         self.left -= 1
         if self.left == 0:
-            self.left = len(self.params)
-            flat = _flat_bucket(self.module)
-            if flat is not None and dist.is_initialized():
-                self.work = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            self.ready = True
+            _issue_ready_prefix()
+
+    def issue(self):
+        if self.work is None and dist.is_initialized():
+            flat, copied = _module_message(self.module)
+            if flat is not None:
+                self.work = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), copied)
 
     def finish(self):
-        """-> True when this module's gradients have been reduced by the overlapped all-reduce."""
+        """Wait for this module's all-reduce (issued by now) and deliver it; resets the per-step state."""
         w, self.work = self.work, None
-        self.left = len(self.params)
+        self.left, self.ready = len(self.params), False
         if w is None:
             return False
-        flat, work = w
+        flat, work, copied = w
         work.wait()
         if self.average:
             flat /= dist.get_world_size()
+        if copied:
+            _scatter_message(self.module, flat)
         return True
 
     def remove(self):
         for h in self.handles:
             h.remove()
+        if self in _SEQ:
+            _SEQ.remove(self)
+
+
+def _issue_ready_prefix():
+    for ov in _SEQ:
+        if ov.work is not None:
+            continue
+        if not ov.ready:
+            break
+        ov.issue()
 
 
 def attach_overlap(modules, average=True):
-    """Install the overlapped bucket all-reduce on field modules (MirrorNeRF).  Idempotent; no-op without a process group."""
+    """Install the overlapped bucket all-reduce on field modules (MirrorNeRF).  Idempotent; no-op without a process group.
+    Pass the modules in FORWARD order (coarse, fine): their buckets go out in the reverse -- the order in which a backward
+    pass completes them -- and that order must be the same on every rank (see _SEQ)."""
     out = []
+    fresh = []
     for m in modules:
         ov = m.__dict__.get("_mnrf_overlap")
         if ov is None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced()):
             ov = _Overlap(m, average)
             m.__dict__["_mnrf_overlap"] = ov
+            fresh.append(ov)
         if ov is not None:
             out.append(ov)
+    _SEQ.extend(reversed(fresh))
     return out
 
 
@@ -200,28 +295,35 @@ def allreduce_gradients(params, average=True, modules=()):
     """Sum (average) the gradients over the ranks.  Field modules passed in `modules` are reduced through their flat
     gradient buffer -- ONE tensor per module whose views are the .grads (autograd._Pending): no torch.cat, no copy back; the
     all-reduce of a module with attach_overlap() was already issued during the backward pass and is only waited for here.
-    Whatever is left (parameters outside those modules, or a module whose .grads autograd had to copy) goes the generic
-    way: one flat copy, one all-reduce, copied back.  RCCL over xGMI: direct reduce-scatter + all-gather inside RCCL uses
-    all 7 links; a 2.65 MB message is latency-, not bandwidth-bound."""
+    Every rank sends exactly one message per module, of one size, in one order (_module_message, _SEQ), so ranks whose
+    local state differs still match.  Parameters outside `modules` go the generic way: one flat copy, one all-reduce,
+    copied back.  RCCL over xGMI: direct reduce-scatter + all-gather inside RCCL uses all 7 links; a 2.65 MB message is
+    latency-, not bandwidth-bound."""
     rank, ws = world()
     if ws == 1 and not forced():
         return
+    from .weights import params_of
     done = set()
-    pending = []
-    for m in modules:
-        ov = m.__dict__.get("_mnrf_overlap")
-        reduced = ov.finish() if ov is not None else False
-        flat = _flat_bucket(m)
-        if flat is None:
-            continue
-        if not reduced:
-            pending.append((flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
-        from .weights import params_of
-        done.update(id(q) for q in params_of(m))
-    for flat, work in pending:
+    with_ov = [m.__dict__["_mnrf_overlap"] for m in modules if m.__dict__.get("_mnrf_overlap") is not None]
+    for ov in _SEQ:                      # whatever the backward pass did not send goes out now, in the fixed order
+        if ov in with_ov:
+            ov.issue()
+    plain = []
+    for m in modules:                    # modules without hooks: same uniform message, issued in the order given
+        if m.__dict__.get("_mnrf_overlap") is None:
+            flat, copied = _module_message(m)
+            if flat is not None:
+                plain.append((m, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), copied))
+    for ov in _SEQ:
+        if ov in with_ov and ov.finish():
+            done.update(id(q) for q in params_of(ov.module))
+    for m, flat, work, copied in plain:
         work.wait()
         if average:
             flat /= ws
+        if copied:
+            _scatter_message(m, flat)
+        done.update(id(q) for q in params_of(m))
     grads = [p.grad for p in params if p.grad is not None and id(p) not in done]
     if not grads:
         return

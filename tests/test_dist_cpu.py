@@ -131,6 +131,17 @@ def _bucket_worker(rank, ws, port, q):
             alias = all(D._flat_bucket(m) is f for m, f in zip(mods, flats))
             vals = [float(m.sigma.weight.grad[0, 0]) for m in mods] + [float(mods[1].xyz_encoding_5[0].weight.grad[3, 7])]
             res.append((started, alias, vals, extra.grad.tolist()))
+        # ranks that DIVERGE: on rank 1 the second module does not take part in the loss (its hooks never fire, its .grads
+        # stay None), on rank 0 it does and its bucket goes out from inside the backward pass.  Every rank must still send
+        # one message per module, of one size, in one order -- rank 1 sends zeros for the module it has no gradient of
+        for m in mods:
+            for p_ in m.parameters():
+                p_.grad = None
+        take = mods if rank == 0 else mods[:1]
+        loss = sum(_FakeFieldFn.apply(m, float(100 * (i + 1) + rank), *params_of(m)) for i, m in enumerate(take))
+        loss.backward()
+        D.allreduce_gradients([q_ for m in mods for q_ in params_of(m)], modules=mods)
+        res.append([float(m.sigma.weight.grad[0, 0]) for m in mods])
         # a module whose .grads do not alias its flat buffer (autograd copied): generic path, still correct
         m = mods[0]
         for p_ in m.parameters():
@@ -162,4 +173,5 @@ def test_flat_gradient_buckets_and_overlapped_allreduce():
             # mean over ranks of (10 i + rank + 1 + step)
             assert vals == [1.5 + step, 11.5 + step, 11.5 + step], vals
             assert eg == [1.5] * 3
-        assert res[2] == 0.5
+        assert res[2] == [100.5, 100.0], res[2]        # mean(100, 101); mean(200 on rank 0, nothing on rank 1)
+        assert res[3] == 0.5
