@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""How far is dwp_gemm_kernel from what the memory system delivers to ANY streaming reader of the same bytes?  Times (HIP events)
+(a) torch's sum over a float32 view of an X-plane buffer of the training step's size, (b) a device-to-device copy of it (read +
+write), (c) mnrf_dw_planes over the same sample count (two evaluations: 196 608 + 49 152 samples, the training step's shape)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mirror_nerf_amd import _lib  # noqa: E402
+from mirror_nerf_amd.weights import PARAM_NAMES, PARAM_SHAPES  # noqa: E402
+
+dev = torch.device("cuda", 0)
+L, p = _lib.lib(), _lib.ptr
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+Bs = [196608, 49152]
+xs = [torch.randint(0, 255, (L.mnrf_train_planes_bytes(B),), dtype=torch.uint8, device=dev) for B in Bs]
+ys = [torch.randint(0, 255, (L.mnrf_train_dy_planes_bytes(B),), dtype=torch.uint8, device=dev) for B in Bs]
+total = sum(t.numel() for t in xs + ys)
+big = xs[0].view(torch.float32)
+t = timed(lambda: big.sum())
+print(f"torch sum over {big.numel() * 4 / 1e9:.2f} GB: {big.numel() * 4 / t / 1e12:.2f} TB/s")
+dst = torch.empty_like(big)
+t = timed(lambda: dst.copy_(big))
+print(f"torch copy of the same (read + write): {2 * big.numel() * 4 / t / 1e12:.2f} TB/s")
+n = len(Bs)
+bs = (ctypes.c_int64 * n)(*Bs)
+seed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in Bs]
+ws = torch.empty(L.mnrf_dw_planes_workspace_floats(n, bs), dtype=torch.float32, device=dev)
+d_p = [torch.empty(*PARAM_SHAPES[k], dtype=torch.float32, device=dev) for k in PARAM_NAMES]
+arr = (ctypes.c_void_p * 32)(*[q.data_ptr() for q in d_p])
+X = (ctypes.c_void_p * n)(*[q.data_ptr() for q in xs])
+Y = (ctypes.c_void_p * n)(*[q.data_ptr() for q in ys])
+S = (ctypes.c_void_p * n)(*[q.data_ptr() for q in seed])
+t = timed(lambda: _lib.check(L.mnrf_dw_planes(n, X, Y, bs, S, p(ws), arr, 0, _lib.stream()), "dw"))
+sb = sum((B + 127) // 128 * 4 for B in Bs)
+print(f"mnrf_dw_planes: {t * 1e3:.3f} ms; unique plane bytes {total / 1e9:.2f} GB = {total / t / 1e12:.2f} TB/s; "
+      f"bytes the jobs read {sb * 812 * 1024 / 1e9:.2f} GB = {sb * 812 * 1024 / t / 1e12:.2f} TB/s")
