@@ -60,14 +60,20 @@ if __name__ == "__main__":
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--libs", default="", help="comma list of libraries (MNRF_LIB; 'default' = in-tree) to alternate INSTEAD of the queue setting")
     a = ap.parse_args()
     if a.child:
         child(a.seconds, a.fused)
         sys.exit(0)
+    variants = [("lib", l) for l in a.libs.split(",")] if a.libs else [("queue", "0"), ("queue", "1")]
     for r in range(a.rounds):
-        for q in ("0", "1"):
-            env = dict(os.environ, MNRF_TILE_QUEUE=q)
+        for kind, q in variants:
+            env = dict(os.environ)
+            if kind == "queue":
+                env["MNRF_TILE_QUEUE"] = q
+            elif q != "default":
+                env["MNRF_LIB"] = os.path.join(ROOT, q)
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--seconds", str(a.seconds)]
                                  + (["--fused"] if a.fused else []), env=env, capture_output=True, text=True, cwd=ROOT)
             lines = [l for l in out.stdout.splitlines() if l.startswith("AB ")]
-            print(lines[-1] if lines else f"queue={q}: child failed\n{out.stdout[-1500:]}{out.stderr[-1500:]}", flush=True)
+            print((f"{q:28s} " if kind == "lib" else "") + (lines[-1] if lines else f"{kind}={q}: child failed\n{out.stdout[-1500:]}{out.stderr[-1500:]}"), flush=True)
