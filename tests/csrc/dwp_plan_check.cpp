@@ -60,7 +60,7 @@ int main() {
     if (wsum != 812) { std::printf("weights sum %d\n", wsum); return 1; }
     std::srand(7);
     int cases = 0;
-    for (int it = 0; it < 4000; ++it) {
+    for (int it = 0; it < 1000; ++it) {
         DwpPlan p;
         p.n_eval = 1 + std::rand() % DWP_MAX_EVAL;
         for (int e = 0; e < DWP_MAX_EVAL; ++e) p.n_sb[e] = 0;
