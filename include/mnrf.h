@@ -12,7 +12,9 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every
- *     buffer (the library never allocates device memory);
+ *     buffer.  The library allocates device memory once: 4 KiB per device at the first launch of the
+ *     48-samples-per-wave field kernels (the counter pairs of their dynamic tile queue;
+ *     MNRF_TILE_QUEUE=0 in the environment keeps the static grid and allocates nothing);
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return value 0 = ok, negative = error (see mnrf_last_error()); nothing throws;
  *   - re-entrant; no global stream or global device state.

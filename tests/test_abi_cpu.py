@@ -106,6 +106,20 @@ def test_isa_invariants_of_the_built_field_kernels():
     assert "ISA check ok" in r.stdout
 
 
+def test_the_shipped_objects_were_built_with_the_default_flags():
+    """csrc/.cxxflags records the flags of the objects in the tree (every object depends on it): an experiment's -DMNRF_EXP_*
+    must never be what the default library was linked from, and the library must not be older than any of its objects."""
+    csrc = os.path.join(ROOT, "mirror_nerf_amd", "csrc")
+    flags = os.path.join(csrc, ".cxxflags")
+    if not os.path.exists(flags):
+        pytest.skip("library not built by this Makefile here")
+    assert "MNRF_EXP" not in open(flags).read()
+    lib = os.path.join(ROOT, "mirror_nerf_amd", "libmnrf_hip.so")
+    objs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".o")]
+    assert objs and all(os.path.getmtime(o) <= os.path.getmtime(lib) + 1.0 for o in objs)
+    assert all(os.path.getmtime(o) >= os.path.getmtime(flags) - 1.0 for o in objs)
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     """`--gpus N` must equal the launched world size (a mismatch used to run one process labelled n_gpus 1)."""
     import subprocess
