@@ -188,9 +188,24 @@ def hash_grid_leg(dev, rays):
         step()
     torch.cuda.synchronize()
     dt_t = (time.perf_counter() - t0) / 10
+    # the same step with the table gradient of the big hashed levels accumulated in half2 by packed atomics (tinycudann's
+    # gradient precision: models/mirror_nerf_tcnn.py:36-49 under train.py:586; module.table_grad_f16, off by default)
+    for m in models.values():
+        m.table_grad_f16 = True
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    dt_t16 = (time.perf_counter() - t0) / 10
+    for m in models.values():
+        m.table_grad_f16 = False
     n = rays.shape[0]
     return {"rays_per_s": n / dt_f, "samples_per_s": n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": 1024 / dt_t,
+            "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
             "gather_roofline": {"bound": "8-byte gathers served by the L2 (ceiling measured with mnrf_bench_gather on a 2 MiB window of the "
                                          "same table: independent loads, 1 M threads x 256)", "achieved": gathers_per_s,
                                 "peak": ceil["l2_resident_8B"], "unit": "G gathers/s",

@@ -48,6 +48,10 @@ extern "C" {
                                   hi/lo f16 pair (3 MFMAs per product block, fp32 accumulation; ~2^-20 relative per
                                   product instead of the bit-exact fp32 fmaf chain of the default) */
 
+#define MNRF_TCNN_GRAD_F16 16u  /* mnrf_tcnn_backward: the levels without private copies accumulate their table gradient scaled by 2^10 in
+                                  half2 with ONE packed atomic per entry (global_atomic_pk_add_f16) instead of two fp32 atomics --
+                                  tinycudann's gradient precision (models/mirror_nerf_tcnn.py:36-49 under train.py:586); the
+                                  workspace then has mnrf_tcnn_backward_workspace_floats2() floats */
 #define MNRF_TCNN_VALU 8u       /* mnrf_tcnn_forward: evaluate the small MLPs with fp32 FMAs on the VALU, one thread per sample
                                   (the first implementation; default: hi/lo f16 tiles on the matrix pipe, ~1e-6 of it) */
 
@@ -307,6 +311,7 @@ int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double 
  * normal = l2n(-d sigma/dx), i.e. what autograd.grad(sigma, x, create_graph=True) propagates in
  * models/mirror_nerf_tcnn.py:172-218 / utils/func.py:10-25 -- to d_table, d_weights and d_xyz. */
 int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host);
+int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags /* MNRF_TCNN_GRAD_F16 or 0 */);
 int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                        int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
@@ -316,7 +321,7 @@ int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double
                        const float* keep_mirror /* (B/spr) per ray [(B) with xyz] or null: 0 = the mirror head of this ray's samples
                                                    sees geo_feat.detach() (models/mirror_nerf_tcnn.py:200-215) */,
                        unsigned flags /* MNRF_CUT_NORMAL_HEAD / MNRF_CUT_MIRROR_HEAD: that head sees geo_feat.detach()
-                                         (mirror_nerf_tcnn.py:186-190, 196-199) */,
+                                         (mirror_nerf_tcnn.py:186-190, 196-199); MNRF_TCNN_GRAD_F16: see there */,
                        void* stream);
 
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */

@@ -31,6 +31,7 @@ MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128
 MNRF_TRAIN_PLANES = 256
+MNRF_TCNN_GRAD_F16 = 16
 MNRF_DETACH_W_MASK = 1
 MNRF_DETACH_W_NORMAL = 2
 N_PARAMS = 32
@@ -76,6 +77,7 @@ SIGNATURES = {
     "mnrf_tcnn_backward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _i64,
                                   _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 11 + [_u32, _str]),
     "mnrf_tcnn_backward_workspace_floats": (_i64, [ctypes.POINTER(ctypes.c_int64)]),
+    "mnrf_tcnn_backward_workspace_floats2": (_i64, [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint]),
     "mnrf_sample_fine": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _str]),
     "mnrf_threshold_mask": (_int, [_c_f, _i64, _c_i, _str]),
     "mnrf_reflect_compact": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i,

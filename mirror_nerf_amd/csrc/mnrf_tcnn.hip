@@ -12,6 +12,7 @@
 // One thread per sample; the 11 k weights are wave-uniform and arrive as scalar loads through the
 // constant address space (mlp_layer below); the table (53 MB fp32 at bound 6) lives in the 256 MB Infinity Cache.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -771,6 +772,12 @@ struct TcnnBwdArgs {
     // still gets its own weight gradients but adds nothing to dL/d geo_feat
     unsigned cut;                                // MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD
     const float* keep_mirror;                    // per ray (per sample with xyz) or null: 0 = cut the mirror head for this ray's samples
+    // MNRF_TCNN_GRAD_F16 (round 3; what tinycudann does, models/mirror_nerf_tcnn.py:36-49 under train.py:586 precision=16): the
+    // levels WITHOUT private copies -- the big hashed ones, where every add is a random line -- accumulate 2^k-scaled gradients
+    // in a table of half2 with ONE packed atomic per entry instead of two fp32 atomics.  The scatter is bound by the number
+    // of atomics (measured: with one of the two fp32 adds compiled out the 1024-ray step takes 3.02 instead of 4.09 ms).
+    __half2* g16;                                // (entries) half2, zero-initialised by the caller; null: fp32 atomics
+    float g16_scale;                             // gradients are multiplied by this on the way in, divided on the way out
 };
 
 __device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
@@ -881,12 +888,22 @@ __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, co
             }
         }
     }
-    if (active && head && !P.exp_noscatter) {
+    if (active && head && !P.exp_noscatter && P.g16 && !P.cp_n[lv]) {      // (wave-uniform choice)
+        __half2* h = P.g16 + A.off[lv];
+        const float k = P.g16_scale;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
+            unsafeAtomicAdd(h + idx, __floats2half2_rn(v0[c] * k, v1[c] * k));
+        }
+    } else if (active && head && !P.exp_noscatter) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
             fadd(dtab + 2ll * idx, v0[c]);
-            fadd(dtab + 2ll * idx + 1, v1[c]);
+#ifndef MNRF_EXP_TCNN_HALF_SCATTER      // experiment (wrong gradients): is the scatter bound by the NUMBER of atomics?  If so, one packed
+            fadd(dtab + 2ll * idx + 1, v1[c]);      // 2 x f16 atomic per entry (tinycudann's choice) would halve it.
+#endif
         }
     }
 }
@@ -1523,10 +1540,28 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     return mnrf_check_launch("mnrf_tcnn_forward");
 }
 
+// d_table += g16 / scale for the entries [e0, e1) of the levels that accumulated in half2 (MNRF_TCNN_GRAD_F16)
+__global__ void tcnn_fold16_kernel(const __half2* __restrict__ g16, float2* __restrict__ d_table, long long e0, long long e1, float inv) {
+    const long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e1) return;
+    const float2 v = __half22float2(g16[e]);
+    float2 d = d_table[e];
+    d.x += v.x * inv;
+    d.y += v.y * inv;
+    d_table[e] = d;
+}
+
 extern "C" int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host) {
     int n[NL];
     long long o[NL];
     return offsets17_host ? plan_copies(offsets17_host, n, o, nullptr) : 0;
+}
+
+// with MNRF_TCNN_GRAD_F16 in `flags` the workspace also holds the half2 gradient table (one 4-byte slot per entry) behind the copies
+extern "C" int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags) {
+    if (!offsets17_host) return 0;
+    const int64_t base = mnrf_tcnn_backward_workspace_floats(offsets17_host);
+    return base + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] : 0);
 }
 
 extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
@@ -1561,6 +1596,13 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     P.cut = flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD);
     P.keep_mirror = keep_mirror;
     P.copies = workspace;
+    P.g16 = nullptr;
+    P.g16_scale = 1.f;
+    if ((flags & MNRF_TCNN_GRAD_F16) && workspace) {
+        P.g16 = (__half2*)(workspace + mnrf_tcnn_backward_workspace_floats(offsets17_host));
+        static const float scale = [] { const char* e = getenv("MNRF_TCNN_GRAD_SCALE"); return e && atof(e) > 0 ? (float)atof(e) : 1024.f; }();
+        P.g16_scale = scale;       // tinycudann's loss scale is 128; 1024 keeps 1e-7-sized contributions above f16's subnormal step
+    }
     P.exp_noscatter = getenv("MNRF_EXP_TCNN_NOSCATTER") != nullptr;
     P.agg_levels = 0;
     // measured (1 M samples, bound 6): 15.96 / 15.00 / 14.12 / 13.77 / 13.70 ms per step with runs summed up to resolution
@@ -1579,6 +1621,15 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
     if (g_normal) hipLaunchKernelGGL(tcnn_bwd2_kernel, grid, block, lds, (hipStream_t)stream, P);     // adds the second-order term
     if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+    if (P.g16) {      // everything from the first level without copies on (copied levels in between only add the zeros they hold)
+        long long e0 = -1;
+        for (int l = 0; l < NL && e0 < 0; ++l)
+            if (!P.cp_n[l]) e0 = A.off[l];
+        const long long e1 = A.off[NL];
+        if (e0 >= 0 && e1 > e0)
+            hipLaunchKernelGGL(tcnn_fold16_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P.g16,
+                               (float2*)d_table, e0, e1, 1.f / P.g16_scale);
+    }
     return mnrf_check_launch("mnrf_tcnn_backward");
 }
 

@@ -15,6 +15,7 @@ density-gradient normal (`normal`) is the second-order term of models/mirror_ner
 by a second kernel of the same call (table, sigma_net, position).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -46,6 +47,9 @@ _BLOB = (("sigma_net.0.weight", 64, 32, 32), ("sigma_net.1.weight", 16, 64, 64),
 
 def _offsets17(cfg):
     return (ctypes.c_int64 * 17)(*[int(v) for v in cfg["offsets"]])
+
+
+GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
 
 
 class TcnnFieldFn(torch.autograd.Function):
@@ -96,13 +100,16 @@ class TcnnFieldFn(torch.autograd.Function):
         d_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_x else None
         d_dir = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_d else None
         offs = _offsets17(m.cfg)
-        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats(offs)), dtype=torch.float32, device=dev)
+        # table_grad_f16 (module attribute; env MNRF_TCNN_GRAD_F16=1 sets the default): the big hashed levels accumulate their
+        # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
+        flags = ctx.cut | (_lib.MNRF_TCNN_GRAD_F16 if getattr(m, "table_grad_f16", GRAD_F16) else 0)
+        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(
                 p(table), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
-                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut,
+                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), flags,
                 _lib.stream()), "mnrf_tcnn_backward")
         grads, off = [], 0
         for _name, rows, used, padded in _BLOB:

@@ -14,11 +14,14 @@ from oracle import mirror_nerf_oracle as O  # noqa: E402  (ray generator only)
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--f16-grads", action="store_true", help="table gradient of the big hashed levels in half2 by packed atomics")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 models = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev)
           for k in ("coarse", "fine")}
+for m_ in models.values():
+    m_.table_grad_f16 = a.f16_grads
 emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
 allrays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
 opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4)

@@ -151,6 +151,48 @@ def test_tcnn_backward_matches_torch_autograd(bound, B, which):
     assert int((got["encoder.embeddings"] != 0).sum()) <= B * 16 * 8 * 2
 
 
+def test_tcnn_backward_packed_f16_table_gradient():
+    """module.table_grad_f16 (flag MNRF_TCNN_GRAD_F16): the big hashed levels accumulate the table gradient in half2 with one
+    packed atomic per entry, scaled by 2^10 -- tinycudann's gradient precision.  Against the default fp32 scatter on the same
+    inputs: everything that is not the table is unchanged bit for bit; the table gradient agrees to f16 accuracy on the
+    entries that matter (2e-3 of the largest entry absolute; 1 % relative on entries above 1 % of the largest), and the same
+    entries are touched."""
+    B = 6000
+    m, _w, cfg = _model(6.0, seed=5, table_scale=0.3)
+    g = torch.Generator().manual_seed(17)
+    xyz = (torch.rand(B, 3, generator=g) * 2 - 1) * 6.0
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    x6 = torch.cat([xyz, d], 1).to(DEV)
+    seeds = {"sigma": 1e-3 * torch.randn(B, generator=g).to(DEV), "rgb": 1e-3 * torch.randn(B, 3, generator=g).to(DEV),
+             "pred_normal": 1e-3 * torch.randn(B, 3, generator=g).to(DEV), "is_mirror": 1e-3 * torch.randn(B, generator=g).to(DEV)}
+    which = ("sigma", "rgb", "pred_normal", "is_mirror")
+    m.table_grad_f16 = False
+    want, _ = _grads_of(m, x6, seeds, which)
+    m.table_grad_f16 = True
+    got, _ = _grads_of(m, x6, seeds, which)
+    for k in want:
+        if k == "encoder.embeddings":
+            continue
+        if k == "x6":
+            assert torch.equal(got[k], want[k]), k
+        else:      # the MLP gradients are sums of atomics over workgroups: order-dependent in the last bits
+            assert float((got[k] - want[k]).abs().max()) <= 1e-5 * (float(want[k].abs().max()) + 1e-12), k
+    a, b = got["encoder.embeddings"], want["encoder.embeddings"]
+    from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
+    offs = list(_offsets17(m.cfg))
+    first16 = next(offs[l] for l in range(16) if offs[l + 1] - offs[l] > 262144)      # levels without private copies (mnrf_tcnn.hip plan_copies)
+    # the copied (coarse) levels keep their fp32 route (atomics: equal up to the order of the adds)
+    assert float((a[:first16] - b[:first16]).abs().max()) <= 1e-5 * float(b[:first16].abs().max())
+    a, b = a[first16:], b[first16:]
+    scale = float(b.abs().max())
+    assert scale > 0 and int((b != 0).sum()) > 10000
+    assert float((a - b).abs().max()) <= 2e-3 * scale
+    big = b.abs() > 1e-2 * scale
+    assert int(big.sum()) > 1000
+    assert float(((a - b).abs()[big] / b.abs()[big]).max()) <= 1e-2
+    assert float(((a != 0) != (b != 0)).float().mean()) < 1e-3      # (a contribution below f16's subnormal step)
+
+
 @pytest.mark.parametrize("mode", ["normal", "mask", "outside"])
 def test_tcnn_backward_detach_density_options(mode):
     """--detach_density_for_normal_loss / _for_mask_loss / _outside_mirror_for_mask_loss on the hash-grid field
