@@ -304,7 +304,9 @@ class _Pending:
                 self.dirty = True
         elif not self.dirty:
             self.flat.zero_()      # no samples at all in this pass
-        return [self._views[n] if n in self._views else torch.zeros(s, device=self.flat.device) for n, s in zip(self.names, self.shapes)]
+        from .weights import decanonical      # (a model with fewer encoding bands: its own column count, weights.canonical)
+        return [decanonical(n, self._views[n], s) if n in self._views else torch.zeros(s, device=self.flat.device)
+                for n, s in zip(self.names, self.shapes)]
 
 
 class EmbedFn(torch.autograd.Function):

@@ -186,7 +186,7 @@ def _module_message(module):
     for sub, pname, full in param_refs(module):
         q = sub._parameters[pname]
         if q is not None and q.requires_grad and q.grad is not None:
-            o, k = lay[full]
+            o, k = lay[full][0], q.numel()      # (a model with fewer encoding bands fills a prefix of its slot, on every rank alike)
             flat[o:o + k].copy_(q.grad.reshape(-1))
     return flat, True
 
@@ -205,7 +205,7 @@ def _scatter_message(module, flat):
     for sub, pname, full in param_refs(module):
         q = sub._parameters[pname]
         if q is not None and q.requires_grad:
-            o, k = lay[full]
+            o, k = lay[full][0], q.numel()
             v = flat[o:o + k].view_as(q)
             q.grad = v.clone() if q.grad is None else q.grad.copy_(v)
 

@@ -260,18 +260,26 @@ class MirrorNeRF(nn.Module):
             self.hidden_dim_is_mirror = W // 2
             self.is_mirror_net = nn.Sequential(nn.Linear(W, W // 2), nn.LeakyReLU(inplace=True),
                                                nn.Linear(W // 2, 1), nn.Sigmoid())
-        if (D, W, in_channels_xyz, in_channels_dir, list(skips)) != (8, 256, 63, 27, [4]):
+        # --N_emb_xyz / --N_emb_dir (opt.py:35-46) below the defaults run on the same kernels: the kernel always evaluates
+        # 10 / 4 frequency bands and the weight columns of the bands this model does not have are packed as zeros
+        # (weights.pack_state), so every value and every gradient is the reference's.  More bands, another depth / width
+        # / skip layout do not fit the kernels' register and weight-stream layout.
+        ok_in = (in_channels_xyz - 3) % 6 == 0 and 3 <= in_channels_xyz <= 63 and \
+            (in_channels_dir - 3) % 6 == 0 and 3 <= in_channels_dir <= 27
+        if (D, W, list(skips)) != (8, 256, [4]) or not ok_in:
             raise NotImplementedError(
-                "the HIP field kernel covers the reference's trunk: D=8, W=256, 63/27 input channels, skips=[4] "
-                "(with or without the normal / mirror-mask heads)")
+                "the HIP field kernel covers the reference's trunk: D=8, W=256, skips=[4], Embedding(N <= 10) for positions "
+                "(3 + 6 N <= 63 input channels) and Embedding(N <= 4) for directions (<= 27), with or without the normal / "
+                "mirror-mask heads")
+        self.n_freqs_xyz, self.n_freqs_dir = (in_channels_xyz - 3) // 6, (in_channels_dir - 3) // 6
 
     def forward(self, x, compute_normal=True, sigma_only=False, embedding_xyz=None, embedding_dir=None,
                 mirror_mask=None, detach_density_outside_mirror_for_mask_loss=False,
                 detach_density_for_mask_loss=False, detach_density_for_normal_loss=False):
         """x: (B,3) when sigma_only else (B, 3+27) = [raw xyz, embedded dir] (mirror_nerf.py:130-133).
         The three detach_* flags only alter gradients in the reference; values are identical."""
-        if embedding_xyz is None or getattr(embedding_xyz, "N_freqs", None) != 10:
-            raise NotImplementedError("embedding_xyz must be Embedding(10) (63 input channels)")
+        if embedding_xyz is None or getattr(embedding_xyz, "N_freqs", None) != self.n_freqs_xyz:
+            raise NotImplementedError(f"embedding_xyz must be Embedding({self.n_freqs_xyz}) ({self.in_channels_xyz} input channels)")
         x = x.float().contiguous()
         B = x.shape[0]
         if sigma_only:
@@ -279,6 +287,8 @@ class MirrorNeRF(nn.Module):
                 raise RuntimeError(f"sigma_only expects (B,3), got {tuple(x.shape)}")
         elif x.shape[1] != 3 + self.in_channels_dir:
             raise RuntimeError(f"expected (B,{3 + self.in_channels_dir}), got {tuple(x.shape)}")
+        elif self.in_channels_dir != 27:      # the kernel reads 27 view-encoding channels per sample: the absent bands as zeros
+            x = torch.cat([x, torch.zeros(B, 27 - self.in_channels_dir, device=x.device)], 1).contiguous()
         ld = x.shape[1]
         o = field_forward(self, B, xyz=x, xyz_stride=ld, spr=1,
                           dir_emb=None if sigma_only else x.view(-1)[3:], dir_stride=ld,
@@ -296,7 +306,7 @@ class MirrorNeRF(nn.Module):
             # the reference evaluates normal_net here as well (mirror_nerf.py:154-161)
             if self.predict_normal:
                 if B:
-                    xx = torch.cat([x, torch.zeros(B, self.in_channels_dir, device=dev)], 1).contiguous()
+                    xx = torch.cat([x, torch.zeros(B, 27, device=dev)], 1).contiguous()
                     o2 = field_forward(self, B, xyz=xx, xyz_stride=30, spr=1, dir_emb=xx.view(-1)[3:], dir_stride=30)
                     out["pred_normal"] = o2["pred_normal"]
                 else:

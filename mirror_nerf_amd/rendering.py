@@ -91,8 +91,12 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     hashgrid = isinstance(models["coarse"], MirrorNeRFTcnn)     # BASELINE config 5 (train.py:67-99)
     if hashgrid and (n_fx, n_fd) != (0, 0):
         raise NotImplementedError("the hash-grid field takes raw positions and directions: Embedding(0)/Embedding(0)")
-    if not hashgrid and (n_fx, n_fd) != (10, 4):
-        raise NotImplementedError("the HIP field kernel is built for Embedding(10)/Embedding(4)")
+    if not hashgrid:
+        for mdl in models.values():
+            if (n_fx, n_fd) != (getattr(mdl, "n_freqs_xyz", 10), getattr(mdl, "n_freqs_dir", 4)):
+                raise NotImplementedError(f"embeddings Embedding({n_fx}) / Embedding({n_fd}) do not match the model's "
+                                          f"{getattr(mdl, 'in_channels_xyz', 63)} / {getattr(mdl, 'in_channels_dir', 27)} input channels")
+        n_fd = 4      # the kernel reads 27 view-encoding channels; a model with fewer bands has zero weights on the others
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
 
     train = torch.is_grad_enabled() and (rays.requires_grad or any(

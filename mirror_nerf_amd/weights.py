@@ -50,6 +50,32 @@ def _zeros(name, dev):
     return t
 
 
+def canonical(name, t):
+    """A parameter of a model with fewer encoding bands (--N_emb_xyz < 10, --N_emb_dir < 4; opt.py:35-46) in the shape the
+    kernels are built for: the columns of the absent bands as zeros.  Band k of Embedding occupies channels 3 + 6 k .. 8 + 6 k
+    (models/mirror_nerf.py:30-38), so the channels of a shorter encoding are a PREFIX of the 63 / 27."""
+    want = PARAM_SHAPES[name]
+    if tuple(t.shape) == want or t.dim() != 2 or t.shape[0] != want[0] or t.shape[1] > want[1]:
+        return t
+    z = lambda n: torch.zeros(t.shape[0], n, dtype=t.dtype, device=t.device)  # noqa: E731
+    if name == "xyz_encoding_5.0.weight":                  # cat([xyz encoding, h]) (mirror_nerf.py:192-193)
+        c = t.shape[1] - 256
+        return torch.cat([t[:, :c], z(63 - c), t[:, c:]], 1) if 3 <= c <= 63 else t
+    if name in ("xyz_encoding_1.0.weight", "dir_encoding.0.weight"):      # the encoding is the (only / last) block of columns
+        return torch.cat([t, z(want[1] - t.shape[1])], 1)
+    return t
+
+
+def decanonical(name, g, shape):
+    """The gradient of a canonical-shape parameter cut back to the model's own shape (inverse of `canonical`)."""
+    if tuple(g.shape) == tuple(shape):
+        return g
+    if name == "xyz_encoding_5.0.weight":
+        c = shape[1] - 256
+        return torch.cat([g[:, :c], g[:, 63:]], 1)
+    return g[:, :shape[1]]
+
+
 def pack_state(tensors, out=None):
     """tensors: dict name -> fp32 CUDA tensor.  Returns the packed image (1-D fp32 CUDA tensor).
     The parameters of an absent optional head (predict_normal=False / predict_mirror_mask=False) are packed as zeros."""
@@ -63,7 +89,7 @@ def pack_state(tensors, out=None):
     arr = (ctypes.c_void_p * _lib.N_PARAMS)()
     dev = next(iter(tensors.values())).device
     for i, n in enumerate(PARAM_NAMES):
-        t = tensors[n].detach() if n in tensors else _zeros(n, dev)
+        t = canonical(n, tensors[n].detach()) if n in tensors else _zeros(n, dev)
         if tuple(t.shape) != PARAM_SHAPES[n]:
             raise RuntimeError(f"{n}: shape {tuple(t.shape)} != {PARAM_SHAPES[n]} (D=8, W=256, N_emb 10/4 only)")
         if t.dtype != torch.float32 or not t.is_cuda:

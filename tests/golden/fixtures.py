@@ -28,7 +28,8 @@ class Fixture:
             z = np.load(os.path.join(HERE, self.meta["weights_file"]))
             sds = [{k[len(m) + 2:]: z[k].copy() for k in z.files if k.startswith(m + "__")} for m in ("coarse", "fine")[:n]]
         else:
-            sds = W.make_state_dict(self.meta["seed"], n)
+            arch = {k: self.meta[k] for k in ("in_xyz", "in_dir") if k in self.meta}      # (G16: fewer encoding bands)
+            sds = W.make_state_dict(self.meta["seed"], n, **arch)
         want = self.meta["checksum"]
         want = want if isinstance(want, list) else [want]
         for sd, c in zip(sds, want):

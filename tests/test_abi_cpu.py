@@ -94,6 +94,10 @@ def test_module_mirrors_reference_names():
         assert (v.numpy() == ref[k]).all(), k     # same construction order => same init under a seed
     with pytest.raises(NotImplementedError):
         M.MirrorNeRF(W=128, predict_normal=True, predict_mirror_mask=True)
+    with pytest.raises(NotImplementedError):
+        M.MirrorNeRF(in_channels_xyz=75, in_channels_dir=27)      # Embedding(12): more bands than the kernels evaluate
+    few = M.MirrorNeRF(in_channels_xyz=39, in_channels_dir=15, predict_normal=True, predict_mirror_mask=True)      # --N_emb_xyz 6 --N_emb_dir 2
+    assert (few.n_freqs_xyz, few.n_freqs_dir) == (6, 2) and few.xyz_encoding_5[0].weight.shape == (256, 256 + 39)
 
 
 def test_isa_invariants_of_the_built_field_kernels():

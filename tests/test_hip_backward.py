@@ -206,7 +206,7 @@ def test_field_backward_ray_mode_accumulates_over_samples():
 
 
 @pytest.mark.parametrize("name", ["g9_train_grads", "g9_train_grads_full", "g9b_detach_mask", "g9b_detach_outside_mirror",
-                                  "g9b_detach_normal", "g9b_detach_ref_color"])
+                                  "g9b_detach_normal", "g9b_detach_ref_color", "g16_nemb_6_2_train_grads"])
 def test_train_step_gradients_golden(name):
     """G9: gradients of a first-order loss through the whole train-semantics render (coarse + fine
     pass, GT mirror mask, compacted reflected rays, blend) against the reference's autograd,
@@ -224,7 +224,9 @@ def test_train_step_gradients_golden(name):
     first_order_loss = getattr(GL, fx.meta.get("loss", "first_order_loss"))
     sds = fx.state_dicts()
     hp = dict(fx.meta["hp"])
-    hp.update(N_emb_xyz=10, N_emb_dir=4, predict_normal=True, predict_mirror_mask=True, model_type="nerf")
+    # (G16, tests/golden/make_golden_nemb.py: --N_emb_xyz 6 --N_emb_dir 2 on the kernels built for 10 / 4 bands)
+    hp.update(N_emb_xyz=fx.meta.get("N_emb_xyz", 10), N_emb_dir=fx.meta.get("N_emb_dir", 4), predict_normal=True,
+              predict_mirror_mask=True, model_type="nerf")
     system = M.NeRFSystem(SimpleNamespace(**hp))
     system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
     system.nerf_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
@@ -235,6 +237,16 @@ def test_train_step_gradients_golden(name):
     res = system(t("rays"), extra)
     loss = first_order_loss(res, t("target"), t("gt_mask"))
     assert abs(loss.item() - float(fx.outputs["loss"])) <= (2e-3 if fx.meta.get("loss") == "full_loss" else 1e-5)
+    if name.startswith("g16"):      # this fixture also holds the forward dict of the step
+        from tests.golden.fixtures import PER_SAMPLE_FINE, tolerance
+        n_cmp = 0
+        for k, want in fx.outputs.items():
+            if k == "loss" or k.startswith("grad__") or k in PER_SAMPLE_FINE or k not in res:
+                continue
+            d = float(np.max(np.abs(res[k].detach().cpu().numpy().astype(np.float64) - want))) if want.size else 0.0
+            assert d <= tolerance(k, fx.meta), (k, d)
+            n_cmp += 1
+        assert n_cmp >= 15
     loss.backward()
     worst = 0.0
     report = []

@@ -651,6 +651,46 @@ def test_training_reduces_loss():
     assert all(np.isfinite(losses)) and losses[-1] < 0.97 * losses[0] and losses[10] < losses[0], losses
 
 
+def test_fewer_encoding_bands_on_the_kernels_for_10_and_4(precision):
+    """--N_emb_xyz 6 --N_emb_dir 2 (opt.py:35-46): MirrorNeRF(39, 15) + Embedding(6) / Embedding(2).  The kernels always evaluate
+    10 / 4 bands; the weight columns of the absent bands are packed as zeros (weights.canonical).  `MirrorNeRF.forward` on
+    (B, 3 + 15) inputs and `render_rays` against the oracle evaluated with 6 / 2 bands (pinned by fixture G16, whose forward
+    dict and gradients the HIP path is held to in tests/test_hip_backward.py); the default-size guards still raise."""
+    M = _M()
+    fx = FX.Fixture("g16_nemb_6_2_train_grads")
+    sd = fx.state_dicts()[1]
+    m = M.MirrorNeRF(in_channels_xyz=39, in_channels_dir=15, predict_normal=True, predict_mirror_mask=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(DEV)
+    emb = {"xyz": M.Embedding(6), "dir": M.Embedding(2)}
+    rs = np.random.RandomState(5)
+    xyz = rs.uniform(-3, 3, (777, 3)).astype(np.float32)
+    d = rs.normal(size=(777, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = torch.cat([torch.from_numpy(xyz).to(DEV), emb["dir"](torch.from_numpy(d).to(DEV))], 1)
+    assert x.shape[1] == 18
+    with torch.no_grad():
+        got = _np(m(x, compute_normal=True, sigma_only=False, embedding_xyz=emb["xyz"], embedding_dir=emb["dir"]))
+        sonly = _np(m(x[:, :3].contiguous(), compute_normal=False, sigma_only=True, embedding_xyz=emb["xyz"], embedding_dir=emb["dir"]))
+    want = O.field_forward(sd, x.cpu().numpy(), False, True, n_freqs_xyz=6)
+    for k in ("sigma", "rgb", "pred_normal", "is_mirror"):
+        scale = max(1.0, float(np.abs(want[k]).max()))
+        assert float(np.max(np.abs(got[k].reshape(want[k].shape) - want[k]))) <= 1e-4 * scale, k
+    assert float(np.max(np.abs(sonly["sigma"].reshape(-1) - want["sigma"].reshape(-1)))) <= 1e-4 * max(1.0, float(np.abs(want["sigma"]).max()))
+    with pytest.raises(NotImplementedError):
+        m(x, embedding_xyz=M.Embedding(10), embedding_dir=emb["dir"])
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    models = {"coarse": m, "fine": m}
+    with torch.no_grad():
+        res = _np(M.render_rays(models, emb, rays, 64, False, 0, 0, 64, 32768, False, True, compute_normal=False))
+    orc = O.render_rays({"coarse": sd, "fine": sd}, {"xyz": 6, "dir": 2}, fx.inputs["rays"], 64, False, 0, 0, 64, 32768, False, True,
+                        compute_normal=False)
+    for k in ("rgb_fine", "depth_fine", "opacity_fine", "mirror_mask_fine"):
+        assert float(np.max(np.abs(res[k] - orc[k]))) <= (8e-4 if k.startswith("depth") else 1e-4), k
+    with pytest.raises(NotImplementedError):
+        M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, 32768, False, True, compute_normal=False)
+
+
 # --------------------------------------------------------------------------- split-f16 vs fp32 at full size
 def test_split_agrees_with_fp32_chain_full_chunk(precision):
     """BASELINE config 2 chunk (32768 rays x 192 samples = 6.29 M evaluations): the split-f16 kernel against the

@@ -117,6 +117,42 @@ def test_config1_through_the_recursion(name):
     _cmp(fx, got, base=5e-6)
 
 
+def test_fewer_encoding_bands_golden():
+    """G16 (tests/golden/make_golden_nemb.py): --N_emb_xyz 6 --N_emb_dir 2 through the reference's NeRFSystem.forward; the
+    oracle takes the band counts as arguments.  And the identity the HIP path rests on: the same model with its weight
+    columns zero-padded to 63 / 27 channels (mirror_nerf_amd.weights.canonical) evaluated with 10 / 4 bands gives the same
+    field outputs."""
+    fx = FX.Fixture("g16_nemb_6_2_train_grads")
+    m = fx.meta
+    sds = fx.state_dicts()
+    assert sds[0]["xyz_encoding_1.0.weight"].shape == (256, 39) and sds[0]["dir_encoding.0.weight"].shape == (128, 256 + 15)
+    emb = {"xyz": m["N_emb_xyz"], "dir": m["N_emb_dir"]}
+    got = O.render_train({"coarse": sds[0], "fine": sds[1]}, emb, fx.inputs["rays"], m["hp"],
+                         {"mirror_mask": fx.inputs["gt_mask"].copy(), "is_eval": False, "train_geometry_stage": False})
+    want = {k: v for k, v in fx.outputs.items() if k != "loss" and not k.startswith("grad__")}
+    for k, w in want.items():
+        if k in FX.PER_SAMPLE_FINE:
+            continue
+        err = float(np.max(np.abs(got[k].astype(np.float64) - w))) if w.size else 0.0
+        assert err <= FX.tolerance(k, m), (k, err)
+    import torch
+    from mirror_nerf_amd.weights import canonical, decanonical
+    sd = sds[1]
+    pad = {k: canonical(k, torch.from_numpy(v)).numpy() for k, v in sd.items()}
+    assert pad["xyz_encoding_1.0.weight"].shape == (256, 63) and pad["xyz_encoding_5.0.weight"].shape == (256, 319)
+    assert pad["dir_encoding.0.weight"].shape == (128, 283)
+    for k in ("xyz_encoding_1.0.weight", "xyz_encoding_5.0.weight", "dir_encoding.0.weight"):
+        assert np.array_equal(decanonical(k, torch.from_numpy(pad[k]), sd[k].shape).numpy(), sd[k])
+    rs = np.random.RandomState(3)
+    xyz = rs.uniform(-3, 3, (200, 3)).astype(np.float32)
+    d = rs.normal(size=(200, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    a = O.field_forward(sd, np.concatenate([xyz, O.embedding(d, 2)], 1), False, True, n_freqs_xyz=6)
+    b = O.field_forward(pad, np.concatenate([xyz, O.embedding(d, 4)], 1), False, True, n_freqs_xyz=10)
+    for k in ("sigma", "rgb", "pred_normal", "is_mirror", "normal"):
+        assert np.max(np.abs(a[k] - b[k])) <= 2e-6 * max(1.0, float(np.abs(a[k]).max())), k
+
+
 @pytest.mark.parametrize("name", ["g12_rays_37x53", "g12_rays_64x64"])
 def test_ray_generation_golden(name):
     """G12: the oracle's pin-hole rays against the reference's (datasets/ray_utils.py:6-53, captured by make_golden_rays.py)."""
