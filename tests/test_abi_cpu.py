@@ -59,7 +59,25 @@ def test_argument_validation_without_gpu(L):
     assert L.mnrf_mse_psnr(null, null, null, 10, 1, null, null, null) < 0
     assert L.mnrf_loss_workspace_floats(1024, 64, 192, 0) > 1024
     assert L.mnrf_mse_blocks() >= 1
+    # round-3 entry points: the same contract (null pointers / sizes are refused with a message; sizes are plain arithmetic)
+    import ctypes as C
+    assert L.mnrf_field_composite_fused(null, 4, null, null, null, 27, 0, null, null, null, null, null, null, null, null) < 0
+    assert b"mnrf_field_composite_fused" in L.mnrf_last_error()
+    assert L.mnrf_fused_samples_per_ray() == 192
+    assert L.mnrf_dw_planes(0, null, null, null, null, null, null, 0, null) < 0          # 1..8 evaluations
+    assert L.mnrf_dw_planes(1, null, null, null, null, null, null, 0, null) < 0
+    assert b"mnrf_dw_planes" in L.mnrf_last_error()
+    assert L.mnrf_train_planes_bytes(128) == 4 * 174 * 2048 and L.mnrf_train_planes_bytes(129) == 8 * 174 * 2048
+    assert L.mnrf_train_dy_planes_bytes(128) == 4 * 172 * 2048
+    one = (C.c_int64 * 1)(4096)
+    assert L.mnrf_dw_planes_workspace_floats(1, one) > 0
+    assert L.mnrf_field_backward_planes(null, 4, null, 3, null, null, 1, null, null, null, null, null, null, null, null, null,
+                                        null, null, null, null, null, 0, null) < 0
+    offs = (C.c_int64 * 17)(*range(0, 17 * 1024, 1024))
+    assert L.mnrf_tcnn_backward_workspace_floats2(offs, 16) == L.mnrf_tcnn_backward_workspace_floats(offs) + 16 * 1024
+    assert L.mnrf_tcnn_backward_workspace_floats2(offs, 0) == L.mnrf_tcnn_backward_workspace_floats(offs)
     # zero-sized work is a no-op, not an error
+    assert L.mnrf_field_composite_fused(null, 0, null, null, null, 27, 0, null, null, null, null, null, null, null, null) < 0   # (pointers are checked first)
     assert L.mnrf_embed(null, 0, 3, 4, null, null) == 0
     assert L.mnrf_threshold_mask(null, 0, null, null) == 0
 
