@@ -467,15 +467,19 @@ def main():
         MN.LAUNCH_LOG = None
         MN.set_precision(a.precision)
 
-        # PCIe-inclusive rate (never `value`): one more frame whose per-ray maps are copied to the host
+        # PCIe-inclusive rate (never `value`): frames whose per-ray maps are copied to the host (one untimed first: it pins the
+        # staging buffers, as the first frame of an eval run does)
+        render(rays, to_cpu="maps")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hm = render(rays, to_cpu="maps")
         torch.cuda.synchronize()
         dt_h = time.perf_counter() - t1
         host_maps = {"rays_per_s": rays_per_frame / dt_h, "bytes_to_host": int(sum(v.numel() * v.element_size() for v in hm.values())),
-                     "note": "same frame with the per-ray maps (rgb, depth, opacity, mask, normals, x_surface) copied to pageable host "
-                             "memory chunk by chunk; the reference copies every dict entry incl. per-sample tensors (eval.py:735-736)"}
+                     "note": "same frame with the per-ray maps (rgb, depth, opacity, mask, normals, x_surface) handed to the host: chunk "
+                             "by chunk into pinned staging buffers on a side stream while the next chunk renders, one host-side copy "
+                             "at the end; final pass ray-fused (maps_only_fused is the same frame left on the device); the reference "
+                             "copies every dict entry incl. per-sample tensors (eval.py:735-736)"}
         hm = None
 
     # the same frame with per-ray maps only, results left on the device: the final pass ray-fused (field evaluation +

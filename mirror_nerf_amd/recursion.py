@@ -270,6 +270,26 @@ class NeRFSystem(nn.Module):
 
 
 # ----------------------------------------------------------------------------- eval semantics
+_COPY_STREAMS, _PINNED = {}, {}
+
+
+def _copy_stream(device):
+    s = _COPY_STREAMS.get(device)
+    if s is None:
+        s = _COPY_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _pinned(key, rows, tail, dtype):
+    """Pinned host staging buffer for one per-ray map of a frame, kept between frames (pinning 51 MB costs more than copying
+    them); grown when a larger frame arrives."""
+    k = (key, tail, dtype)
+    buf = _PINNED.get(k)
+    if buf is None or buf.shape[0] < rows:
+        buf = _PINNED[k] = torch.empty((rows,) + tail, dtype=dtype).pin_memory()
+    return buf
+
+
 @torch.no_grad()
 def batched_inference(models, embeddings, rays, N_samples, N_importance, use_disp, chunk, **kwargs):
     """eval.batched_inference.  kwargs: args (namespace/dict with predict_normal, only_one_field,
@@ -411,6 +431,12 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     # per-sample tensors of TWO chunks are alive at once (~2 x 3 KB/ray x chunk: 200 MB at chunk 32768) -- set it to 0 on a
     # memory-tight device.  With random roughness draws (no injection) a guard retry draws afresh, as any re-render would.
     results = defaultdict(list)
+    # to_cpu="maps" on the GPU: the per-ray maps of a chunk travel to PINNED staging buffers on a side stream while the next
+    # chunk renders (pageable destinations made every copy synchronous: 33 ms per 51 MB frame); one host-side copy out of
+    # the staging buffers at the end hands back ordinary tensors the caller owns
+    stage_maps = to_cpu == "maps" and rays.is_cuda
+    staged, staged_rows, hold = {}, defaultdict(int), []
+    copy_stream = _copy_stream(rays.device) if stage_maps else None
     starts = list(range(0, rays.shape[0], chunk))
     pipelined = rays.is_cuda and not rough and len(starts) > 1 and os.environ.get("MNRF_EVAL_PIPELINE", "1") != "0"
     host_flags = torch.zeros(2, dtype=torch.int32).pin_memory() if pipelined else None
@@ -423,13 +449,32 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
             out = stage_b(state)
         else:
             out = recurse(rays[i:i + chunk].contiguous(), 0)
+        if stage_maps:
+            done = torch.cuda.Event()
+            done.record()
+            copy_stream.wait_event(done)
         for k, v in out.items():
             if to_cpu == "maps" or maps_only:
                 if v.dim() <= 2 and (v.dim() == 1 or v.shape[1] <= 3):     # per-ray maps only
-                    results[k] += [v.to("cpu", non_blocking=True) if to_cpu == "maps" else (v.cpu() if to_cpu else v)]
+                    if stage_maps:
+                        buf = staged.get(k)
+                        if buf is None:
+                            buf = staged[k] = _pinned(k, rays.shape[0], tuple(v.shape[1:]), v.dtype)
+                        r0 = staged_rows[k]
+                        with torch.cuda.stream(copy_stream):
+                            buf[r0:r0 + v.shape[0]].copy_(v, non_blocking=True)
+                        staged_rows[k] = r0 + v.shape[0]
+                        hold.append(v)      # (alive until the copies have run)
+                    else:
+                        results[k] += [v.to("cpu", non_blocking=True) if to_cpu == "maps" else (v.cpu() if to_cpu else v)]
             else:
                 results[k] += [v.cpu() if to_cpu else v]
-    if to_cpu == "maps" and rays.is_cuda:
+    if stage_maps:
+        copy_stream.synchronize()
+        hold.clear()
+        for k, buf in staged.items():
+            results[k] = [buf[:staged_rows[k]].clone()]      # out of the (re-used) staging buffer into a tensor of the caller's
+    elif to_cpu == "maps" and rays.is_cuda:
         torch.cuda.current_stream().synchronize()
     # range guard of the split arithmetic, once per call (= per frame): a tripped model is on the fp32 kernels now
     from .mirror_nerf import check_guard

@@ -891,6 +891,14 @@ def test_fused_eval_through_the_recursion(precision):
         assert torch.equal(maps[k], full[k]), k
         assert torch.equal(host[k], full[k].cpu()), k
     assert all(v.dim() <= 2 for v in maps.values())
+    # the host maps travel through pinned staging buffers that are RE-USED between frames: what a call returns must not
+    # alias them (a second frame -- other rays, fewer of them -- must leave the first frame's tensors untouched)
+    keep = {k: v.clone() for k, v in host.items()}
+    other = M.batched_inference(models, _emb(), rays[100:400].flip(0).contiguous(), 64, 128, False, 200, args=args,
+                                trace_secondary_rays=True, to_cpu="maps")
+    assert other["rgb_fine"].shape[0] == 300 and not other["rgb_fine"].is_pinned()
+    for k, v in host.items():
+        assert torch.equal(v, keep[k]), k
     if precision == "split" and os.environ.get("MNRF_SPLIT32", "0") != "1" and os.environ.get("MNRF_SPLIT48", "1") != "0":
         assert "weights_fine" not in maps
     # N_importance = 64 (128 samples per ray) is not the fused launch class: the request is honoured by the two-kernel path
