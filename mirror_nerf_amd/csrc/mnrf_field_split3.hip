@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include <stdlib.h>
+#include <mutex>
 
 #include "mnrf_layout.h"
 #include "mnrf_field_args.h"
@@ -54,6 +55,8 @@ static bool tile_queue_slot(FieldArgs& A) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_DEVICES) return false;
     TileQueues& q = g_tq[dev];
+    static std::mutex init_lock;      // (first use from two host threads at once)
+    std::lock_guard<std::mutex> hold(init_lock);
     if (!q.base) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
