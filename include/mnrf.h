@@ -174,6 +174,12 @@ int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const floa
                             const float* keep_mirror /* (n_rays) or null: 0 = this ray's mirror mask sees weights.detach() */,
                             void* stream);
 
+/* Ray gradients of one field evaluation in ray mode (autograd of models/rendering.py:302 `x = o + d z` and of the per-ray view
+ * encoding, rendering.py:275-277): g_rays (n_rays, 8) = [sum_s dL/dx_s | sum_s z_s dL/dx_s | 0 0] from d_xyz (n_rays*spr, 3) and
+ * z_vals (n_rays, spr); g_de (n_rays, 27) = sum_s d_dir[s][:27] from d_dir (n_rays*spr, 32).  Either output may be null. */
+int mnrf_ray_grads(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                   float* g_de, void* stream);
+
 /* ---- backward of the per-ray glue (training; autograd through train.py:217-296, mirror_nerf.py:20-38)
  * reflect: g_sec (n_sec,8) = dL/d secondary rays -> dL/dx_surface (n_rays,3), dL/d normal (n_rays,3),
  *          dL/d rays (n_rays,8: direction and far columns); rows without a selected ray get zeros.

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mnrf_reflect_backward": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _str]),
     "mnrf_blend_backward": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _str]),
     "mnrf_embed_backward": (_int, [_c_f, _c_f, _i64, _int, _int, _c_f, _str]),
+    "mnrf_ray_grads": (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _str]),
     "mnrf_train_save_floats": (_i64, [_i64]),
     "mnrf_train_mask_words": (_i64, [_i64]),
     "mnrf_train_workspace_floats": (_i64, [_i64]),

@@ -11,6 +11,7 @@ import os
 FOLD_GRADS = os.environ.get("MNRF_FOLD_GRADS", "1") != "0"
 # MNRF_DW_PLANES=0: the round-1/2 weight-gradient route of the split arithmetic (fp32 rows of saved activations and of dY, one
 # set of bf16 x 6 GEMM launches per evaluation) instead of operand planes + ONE GEMM launch per module and pass (mnrf_dwp.h)
+RAY_GRADS_KERNEL = os.environ.get("MNRF_RAY_GRADS", "1") != "0"      # 0: the torch ops it replaced (A/B measurements)
 DW_PLANES = os.environ.get("MNRF_DW_PLANES", "1") != "0"
 
 
@@ -252,14 +253,24 @@ class FieldFn(torch.autograd.Function):
             if xyz is not None:
                 g_xyz = torch.zeros_like(xyz)
                 g_xyz[:, :3] = d_xyz
-            else:   # x = o + d*z  (rendering.py:302): dL/do = sum_s dL/dx, dL/dd = sum_s z dL/dx
+            elif rays.shape[1] == 8 and RAY_GRADS_KERNEL:   # x = o + d*z  (rendering.py:302): dL/do = sum_s dL/dx, dL/dd = sum_s z dL/dx -- one kernel,
+                g_rays = torch.empty_like(rays)      # together with the per-ray sum of the view-encoding gradient
+                if d_dir is not None:
+                    g_de = f(rays.shape[0], 27)
+                _lib.check(L.mnrf_ray_grads(p(d_xyz), p(z_vals), p(d_dir), rays.shape[0], spr, p(g_rays), p(g_de), _lib.stream()),
+                           "mnrf_ray_grads")
+            else:
                 N = rays.shape[0]
                 dx = d_xyz.view(N, spr, 3)
                 g_rays = torch.zeros_like(rays)
                 g_rays[:, 0:3] = dx.sum(1)
                 g_rays[:, 3:6] = (dx * z_vals.view(N, spr, 1)).sum(1)
-        if d_dir is not None:
-            g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
+        if d_dir is not None and g_de is None:
+            if rays is not None and xyz is None and B and RAY_GRADS_KERNEL:
+                g_de = f(rays.shape[0], 27)
+                _lib.check(L.mnrf_ray_grads(None, None, p(d_dir), rays.shape[0], spr, None, p(g_de), _lib.stream()), "mnrf_ray_grads")
+            else:
+                g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
         n_par = len(ctx.param_shapes)
         return (None, None, g_xyz, g_rays, None, g_de, None, *(d_params if hand_over else [None] * n_par))
 

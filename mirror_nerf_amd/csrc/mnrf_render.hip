@@ -749,6 +749,51 @@ extern "C" int mnrf_blend_backward(const float* g_out, const float* mask, const 
     return mnrf_check_launch("mnrf_blend_backward");
 }
 
+// Ray gradients of one field evaluation from its per-sample position / view-encoding gradients: x = o + d z
+// (models/rendering.py:302) gives dL/do = sum_s dL/dx_s and dL/dd = sum_s z_s dL/dx_s; the view encoding is per ray, so its
+// gradient is the sum over the ray's samples.  One wavefront per ray, fixed summation order.  (This was seven torch kernels
+// per evaluation -- zeros, two slices, a product, three reductions -- 28 launches of a training step.)
+__global__ __launch_bounds__(256) void ray_grads_kernel(const float* __restrict__ d_xyz, const float* __restrict__ z,
+                                                        const float* __restrict__ d_dir, long long n_rays, int spr,
+                                                        float* __restrict__ g_rays, float* __restrict__ g_de) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    if (g_rays) {
+        float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = lane; s < spr; s += 64) {
+            const float* p = d_xyz + (ray * spr + s) * 3;
+            const float zz = z[ray * spr + s];
+            const float p0 = p[0], p1 = p[1], p2 = p[2];
+            a[0] += p0; a[1] += p1; a[2] += p2;
+            a[3] += zz * p0; a[4] += zz * p1; a[5] += zz * p2;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d);
+        if (lane < 8) g_rays[ray * 8 + lane] = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3]
+                                               : lane == 4 ? a[4] : lane == 5 ? a[5] : 0.f;      // (near, far: no gradient)
+    }
+    if (g_de) {      // d_dir: (B, 32) rows, the 27 channels of Embedding(4) used
+        const int c = lane & 31;
+        float acc = 0.f;
+        for (int s = lane >> 5; s < spr; s += 2) acc += d_dir[(ray * spr + s) * 32 + c];
+        acc += __shfl_xor(acc, 32);
+        if (lane < 27) g_de[ray * 27 + lane] = acc;
+    }
+}
+
+extern "C" int mnrf_ray_grads(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                              float* g_de, void* stream) {
+    if (n_rays < 0 || spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: bad size");
+    if (n_rays == 0 || (!g_rays && !g_de)) return MNRF_OK;
+    if ((g_rays && (!d_xyz || !z_vals)) || (g_de && !d_dir)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: null pointer");
+    hipLaunchKernelGGL(ray_grads_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, d_xyz, z_vals, d_dir,
+                       (long long)n_rays, spr, g_rays, g_de);
+    return mnrf_check_launch("mnrf_ray_grads");
+}
+
 extern "C" int mnrf_embed_backward(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, void* stream) {
     if (n < 0 || c < 1 || n_freqs < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed_backward: bad size");
     if (n == 0) return MNRF_OK;
