@@ -305,6 +305,7 @@ def allreduce_gradients(params, average=True, modules=()):
     from .weights import params_of
     done = set()
     with_ov = [m.__dict__["_mnrf_overlap"] for m in modules if m.__dict__.get("_mnrf_overlap") is not None]
+    with_ov += [ov for ov in _SEQ if ov.work is not None and ov not in with_ov]      # (sent by its hooks but not listed: still waited for)
     for ov in _SEQ:                      # whatever the backward pass did not send goes out now, in the fixed order
         if ov in with_ov:
             ov.issue()
