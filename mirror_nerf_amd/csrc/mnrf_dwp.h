@@ -40,6 +40,19 @@ namespace mnrf {
 // gradients of the first layers within ~4e-6 of the fp32-row route (3e-5 without).  The price is headroom: a scaled
 // gradient of 65504 / 16 or more would overflow a plane; the backward kernel raises MNRF_GUARD_SATURATED already there.
 constexpr int PL_BOOST_LOG2 = 4;
+// cache policy of the producers' plane stores (aux operand of raw_buffer_store: 0 default, 2 = non-temporal).  The planes are
+// 2.7 GB per kernel that nothing reads again before the weight-gradient GEMM; the weight stream of the same kernel lives in L2.
+// Measured (scripts/bench_train.py, alternating libraries on one box): 5.97 ms per step with the default policy, 5.90 with
+// sc0 (1), **5.47-5.55 with nt (2)**, 5.76 with 3, 5.9-6.1 with sc1 (16), 5.49 with nt + sc1 (18): streaming the planes
+// through the L2 evicts the kernels' own weight stream.
+#ifndef MNRF_EXP_STORE_AUX
+#define MNRF_EXP_STORE_AUX 2
+#endif
+#ifndef MNRF_EXP_LOAD_AUX
+#define MNRF_EXP_LOAD_AUX 0
+#endif
+constexpr int PL_LOAD_AUX = MNRF_EXP_LOAD_AUX;      // the same operand of the GEMM's LDS-DMA loads of the planes
+constexpr int PL_STORE_AUX = MNRF_EXP_STORE_AUX;
 constexpr int PL_TILE_BYTES = 1024;                  // one plane of one feature block of one sample block
 constexpr int PL_FB_BYTES = 2 * PL_TILE_BYTES;       // [hi tile][lo tile]
 constexpr int PL_SB = 32;                            // samples per sample block = one wave of the field kernels (2 groups x 16)

@@ -63,7 +63,7 @@ __device__ __forceinline__ u32x4 read_operand(const char* tile, int lane8) {
 // tile t (1 KiB, lane-linear) of a contiguous run of tiles: global -> LDS by LDS-DMA
 __device__ __forceinline__ void dma_tile(const char* src, char* dst, int lane16) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane16),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, PL_LOAD_AUX);
 }
 
 // MB: dY blocks per wave row (wn), KB: X blocks per wave column (wk); NA / NX: blocks of the job's operands
