@@ -20,6 +20,14 @@
 #include "../../include/mnrf.h"
 #include "mnrf_error.h"
 
+// per-sample outputs of the matrix-pipe kernel: -DMNRF_EXP_TCNN_OUT_NT stores them non-temporally (experiment: 201 MB of outputs
+// per launch compete with the 53 MB table for the 256 MB Infinity Cache)
+#ifdef MNRF_EXP_TCNN_OUT_NT
+#define TOUT(p, v) __builtin_nontemporal_store((float)(v), (float*)(p))
+#else
+#define TOUT(p, v) (*(p) = (v))
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -618,12 +626,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (!live[gi]) continue;
-            if (A.sigma && g == 0) A.sigma[idx[gi]] = s1[gi][0][0];
+            if (A.sigma && g == 0) TOUT(A.sigma + idx[gi], s1[gi][0][0]);
             if (A.geo_feat) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * g + r;
-                    if (row >= 1) A.geo_feat[idx[gi] * 15 + row - 1] = s1[gi][0][r];
+                    if (row >= 1) TOUT(A.geo_feat + idx[gi] * 15 + row - 1, s1[gi][0][r]);
                 }
             }
         }
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
             for (int gi = 0; gi < NG; ++gi) {
                 const float v0 = o3[gi][0][0], v1 = o3[gi][0][1], v2 = o3[gi][0][2];
                 const float inv = 1.f / sqrtf(fmaxf(v0 * v0 + v1 * v1 + v2 * v2, EPS32));
-                if (live[gi] && g == 0) { float* o = A.pred_normal + idx[gi] * 3; o[0] = v0 * inv; o[1] = v1 * inv; o[2] = v2 * inv; }
+                if (live[gi] && g == 0) { float* o = A.pred_normal + idx[gi] * 3; TOUT(o, v0 * inv); TOUT(o + 1, v1 * inv); TOUT(o + 2, v2 * inv); }
             }
         }
         // ---- mirror probability: 15 -> 32 LeakyReLU(0.01) -> 1 sigmoid, with biases
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
             layer<1, 1>(14, lane, mh, ml, o1);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
-                if (live[gi] && g == 0) A.is_mirror[idx[gi]] = 1.f / (1.f + expf(-(o1[gi][0][0] + ws1[96])));
+                if (live[gi] && g == 0) TOUT(A.is_mirror + idx[gi], 1.f / (1.f + expf(-(o1[gi][0][0] + ws1[96]))));
         }
         // ---- colour: cat[SH4(d), geo_feat] -> 64 -> 64 -> 3 sigmoid; slots 4-7 = SH components 4g .. 4g+3
         if (A.rgb) {
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
                 if (live[gi] && g == 0) {
                     float* o = A.rgb + idx[gi] * 3;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) o[k] = 1.f / (1.f + expf(-o3[gi][0][k]));
+                    for (int k = 0; k < 3; ++k) TOUT(o + k, 1.f / (1.f + expf(-o3[gi][0][k])));
                 }
         }
     }
