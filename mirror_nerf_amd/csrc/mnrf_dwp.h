@@ -41,10 +41,12 @@ namespace mnrf {
 // gradient of 65504 / 16 or more would overflow a plane; the backward kernel raises MNRF_GUARD_SATURATED already there.
 constexpr int PL_BOOST_LOG2 = 4;
 // cache policy of the producers' plane stores (aux operand of raw_buffer_store: 0 default, 2 = non-temporal).  The planes are
-// 2.7 GB per kernel that nothing reads again before the weight-gradient GEMM; the weight stream of the same kernel lives in L2.
+// 2.7 GB per kernel that nothing reads again before the weight-gradient GEMM.
 // Measured (scripts/bench_train.py, alternating libraries on one box): 5.97 ms per step with the default policy, 5.90 with
-// sc0 (1), **5.47-5.55 with nt (2)**, 5.76 with 3, 5.9-6.1 with sc1 (16), 5.49 with nt + sc1 (18): streaming the planes
-// through the L2 evicts the kernels' own weight stream.
+// sc0 (1), **5.47-5.55 with nt (2)**, 5.76 with 3, 5.9-6.1 with sc1 (16), 5.49 with nt + sc1 (18).  Counters
+// (profiles/r03r_store_policy_pmc.txt): same fetched bytes, same L2 hits / misses; the L2's memory-side write requests stall
+// 34-84 % longer with the default policy (lines allocated, written back later), and the weight stream's counted waits sit
+// behind the stores.
 #ifndef MNRF_EXP_STORE_AUX
 #define MNRF_EXP_STORE_AUX 2
 #endif
