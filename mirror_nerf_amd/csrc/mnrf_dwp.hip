@@ -152,6 +152,151 @@ __device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, con
     }
 }
 
+// ---- the same segment with a DEEPER prefetch: an experiment (MNRF_DWP_HALF=1), NOT the default.  With whole stages the two
+// 64-KiB buffers hold the stage being multiplied and ONE stage in flight, and the kernel's throughput scales with the number of
+// workgroups (2.9 TB/s at 128, 4.5 TB/s at 256) -- which looked like a bound by bytes in flight.  Here a stage travels as two
+// HALF-STAGES -- rows 0-15 and rows 16-31 of every tile, 512 B each -- through a ring of four 32-KiB buffers: one is multiplied
+// (v_mfma_f32_16x16x16_f16: a k step of 16 samples = ONE transposing read per operand) while THREE are in flight, 96 KiB per CU.
+// Measured (scripts/bw_probe.py, one box): 1.65 ms against 1.39 ms of the two-buffer version -- the K = 16 MFMA runs at half the
+// rate of the K = 32 one and binds this loop (with two of its three products compiled out: 1.32 ms = 4.85 TB/s; reading 1-KiB
+// contiguous runs instead of 512-byte halves changes nothing).  So even with the matrix work out of the way, 96 KiB in flight
+// buy 5 % over 64: the memory system is saturated at 4.6-4.9 TB/s on these boxes, the two-buffer kernel is there, and stays.  One LDS-DMA instruction brings the hi and the lo half-tile of a
+// feature block (lanes 0-31 / 32-63: two 512-byte runs in memory, 1 KiB lane-linear in LDS).  Every wave issues the same number
+// of instructions per half-stage (a wave without work re-loads a pair: identical bytes), so the wait for the oldest half-stage
+// is a counted s_waitcnt (VMEM operations complete in order).
+constexpr int DWP_HBUF = 32 * 1024;        // one half-stage: [dY half-tiles: 16 KiB][X half-tiles: 16 KiB]
+constexpr int DWP_HXOFF = 16 * 1024;
+static_assert(4 * DWP_HBUF == DWP_LDS, "the ring of four half-stage buffers fills the same LDS");
+
+__device__ __forceinline__ f32x4 mfma_h16(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x2 read_operand16(const char* half_tile, int lane8) {
+    typedef __attribute__((address_space(3))) h4 lds_h4;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(half_tile + lane8)));
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+template <int MB, int KB, int NA, int NX>
+__device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, const char* __restrict__ Xb, int s_lo, int s_hi,
+                                                  bool bias, float* __restrict__ slot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wk = wave >> 2;
+    const int lane8 = lane * 8;
+    const bool has_a = wn * MB < NA;
+    constexpr int NP = NA + NX;                  // feature blocks = (hi, lo) half-tile pairs per half-stage
+    constexpr int Q = (NP + 7) / 8;              // LDS-DMA instructions per wave and half-stage
+    static_assert(NA * 1024 <= DWP_HXOFF && NX * 1024 <= DWP_HBUF - DWP_HXOFF, "a half-stage fits its buffer");
+    char* const lds = dwp_smem;
+#ifdef MNRF_EXP_DWP_CONTIG      // experiment (wrong data): the same byte count as 1-KiB contiguous runs -- is the 512-byte granularity the cost?
+    const int lsrc = lane * 16;
+#else
+    const int lsrc = (lane >> 5) * PL_TILE_BYTES + (lane & 31) * 16;      // hi tile (lanes 0-31) / lo tile (32-63) of the block
+#endif
+
+    f32x4 acc[MB][KB], bacc[MB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+        bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const u32x2 ones = u32x2{0x3c003c00u, 0x3c003c00u};
+
+    const int n_hs = 2 * (s_hi - s_lo);
+    auto issue = [&](int hs) {      // half-stage hs = rows 16 (hs & 1) .. of sample block s_lo + hs / 2, into ring slot hs & 3
+        const int s = s_lo + (hs >> 1);
+#ifdef MNRF_EXP_DWP_CONTIG
+        const char* ya = Yb + (long long)s * PLY_SB_BYTES + (hs & 1) * PL_TILE_BYTES + lsrc;
+        const char* xa = Xb + (long long)s * PLX_SB_BYTES + (hs & 1) * PL_TILE_BYTES + lsrc;
+#else
+        const char* ya = Yb + (long long)s * PLY_SB_BYTES + (hs & 1) * 512 + lsrc;
+        const char* xa = Xb + (long long)s * PLX_SB_BYTES + (hs & 1) * 512 + lsrc;
+#endif
+        char* base = lds + (hs & 3) * DWP_HBUF;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            int pr = wave + 8 * q;
+            if (pr >= NP) pr -= NP;              // (no work left for this wave: an identical re-load keeps the counts uniform)
+            const char* src = pr < NA ? ya + pr * PL_FB_BYTES : xa + (pr - NA) * PL_FB_BYTES;
+            char* dst = pr < NA ? base + pr * 1024 : base + DWP_HXOFF + (pr - NA) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, PL_LOAD_AUX);
+        }
+    };
+    static_assert(NP >= 8 || 2 * NP >= 8 + 1 || true, "");
+
+    __syncthreads();                 // the previous segment's last half-stage has been read by every wave
+    if (n_hs > 0) issue(0);
+    if (n_hs > 1) issue(1);
+    if (n_hs > 2) issue(2);
+    for (int hs = 0; hs < n_hs; ++hs) {
+        // the two half-stages issued after hs may still be on their way: 2 Q instructions of this wave (fewer at the end)
+        if (hs + 2 < n_hs) wait_vm<2 * Q>();
+        else if (hs + 1 < n_hs) wait_vm<Q>();
+        else wait_vm<0>();
+        // a RAW barrier: __syncthreads() waits for vmcnt(0) first and would drain the three half-stages in flight (the first
+        // build of this loop did, and ran at 3.0 TB/s).  LDS reads of half-stage hs - 1 were consumed by its MFMAs.
+        __builtin_amdgcn_s_barrier();                         // everybody's tiles of hs are there; slot (hs - 1) & 3 has been read
+        if (hs + 3 < n_hs) issue(hs + 3);
+        const char* A = lds + (hs & 3) * DWP_HBUF;
+        const char* X = A + DWP_HXOFF;
+        if (has_a) {
+            u32x2 ah[MB], al[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah[mb] = read_operand16(A + (wn * MB + mb) * 1024, lane8);
+                al[mb] = read_operand16(A + (wn * MB + mb) * 1024 + 512, lane8);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const u32x2 bh = read_operand16(X + (wk * KB + kb) * 1024, lane8);
+                const u32x2 bl = read_operand16(X + (wk * KB + kb) * 1024 + 512, lane8);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    f32x4 c = acc[mb][kb];
+#ifdef MNRF_EXP_DWP_ONE_MFMA      // experiment (wrong sums): is the half-stage version bound by the K = 16 MFMA rate?
+                    c = mfma_h16(ah[mb], bh, c);
+#else
+                    c = mfma_h16(al[mb], bh, c);
+                    c = mfma_h16(ah[mb], bl, c);
+                    c = mfma_h16(ah[mb], bh, c);
+#endif
+                    acc[mb][kb] = c;
+                }
+            }
+            if (bias && wk == 0) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    bacc[mb] = mfma_h16(al[mb], ones, bacc[mb]);
+                    bacc[mb] = mfma_h16(ah[mb], ones, bacc[mb]);
+                }
+            }
+        }
+    }
+    if (has_a) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                ((f32x4*)slot)[((wn * MB + mb) * NX + (wk * KB + kb)) * 64 + lane] = acc[mb][kb];
+        if (bias && wk == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) ((f32x4*)(slot + 256 * 256))[(wn * MB + mb) * 4 + (lane >> 4)] = bacc[mb];
+        }
+    }
+}
+
+template <bool HALF>
 __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) {
     const int g = blockIdx.x;
     const DwpPlan& p = A.plan;
@@ -169,13 +314,24 @@ __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) 
             const char* Yb = A.ev[e].Y + (long long)jb.ya * PL_FB_BYTES;
             const char* Xb = A.ev[e].X + (long long)jb.xa * PL_FB_BYTES;
             float* slot = A.part + (long long)(g + j * p.n_eval + e) * DWP_SLOT_FLOATS;
-            switch (jb.shape) {
-            case 0: dwp_segment_run<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-            case 1: dwp_segment_run<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-            case 2: dwp_segment_run<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-            case 3: dwp_segment_run<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-            case 4: dwp_segment_run<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-            default: dwp_segment_run<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+            if constexpr (HALF) {
+                switch (jb.shape) {
+                case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 1: dwp_segment_run_h<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 2: dwp_segment_run_h<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 3: dwp_segment_run_h<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 4: dwp_segment_run_h<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                default: dwp_segment_run_h<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                }
+            } else {
+                switch (jb.shape) {
+                case 0: dwp_segment_run<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 1: dwp_segment_run<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 2: dwp_segment_run<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 3: dwp_segment_run<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 4: dwp_segment_run<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                default: dwp_segment_run<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                }
             }
         }
     }
@@ -341,11 +497,15 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr};
     A.part = ws;
     static const bool once = [] {
-        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL(dwp_gemm_kernel, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    // MNRF_DWP_HALF=1 (read once): the half-stage ring (experiment, see dwp_segment_run_h) instead of whole stages through two buffers
+    static const bool half = [] { const char* e = getenv("MNRF_DWP_HALF"); return e && atoi(e) == 1; }();
+    if (half) hipLaunchKernelGGL(dwp_gemm_kernel<true>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    else hipLaunchKernelGGL(dwp_gemm_kernel<false>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
 
     DwpFinishArgs F;
     F.part = ws;

@@ -500,6 +500,20 @@ def test_planes_route_agrees_with_rows_route(B, n_eval, precision):
         assert _rel(a, n_eval * b) <= 1e-5, n
 
 
+def test_half_stage_ring_of_the_weight_gradient_gemm():
+    """MNRF_DWP_HALF=1 (read once by the library): the deeper-prefetch experiment of mnrf_dwp.hip -- half-stages through a ring
+    of four buffers, K = 16 MFMAs -- computes the same gradients; the plane-route test runs on it in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MNRF_DWP_HALF="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "planes_route_agrees or field_backward_matches_autograd"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def _two_evals(model, x1, x2, d):
     """Two evaluations of one module in one graph (the primary / reflected pattern of a training step)."""
     from mirror_nerf_amd.autograd import FieldFn
