@@ -10,7 +10,7 @@ mkdir -p $OUT
 for tag in default variant; do
   if [ $tag == variant ]; then [ -z "$LIBV" ] && continue; export MNRF_LIB=$GRAFT_REPO_ROOT/$LIBV; else unset MNRF_LIB; fi
   for c in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${tag}_$c -o p -- python scripts/bench_train.py --steps 8 --warmup 2 > $OUT/${tag}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${tag}_$c -o p -- python scripts/bench_train.py --steps 8 --warmup 2 ${BENCH_ARGS:-} > $OUT/${tag}_$c.log 2>&1
   done
 done
 python - "$OUT" <<'PY'
@@ -26,7 +26,7 @@ for tag in ("default", "variant"):
             if row.get("Counter_Name") == c:
                 k = row["Kernel_Name"].split("(")[0][-60:]
                 acc[k] += float(row["Counter_Value"]); n[k] += 1
-        top = sorted(acc.items(), key=lambda kv: -kv[1])[:4]
+        top = sorted(acc.items(), key=lambda kv: -kv[1])[:8]
         print(tag, c, "per launch (KiB for *_SIZE, counts otherwise):", {k: round(v / n[k], 1) for k, v in top}, "launches:", {k: n[k] for k, _ in top})
 PY
 find $OUT -name "*.csv" -size +1M -delete
