@@ -210,7 +210,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()
         elif noise_std != 0:
-            noise = torch.randn(N, S, device=dev) * noise_std            # rendering.py:189
+            noise = torch.randn(N, S, device=dev)                        # rendering.py:189
+            if noise_std != 1:      # (x * 1.0 is x: the training default needs no second kernel)
+                noise = noise * noise_std
         weights, opacity = f(N, S), f(N)
         full = not sigma_only
         has_m, has_n = full and "is_mirror" in o, full and "pred_normal" in o     # optional heads (mirror_nerf.py:80-99)
@@ -265,7 +267,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()
         elif noise_std != 0:
-            noise = torch.randn(N, S, device=dev) * noise_std
+            noise = torch.randn(N, S, device=dev)
+            if noise_std != 1:
+                noise = noise * noise_std
         nrm = normal if compute_normal else None
         if not getattr(model, "predict_mirror_mask", True):     # optional heads: evaluated on zero weights, never read
             mir = None
