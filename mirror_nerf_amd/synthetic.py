@@ -134,3 +134,13 @@ def build_models(dev, tweaks=None, seed=0, names=("coarse", "fine")):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         models[name] = m.to(dev)
     return models, sds
+
+
+def make_tcnn_table(n_entries, seed, scale, keep_levels=None, offsets=None):
+    """Deterministic hash-grid table (n_entries, 2) fp32 for fixtures and tests: uniform(-scale, scale) from numpy's
+    RandomState(seed); with `keep_levels` = k the levels k.. are zero (a random table is white noise at the fine levels:
+    d(output)/d(position) ~ 1e4, which makes the comparison of two fp32 implementations ill-conditioned)."""
+    t = np.random.RandomState(seed).uniform(-scale, scale, (int(n_entries), 2)).astype(np.float32)
+    if keep_levels is not None:
+        t[int(offsets[keep_levels]):] = 0
+    return t

@@ -259,14 +259,17 @@ def _eval_field(w, xyz, dir_emb, n_rays, n_s, sigma_only, compute_normal, n_freq
     """rendering.py:108-179: flatten, repeat the dir embedding, evaluate in chunks."""
     xyz_ = xyz.reshape(-1, 3)
     outs = {}
+    if "encoder.embeddings" in w:      # hash-grid model (train.py:67-99: Embedding(0), so `dir_emb` is the raw direction);
+        fwd = lambda x, so: tcnn_field_forward(w, x, w["_cfg"], so, compute_normal)  # noqa: E731  (`_cfg`: hashgrid_config)
+    else:
+        fwd = lambda x, so: field_forward(w, x, so, compute_normal, n_freqs_xyz)  # noqa: E731
     for i in range(0, xyz_.shape[0], chunk):
         xc = xyz_[i:i + chunk]
         if sigma_only:
-            o = field_forward(w, xc, True, compute_normal, n_freqs_xyz)
+            o = fwd(xc, True)
         else:
             ray_idx = np.arange(i, min(i + chunk, xyz_.shape[0])) // n_s
-            o = field_forward(w, np.concatenate([xc, dir_emb[ray_idx]], 1), False,
-                              compute_normal, n_freqs_xyz)
+            o = fwd(np.concatenate([xc, dir_emb[ray_idx]], 1), False)
         for k, v in o.items():
             if k != "geo_feat":
                 outs.setdefault(k, []).append(v)

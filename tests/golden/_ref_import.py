@@ -121,3 +121,75 @@ def get_hparams(**over):
     for k_, v in over.items():
         setattr(hp, k_, v)
     return hp
+
+
+def install_tcnn():
+    """Stand-ins for the two CUDA-only encoders of models/mirror_nerf_tcnn.py, so that the file itself -- its MLPs (51-149)
+    and `forward` (151-259): the [0,1] mapping, raw sigma = h[...,0], geo_feat = h[...,1:], the four heads, the three
+    `detach` branches, the autograd normal -- imports and runs UNCHANGED in this container (fixtures G17):
+
+    * `tinycudann.Encoding` (mirror_nerf_tcnn.py:39-49; un-vendored, un-pinned, CUDA-only): a torch module that evaluates a
+      multiresolution hash grid from its `params` with the level geometry it is constructed with (n_levels,
+      n_features_per_level, log2_hashmap_size, base_resolution, per_level_scale) -- the restatement in tests/torch_ref.py
+      (`hashgrid_encode`: corner hashing / linear interpolation of models/gridencoder/src/gridencoder.cu:51-272, level
+      sizes of models/gridencoder/grid.py:181-194), float32, twice differentiable.  The ENCODER'S interpolation is therefore
+      NOT pinned by G17 (it is this repository's own reading); everything downstream of it is the reference's code.
+    * `models.shencoder.SHEncoder` (models/encoding.py:71-74; the CUDA extension of models/shencoder/src/shencoder.cu): the
+      degree-4 real spherical harmonics, pinned separately against scipy (tests/test_oracle_golden.py)."""
+    install()
+    import numpy as np
+    import torch
+    from torch import nn
+    from tests import torch_ref as TR
+
+    class Encoding(nn.Module):
+        def __init__(self, n_input_dims, encoding_config, **_kw):
+            super().__init__()
+            c = dict(encoding_config)
+            assert n_input_dims == 3 and c["otype"] == "HashGrid"
+            L, F = int(c["n_levels"]), int(c["n_features_per_level"])
+            offsets, off = [], 0
+            for i in range(L):                                           # grid.py:181-194
+                res = int(np.ceil(c["base_resolution"] * c["per_level_scale"] ** i))
+                n = int(np.ceil(min(2 ** c["log2_hashmap_size"], (res + 1) ** 3) / 8) * 8)
+                offsets.append(off)
+                off += n
+            offsets.append(off)
+            self.encoding_config = c
+            self.cfg = dict(offsets=np.array(offsets, dtype=np.int64), S=float(np.log2(c["per_level_scale"])),
+                            H=int(c["base_resolution"]), n_levels=L, level_dim=F)
+            self.n_output_dims = L * F
+            self.params = nn.Parameter(torch.empty(off * F).uniform_(-1e-4, 1e-4))
+
+        def forward(self, x):
+            out = TR.hashgrid_encode(x, self.params.view(-1, self.cfg["level_dim"]), self.cfg)
+            # `module.double()` runs (the generators' fp32-vs-fp64 noise floors): mirror_nerf_tcnn.py:225-227 calls `.float()`
+            # on this output, which must then keep the float64 values
+            return out.as_subclass(_KeepDouble) if out.dtype == torch.float64 else out
+
+    class _KeepDouble(torch.Tensor):
+        def float(self):
+            return self.as_subclass(torch.Tensor)
+
+    class SHEncoder(nn.Module):
+        def __init__(self, input_dim=3, degree=4):
+            super().__init__()
+            assert input_dim == 3 and degree == 4
+            self.input_dim, self.degree, self.output_dim = input_dim, degree, degree ** 2
+
+        def forward(self, inputs, size=1):
+            return TR.sh4(inputs / size)           # sphere_harmonics.py:83-84
+
+    _stub("tinycudann", Encoding=Encoding)
+    import models  # noqa: F401  (the reference package)
+    _stub("models.shencoder", SHEncoder=SHEncoder)
+
+
+def grid_encoder_class():
+    """models/gridencoder/grid.py's `GridEncoder` with its compiled backend stubbed out: the constructor (level offsets,
+    181-194) is plain Python and is what pins `hashgrid_config`'s table layout."""
+    install()
+    import models  # noqa: F401
+    _stub("models.gridencoder.backend", _backend=None)
+    from models.gridencoder.grid import GridEncoder
+    return GridEncoder

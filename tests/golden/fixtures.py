@@ -63,3 +63,30 @@ def tolerance(key, meta, base=1e-4):
     if key in GRAD_NORMAL_KEYS:
         tol = max(tol, 2e-2)
     return tol
+
+
+# ---- fixtures G17 (tests/golden/make_golden_tcnn.py): the reference's models/mirror_nerf_tcnn.py with stand-in encoders
+TCNN_MLP_NAMES = ("sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight",
+                  "normal_net.0.weight", "normal_net.1.weight", "is_mirror_net.0.weight", "is_mirror_net.0.bias",
+                  "is_mirror_net.2.weight", "is_mirror_net.2.bias")
+
+
+def tcnn_weights(fx, prefix, which=0):
+    """State dict (this repository's names, numpy) of one hash-grid model of a G17 fixture: the stored MLPs + the table
+    rebuilt from its seed; `_cfg` = the level geometry (oracle.hashgrid_config)."""
+    from oracle import mirror_nerf_oracle as O
+    t = fx.meta["table"]
+    cfg = O.hashgrid_config(t["bound"])
+    seed = t["table_seeds"][which] if "table_seeds" in t else t["table_seed"]
+    w = {k: fx.inputs[prefix + k].copy() for k in TCNN_MLP_NAMES}
+    w["encoder.embeddings"] = W.make_tcnn_table(cfg["offsets"][-1], seed, t["table_scale"], t.get("keep_levels"), cfg["offsets"])
+    w["_cfg"] = cfg
+    return w
+
+
+def table_grad_summary(g, cfg, idx):
+    """Per-level [sum, norm, absmax] of a table gradient (n_entries, 2) and its values at the fixture's flat indices."""
+    g = np.asarray(g, np.float64).reshape(-1, 2)
+    lv = np.stack([[g[a:b].sum(), np.sqrt((g[a:b] ** 2).sum()), np.abs(g[a:b]).max()]
+                   for a, b in zip(cfg["offsets"][:-1], cfg["offsets"][1:])])
+    return lv, g.reshape(-1)[idx], int(np.count_nonzero(g))

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Fixtures G17: models/mirror_nerf_tcnn.py (BASELINE config 5) run UNCHANGED in this container.
+
+tinycudann and the CUDA spherical-harmonics extension are absent, so `_ref_import.install_tcnn()` replaces exactly those two
+(`tinycudann.Encoding` -> a torch hash grid evaluated from its `params`; `models.shencoder.SHEncoder` -> the SH-4 closed form
+pinned to scipy).  Everything else that runs here is the reference's own code: the MLP definitions (mirror_nerf_tcnn.py:51-149),
+`forward` (151-259: the [0,1] mapping, sigma = h[...,0] raw, geo_feat = h[...,1:], colour / normal / mirror heads, the three
+detach branches, the autograd normal through utils/func.py:10-25), `models/rendering.py:render_rays`, `train.NeRFSystem`
+(`model_type="nerf_tcnn"`, train.py:67-99, 102-348) and torch.autograd for every gradient.  So G17 pins everything DOWNSTREAM
+of the encoder's interpolation; the interpolation itself stays unpinned (tinycudann absent).
+
+    g17_grid_offsets           models/gridencoder/grid.py:181-194 (GridEncoder.__init__, backend stubbed): level offsets
+    g17_tcnn_field_b{1,6}      forward: full + compute_normal, sigma_only
+    g17_tcnn_field_grads       gradients of <cotangent, outputs> for: no flag / detach_density_for_normal_loss /
+                               detach_density_for_mask_loss / detach_density_outside_mirror_for_mask_loss / second order
+                               (a cotangent on the autograd normal)
+    g17_tcnn_render_{train,test}   render_rays 64 + 64 with a coarse and a fine hash-grid model
+    g17_tcnn_train_grads[_full]    NeRFSystem.forward (GT mask, compacted reflected rays, blend) + loss + every gradient
+
+The 49 MB table is not stored: it is numpy's RandomState(seed).uniform (mirror_nerf_amd.synthetic.make_tcnn_table); the small
+MLPs are stored.  Table gradients are stored as per-level norms plus 4096 (index, value) samples of the touched entries.
+
+Build-container only:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_tcnn.py"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.dont_write_bytecode = True
+
+import _ref_import as R  # noqa: E402
+
+R.install_tcnn()
+import torch  # noqa: E402
+import make_golden as MG  # noqa: E402
+import weights as W  # noqa: E402
+from make_golden_loss import first_order_loss, full_loss  # noqa: E402
+from models.mirror_nerf import Embedding  # noqa: E402  (reference)
+from models.mirror_nerf_tcnn import MirrorNeRFTcnn  # noqa: E402  (reference)
+from models.rendering import render_rays as ref_render_rays  # noqa: E402
+from oracle import mirror_nerf_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+MLP_NAMES = ("sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight",
+             "normal_net.0.weight", "normal_net.1.weight", "is_mirror_net.0.weight", "is_mirror_net.0.bias",
+             "is_mirror_net.2.weight", "is_mirror_net.2.bias")
+
+
+def ref_model(bound, seed, table_seed, table_scale, keep_levels=None, sigma_gain=1.0):
+    """The reference module (constructed as train.py:71-82 does) with a seeded table; returns it + the numpy weights under
+    this repository's names (`encoder.embeddings` (n,2) instead of tinycudann's flat `encoder.params`)."""
+    torch.manual_seed(seed)
+    m = MirrorNeRFTcnn(encoding="hashgrid", bound=bound, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=10,
+                       bg_radius=False, predict_normal=True, predict_mirror_mask=True)
+    cfg = O.hashgrid_config(bound)
+    # the geometry the reference handed to tinycudann (mirror_nerf_tcnn.py:36-49) is the one hashgrid_config derives
+    enc = m.encoder.encoding_config
+    assert (enc["n_levels"], enc["n_features_per_level"], enc["log2_hashmap_size"], enc["base_resolution"]) == (16, 2, 19, 16)
+    assert abs(np.log2(enc["per_level_scale"]) - cfg["S"]) < 1e-15 and np.array_equal(m.encoder.cfg["offsets"], cfg["offsets"])
+    table = W.make_tcnn_table(cfg["offsets"][-1], table_seed, table_scale, keep_levels, cfg["offsets"])
+    with torch.no_grad():
+        m.encoder.params.copy_(torch.from_numpy(table.reshape(-1)))
+        m.sigma_net[1].weight[0] *= sigma_gain
+    w = {k: v.detach().numpy().copy() for k, v in m.state_dict().items() if k != "encoder.params"}
+    assert tuple(w) == MLP_NAMES, tuple(w)
+    w["encoder.embeddings"] = table
+    w["_cfg"] = cfg
+    return m, w, cfg
+
+
+def table_meta(bound, table_seed, table_scale, keep_levels=None, sigma_gain=1.0):
+    return dict(bound=bound, table_seed=table_seed, table_scale=table_scale, keep_levels=keep_levels, sigma_gain=sigma_gain)
+
+
+def mlp_arrays(w, prefix=""):
+    return {prefix + k: w[k] for k in MLP_NAMES}
+
+
+def table_grad_summary(g, cfg, n_pick=4096):
+    """g (n_entries, 2) -> per-level [sum, norm, absmax] (16,3) + sampled (flat index, value) pairs of the touched entries."""
+    g = np.asarray(g, np.float64).reshape(-1, 2)
+    lv = np.stack([[g[a:b].sum(), np.sqrt((g[a:b] ** 2).sum()), np.abs(g[a:b]).max()]
+                   for a, b in zip(cfg["offsets"][:-1], cfg["offsets"][1:])])
+    flat = g.reshape(-1)
+    nz = np.flatnonzero(flat)
+    pick = nz[np.linspace(0, len(nz) - 1, min(n_pick, len(nz))).astype(np.int64)] if len(nz) else nz
+    return lv, pick.astype(np.int64), flat[pick], len(nz)
+
+
+def points(bound, B, seed, n_out=6):
+    rs = np.random.RandomState(seed)
+    xyz = rs.uniform(-bound, bound, (B, 3)).astype(np.float32)
+    xyz[:n_out] *= 1.5                      # a few samples outside the box
+    d = rs.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return np.concatenate([xyz, d], 1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ grid.py offsets
+def grid_offsets():
+    GE = R.grid_encoder_class()
+    outs, meta = {}, {"bounds": [1.0, 2.0, 6.0]}
+    for b in meta["bounds"]:
+        pls = float(np.exp2(np.log2(2048 * b / 16) / 15))        # mirror_nerf_tcnn.py:38
+        g = GE(input_dim=3, num_levels=16, level_dim=2, per_level_scale=pls, base_resolution=16, log2_hashmap_size=19,
+               gridtype="hash", align_corners=False)
+        ref = g.offsets.numpy().astype(np.int64)
+        assert np.array_equal(ref, O.hashgrid_config(b)["offsets"]), b
+        assert tuple(g.embeddings.shape) == (int(ref[-1]), 2)
+        outs[f"offsets_b{b:g}"] = ref
+    MG.save("g17_grid_offsets", meta, {}, outs)
+
+
+# ------------------------------------------------------------------------------------------------ forward
+def field_case(name, bound, B, seed):
+    tm = table_meta(bound, 100 + seed, 0.5)
+    m, w, cfg = ref_model(bound, seed, tm["table_seed"], tm["table_scale"])
+    x6 = points(bound, B, seed)
+    full = MG.to_np(m(torch.from_numpy(x6.copy()), compute_normal=True))
+    with torch.no_grad():
+        so = MG.to_np(m(torch.from_numpy(x6[:, :3].copy()), compute_normal=False, sigma_only=True))
+    assert full["sigma"].shape == (B,) and full["is_mirror"].shape == (B, 1) and "rgb" not in so and "pred_normal" in so
+    orc = O.tcnn_field_forward(w, x6, cfg, False, True)
+    for k in ("sigma", "geo_feat", "rgb", "is_mirror", "pred_normal", "normal"):
+        d = np.abs(orc[k].reshape(full[k].shape) - full[k])
+        print(f"    {name} oracle vs reference {k:12s} max {d.max():.2e} median {np.median(d):.2e}")
+    # fp32-vs-fp64 of the reference itself (normal keys: noise floor of l2n(-grad))
+    m.double()
+    f64 = MG.to_np(m(torch.from_numpy(x6.copy()).double(), compute_normal=True))
+    floor = {k: float(np.max(np.abs(f64[k] - full[k]))) for k in full}
+    print("    reference fp32 vs fp64:", {k: f"{v:.1e}" for k, v in floor.items()})
+    outs = {f"full__{k}": v for k, v in full.items()}
+    outs.update({f"sigma_only__{k}": v for k, v in so.items()})
+    MG.save(name, dict(table=tm, seed=seed, floor=floor), dict(x6=x6, **mlp_arrays(w, "w__")), outs)
+
+
+def field_grads(name, bound, B, seed):
+    """d <cot, out> / d (every parameter, x6) from the reference's autograd for each of the gradient-steering options of
+    mirror_nerf_tcnn.py:186-215, and the second-order term (a cotangent on `normal`, 172-180)."""
+    tm = table_meta(bound, 100 + seed, 0.3, keep_levels=8)
+    m, w, cfg = ref_model(bound, seed, tm["table_seed"], tm["table_scale"], tm["keep_levels"])
+    x6 = points(bound, B, seed, n_out=4)
+    rs = np.random.RandomState(seed + 1)
+    cot = {"sigma": rs.normal(size=B), "rgb": rs.normal(size=(B, 3)), "pred_normal": rs.normal(size=(B, 3)),
+           "is_mirror": rs.normal(size=(B, 1)), "normal": rs.normal(size=(B, 3))}
+    cot["is_mirror"] *= 50.0      # (the mirror head's pull on geo_feat is small: sigmoid' x two small matrices; weigh it up so
+    cot = {k: v.astype(np.float32) for k, v in cot.items()}       # that the two mask options visibly move the gradients)
+    inside = (rs.uniform(size=B) < 0.4).astype(np.float32)            # per-sample GT mirror mask of the `outside` option
+    variants = {"plain": {}, "detach_normal": dict(detach_density_for_normal_loss=True),
+                "detach_mask": dict(detach_density_for_mask_loss=True),
+                "detach_outside": dict(detach_density_outside_mirror_for_mask_loss=True, mirror_mask=torch.from_numpy(inside)),
+                "second_order": {}}
+    outs, base = {}, None
+    for vname, kw in variants.items():
+        second = vname == "second_order"
+        m.zero_grad()
+        x = torch.from_numpy(x6.copy()).requires_grad_(True)
+        o = m(x, compute_normal=second, **kw)
+        keys = ("sigma", "normal") if second else ("sigma", "rgb", "pred_normal", "is_mirror")
+        loss = sum((o[k] * torch.from_numpy(cot[k])).sum() for k in keys)
+        loss.backward()
+        g = {k: (p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)) for k, p in m.named_parameters()}
+        tg = g.pop("encoder.params").reshape(-1, 2)
+        lv, idx, val, n_nz = table_grad_summary(tg, cfg)
+        outs.update({f"{vname}__grad__{k}": v for k, v in g.items()})
+        outs.update({f"{vname}__table_levels": lv, f"{vname}__table_idx": idx, f"{vname}__table_val": val,
+                     f"{vname}__table_nnz": np.array(n_nz), f"{vname}__grad__x6": x.grad.numpy().copy(),
+                     f"{vname}__loss": np.array(loss.item())})
+        if vname == "plain":
+            base = dict(g, table=tg)
+        elif not second:      # every option must move some gradient of the reference, or the fixture pins nothing
+            moved = max(float(np.abs(g[k] - base[k]).max() / (np.abs(base[k]).max() + 1e-30)) for k in g)
+            tmoved = float(np.abs(tg - base["table"]).max() / np.abs(base["table"]).max())
+            print(f"    {vname}: moves the reference's MLP gradients by {moved:.0%}, the table gradient by {tmoved:.0%}")
+            assert moved > 0.01 and tmoved > 0.01          # (the GPU test holds these gradients to ~1e-4 of their scale)
+        print(f"    {vname}: loss {loss.item():.5f}, touched table values {n_nz}")
+    MG.save(name, dict(table=tm, seed=seed), dict(x6=x6, inside=inside, **{f"cot__{k}": v for k, v in cot.items()},
+                                                  **mlp_arrays(w, "w__")), outs)
+
+
+# ------------------------------------------------------------------------------------------------ render_rays
+# bound 6 as BASELINE config 5 has it, the camera of SURVEY 8d.  Only the five coarsest levels carry values and the density row
+# has a gain of 10: a random table is white noise at the fine levels (d output / d position ~ 1e4), where the reference's own
+# fp32 and fp64 runs differ by 37 % in some gradients (measured with 8 levels at gain 10); with these values they agree to 2e-3
+RENDER = dict(bound=6.0, keep_levels=5, table_scale=0.1, sigma_gain=10.0)
+
+
+def pair(seed):
+    mods, ws = [], []
+    for i in range(2):
+        m, w, cfg = ref_model(RENDER["bound"], seed + i, 200 + seed + i, RENDER["table_scale"], RENDER["keep_levels"],
+                              RENDER["sigma_gain"])
+        mods.append(m)
+        ws.append(w)
+    return mods, ws, cfg
+
+
+def render_case(name, test_time, n_rays=96, seed=31):
+    mods, ws, cfg = pair(seed)
+    rays = MG.pick_rays(n_rays, seed)
+    emb = {"xyz": Embedding(0), "dir": Embedding(0)}                                   # train.py:69-70
+    res = MG.to_np(ref_render_rays({"coarse": mods[0], "fine": mods[1]}, emb, torch.from_numpy(rays), 64, False, 0, 0, 64,
+                                   32768, False, test_time, compute_normal=not test_time))
+    orc = O.render_rays({"coarse": ws[0], "fine": ws[1]}, {"xyz": 0, "dir": 0}, rays, 64, False, 0, 0, 64, 32768, False,
+                        test_time, compute_normal=not test_time)
+    MG.report(name, res, orc, skip=("z_vals_fine", "weights_fine", "pred_normal_fine", "normal_fine"))
+    print(f"    opacity_fine: mean {res['opacity_fine'].mean():.3f}, rays above 0.9: {(res['opacity_fine'] > 0.9).mean():.0%}")
+    for mm in mods:
+        mm.double()
+    r64 = MG.to_np(ref_render_rays({"coarse": mods[0], "fine": mods[1]}, emb, torch.from_numpy(rays).double(), 64, False, 0, 0,
+                                   64, 32768, False, test_time, compute_normal=not test_time))
+    floor = {k: float(np.max(np.abs(r64[k] - res[k]))) if res[k].size else 0.0 for k in res}
+    print("    reference fp32 vs fp64 > 2e-5:", {k: f"{v:.1e}" for k, v in floor.items() if v > 2e-5})
+    meta = dict(table=dict(RENDER, seeds=[seed, seed + 1], table_seeds=[200 + seed, 201 + seed]), floor=floor,
+                test_time=test_time)
+    ins = dict(rays=rays, **mlp_arrays(ws[0], "coarse__"), **mlp_arrays(ws[1], "fine__"))
+    MG.save(name, meta, ins, res, keep_per_sample=False)
+
+
+# ------------------------------------------------------------------------------------------------ NeRFSystem + gradients
+def train_case(name, loss_fn, n_rays=64, seed=41):
+    import train as ref_train
+    hp = R.get_hparams(model_type="nerf_tcnn", bound=RENDER["bound"], predict_normal=True, predict_mirror_mask=True,
+                       trace_secondary_rays=True, N_samples=64, N_importance=64, perturb=0, noise_std=0,
+                       only_trace_rays_in_mirrors=True, max_recursive_level=1)
+    system = ref_train.NeRFSystem(hp)
+    assert type(system.nerf_coarse) is MirrorNeRFTcnn and system.embedding_xyz.N_freqs == 0
+    mods, ws, cfg = pair(seed)
+    for mod, src in ((system.nerf_coarse, mods[0]), (system.nerf_fine, mods[1])):
+        mod.load_state_dict(src.state_dict())
+    system.train_dataset = types.SimpleNamespace(white_back=False)
+    rays = MG.pick_rays(n_rays, seed)
+    rs = np.random.RandomState(seed + 2)
+    gt = (rs.uniform(size=n_rays) < 0.3).astype(np.float32)
+    target = rs.uniform(size=(n_rays, 3)).astype(np.float32)
+
+    def run(dt):
+        system.zero_grad()
+        t = lambda a: torch.from_numpy(a.copy()).to(dt)  # noqa: E731
+        res = system(t(rays), {"mirror_mask": t(gt), "is_eval": False, "train_geometry_stage": False})
+        loss = loss_fn(res, t(target), t(gt))
+        loss.backward()
+        grads = {f"{mn}__{pn_}": (p_.grad.detach().numpy().copy() if p_.grad is not None else np.zeros(p_.shape))
+                 for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)) for pn_, p_ in mod.named_parameters()}
+        return MG.to_np(res), float(loss.item()), grads
+
+    ref, loss, g32 = run(torch.float32)
+    hp_o = dict(N_samples=64, use_disp=False, perturb=0, noise_std=0, N_importance=64, chunk=hp.chunk,
+                trace_secondary_rays=True, only_one_field=False, max_recursive_level=1, only_trace_rays_in_mirrors=True,
+                for_vis=False)
+    orc = O.render_train({"coarse": ws[0], "fine": ws[1]}, {"xyz": 0, "dir": 0}, rays, hp_o,
+                         {"mirror_mask": gt.copy(), "is_eval": False, "train_geometry_stage": False})
+    MG.report(name, ref, orc, skip=("z_vals_fine", "weights_fine", "pred_normal_fine", "normal_fine"))
+    n_refl = int((ref["rgb_fine_direct"] != ref["rgb_fine"]).any(-1).sum())
+    print(f"    rays whose colour changed by reflection: {n_refl}/{n_rays}; loss {loss:.6f}")
+    assert n_refl > 0
+    system.double()
+    res64, loss64, g64 = run(torch.float64)
+    floor = {k: float(np.max(np.abs(res64[k] - ref[k]))) if ref[k].size else 0.0 for k in ref}
+    gfl = {k: float(np.abs(g32[k] - g64[k]).max() / np.abs(g64[k]).max()) for k in g64 if np.abs(g64[k]).max() > 0}
+    gfloor = max(gfl.values())
+    print("    per-tensor gradient floors > 1e-3:", {k: f"{v:.1e}" for k, v in gfl.items() if v > 1e-3})
+    print(f"    reference fp32-vs-fp64: forward floor > 2e-5 {({k: f'{v:.1e}' for k, v in floor.items() if v > 2e-5})}, "
+          f"gradient floor {gfloor:.2e}, loss {abs(loss - loss64):.1e}")
+    outs = dict(ref)
+    outs["loss"] = np.array(loss)
+    for k, g in g32.items():
+        mn, pn_ = k.split("__")
+        if pn_ == "encoder.params":
+            lv, idx, val, n_nz = table_grad_summary(g, cfg)
+            outs.update({f"table_levels__{mn}": lv, f"table_idx__{mn}": idx, f"table_val__{mn}": val,
+                         f"table_nnz__{mn}": np.array(n_nz)})
+        else:
+            outs[f"grad__{mn}__{pn_}"] = g
+    meta = dict(table=dict(RENDER, seeds=[seed, seed + 1], table_seeds=[200 + seed, 201 + seed]), hp=hp_o, floor=floor,
+                grad_floor=gfloor, grad_floors=gfl, loss=loss_fn.__name__)
+    ins = dict(rays=rays, gt_mask=gt, target=target, **mlp_arrays(ws[0], "coarse__"), **mlp_arrays(ws[1], "fine__"))
+    MG.save(name, meta, ins, outs, keep_per_sample=False)
+
+
+if __name__ == "__main__":
+    grid_offsets()
+    field_case("g17_tcnn_field_b1", 1.0, 400, 3)
+    field_case("g17_tcnn_field_b6", 6.0, 400, 4)
+    field_grads("g17_tcnn_field_grads", 1.0, 300, 5)
+    render_case("g17_tcnn_render_train", False)
+    render_case("g17_tcnn_render_test", True)
+    train_case("g17_tcnn_train_grads", first_order_loss)
+    train_case("g17_tcnn_train_grads_full", full_loss)

@@ -171,7 +171,105 @@ def test_synthetic_rays_shape_and_norm():
     assert np.all(rays[:, 6] == np.float32(0.05)) and np.all(rays[:, 7] == 8)
 
 
-# ---- a15 (parity unpinned): internal consistency of the hash-grid restatement
+# ---- a15: fixtures G17 = the reference's models/mirror_nerf_tcnn.py run unchanged over stand-in encoders
+#      (tests/golden/make_golden_tcnn.py): everything downstream of the encoder's interpolation is pinned
+def test_g17_grid_offsets():
+    """Level offsets of the table against models/gridencoder/grid.py:181-194 (GridEncoder.__init__ run with its backend
+    stubbed) at the per_level_scale of mirror_nerf_tcnn.py:38 -- oracle and product."""
+    from mirror_nerf_amd.mirror_nerf_tcnn import hashgrid_config
+    fx = FX.Fixture("g17_grid_offsets")
+    for b in fx.meta["bounds"]:
+        want = fx.outputs[f"offsets_b{b:g}"]
+        assert np.array_equal(O.hashgrid_config(b)["offsets"], want)
+        assert np.array_equal(hashgrid_config(b)["offsets"], want)
+        assert hashgrid_config(b)["S"] == O.hashgrid_config(b)["S"]
+
+
+@pytest.mark.parametrize("name", ["g17_tcnn_field_b1", "g17_tcnn_field_b6"])
+def test_g17_tcnn_field(name):
+    fx = FX.Fixture(name)
+    w = FX.tcnn_weights(fx, "w__")
+    x6 = fx.inputs["x6"]
+    full = O.tcnn_field_forward(w, x6, w["_cfg"], False, True)
+    so = O.tcnn_field_forward(w, x6[:, :3], w["_cfg"], True, False)
+    assert set(so) == {"sigma", "geo_feat", "pred_normal"}           # pred_normal also when sigma_only (mirror_nerf_tcnn.py:184-192)
+    for k, want in fx.outputs.items():
+        mode, key = k.split("__")
+        got = (full if mode == "full" else so)[key].reshape(want.shape)
+        err = float(np.max(np.abs(got - want)))
+        assert err <= (2e-6 if key in ("sigma", "geo_feat", "rgb", "is_mirror") else 5e-6), (k, err)
+
+
+@pytest.mark.parametrize("name", ["g17_tcnn_render_train", "g17_tcnn_render_test"])
+def test_g17_tcnn_render_rays(name):
+    fx = FX.Fixture(name)
+    ws = {"coarse": FX.tcnn_weights(fx, "coarse__", 0), "fine": FX.tcnn_weights(fx, "fine__", 1)}
+    tt = fx.meta["test_time"]
+    got = O.render_rays(ws, {"xyz": 0, "dir": 0}, fx.inputs["rays"], 64, False, 0, 0, 64, 32768, False, tt, compute_normal=not tt)
+    n = 0
+    for k, want in fx.outputs.items():
+        if k in FX.PER_SAMPLE_FINE:
+            continue
+        err = float(np.max(np.abs(got[k].astype(np.float64) - want))) if want.size else 0.0
+        assert err <= FX.tolerance(k, fx.meta), (k, err)
+        n += 1
+    assert n >= (8 if tt else 18)
+
+
+@pytest.mark.parametrize("name", ["g17_tcnn_train_grads"])
+def test_g17_tcnn_train_forward(name):
+    fx = FX.Fixture(name)
+    ws = {"coarse": FX.tcnn_weights(fx, "coarse__", 0), "fine": FX.tcnn_weights(fx, "fine__", 1)}
+    got = O.render_train(ws, {"xyz": 0, "dir": 0}, fx.inputs["rays"], fx.meta["hp"],
+                         {"mirror_mask": fx.inputs["gt_mask"].copy(), "is_eval": False, "train_geometry_stage": False})
+    n = 0
+    for k, want in fx.outputs.items():
+        if k == "loss" or k.startswith(("grad__", "table_")) or k in FX.PER_SAMPLE_FINE:
+            continue
+        err = float(np.max(np.abs(got[k].astype(np.float64) - want))) if want.size else 0.0
+        assert err <= FX.tolerance(k, fx.meta), (k, err)
+        n += 1
+    assert n >= 20
+
+
+@pytest.mark.parametrize("variant", ["plain", "detach_normal", "detach_mask", "detach_outside", "second_order"])
+def test_g17_torch_restatement_gradients(variant):
+    """tests/torch_ref.tcnn_field -- the autograd yardstick of the GPU gradient tests -- against the reference's own
+    gradients: which head sees geo_feat.detach() under which flag, the raw sigma, the biased mirror head, the second-order
+    term through normal = l2n(-d sigma / dx)."""
+    import torch
+    from tests import torch_ref as TR
+    fx = FX.Fixture("g17_tcnn_field_grads")
+    w = FX.tcnn_weights(fx, "w__")
+    cfg = w.pop("_cfg")
+    wt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    x = torch.from_numpy(fx.inputs["x6"].copy()).requires_grad_(True)
+    cot = {k[5:]: torch.from_numpy(v) for k, v in fx.inputs.items() if k.startswith("cot__")}
+    if variant == "second_order":
+        sigma, _rgb, _pn, _m, normal = TR.tcnn_field_with_normal(wt, x, cfg)
+        loss = (sigma * cot["sigma"]).sum() + (normal * cot["normal"]).sum()
+    else:
+        inside = torch.from_numpy(fx.inputs["inside"]).bool()
+        dm = {"detach_mask": True, "detach_outside": ~inside}.get(variant)
+        sigma, rgb, pn, m = TR.tcnn_field(wt, x, cfg, detach_normal=variant == "detach_normal", detach_mirror=dm)
+        loss = (sigma * cot["sigma"]).sum() + (rgb * cot["rgb"]).sum() + (pn * cot["pred_normal"]).sum() \
+            + (m[:, None] * cot["is_mirror"]).sum()
+    loss.backward()
+    o = fx.outputs
+    assert abs(loss.item() - float(o[f"{variant}__loss"])) <= 1e-5 * abs(float(o[f"{variant}__loss"]))
+    for k in FX.TCNN_MLP_NAMES:
+        want = o[f"{variant}__grad__{k}"]
+        g = wt[k].grad.numpy() if wt[k].grad is not None else np.zeros_like(want)
+        assert np.max(np.abs(g - want)) <= 2e-5 * np.abs(want).max() + 1e-9, (k, np.max(np.abs(g - want)), np.abs(want).max())
+    lv, val, nnz = FX.table_grad_summary(wt["encoder.embeddings"].grad.numpy(), cfg, o[f"{variant}__table_idx"])
+    assert nnz == int(o[f"{variant}__table_nnz"])
+    assert np.max(np.abs(val - o[f"{variant}__table_val"])) <= 2e-5 * np.abs(o[f"{variant}__table_val"]).max()
+    assert np.max(np.abs(lv - o[f"{variant}__table_levels"])) <= 2e-5 * np.abs(o[f"{variant}__table_levels"]).max()
+    gx = o[f"{variant}__grad__x6"]
+    assert np.max(np.abs(x.grad.numpy() - gx)) <= 1e-4 * np.abs(gx).max()
+
+
+# ---- a15 (encoder interpolation: parity unpinned): internal consistency of the hash-grid restatement
 def test_hashgrid_restatement_is_self_consistent():
     cfg = O.hashgrid_config(bound=6.0)
     assert int(cfg["offsets"][-1]) == 6616280            # SURVEY 2.1: table size at bound 6

@@ -96,31 +96,14 @@ def blend(base, sec, mask, compact):
     return m * part + (1 - m) * base
 
 
-def tcnn_field_with_normal(w, x6, cfg):
-    """tcnn_field plus normal = l2n(-d sigma/dx) built with create_graph=True (models/mirror_nerf_tcnn.py:172-218,
-    utils/func.py:10-25): torch's double backward through it is the reference for the second-order kernel."""
-    if not x6.requires_grad:
-        x6 = x6.requires_grad_(True)
-    sigma, rgb, pn, m = tcnn_field(w, x6, cfg)
-    (grad,) = torch.autograd.grad(sigma, x6, torch.ones_like(sigma), create_graph=True, retain_graph=True)
-    return sigma, rgb, pn, m, l2n(-grad[:, :3])
-
-
-def tcnn_field(w, x6, cfg, detach_normal=False, detach_mirror=None):
-    """MirrorNeRFTcnn.forward (models/mirror_nerf_tcnn.py:220-259) with torch ops: the hash-grid cells and interpolation
-    weights follow the oracle (`hashgrid_encode` / `_grid_index`), the table look-up is a differentiable gather.
-    w: dict of torch tensors (state_dict names), x6 (B,6) = [xyz, raw direction].  Returns sigma (B), rgb, pred_normal,
-    is_mirror (B)."""
+def hashgrid_encode(x01, table, cfg):
+    """Multiresolution hash encoding with torch ops (differentiable in `table` and, through the interpolation weights, in
+    `x01`; twice differentiable): cells, hashing and level geometry follow the oracle (`hashgrid_encode` / `_grid_index`,
+    i.e. models/gridencoder/src/gridencoder.cu:51-272), the table look-up is a gather.  x01 (B,3) fp32 in [0,1];
+    table (n_entries, 2).  Returns (B, 2 * n_levels), level-major."""
     import numpy as np
     from oracle import mirror_nerf_oracle as O
-    xyz, d = x6[:, :3], x6[:, 3:6]
-    bound = cfg["bound"]
-    # cell coordinates in fp32 like the kernel (a cell of the finest level is 2e-4 of the box: fp64 coordinates would
-    # differ from the kernel's by 1e-4 of a cell); everything after the interpolation weights runs in the dtype of w
-    xf = xyz.float()
-    x01 = (xf + bound) / torch.full_like(xf, 2 * bound)     # a tensor divisor: torch turns "/ scalar" into "* (1/scalar)" on the GPU
     oob = ((x01 < 0) | (x01 > 1)).any(-1)
-    table = w["encoder.embeddings"]
     feats = []
     for lv in range(cfg["n_levels"]):
         off0, off1 = int(cfg["offsets"][lv]), int(cfg["offsets"][lv + 1])
@@ -138,25 +121,54 @@ def tcnn_field(w, x6, cfg, detach_normal=False, detach_mirror=None):
                 bit = (c >> a) & 1
                 wgt = wgt * (fr[:, a] if bit else 1 - fr[:, a])
                 loc[:, a] = pgi[:, a] + np.uint32(bit)
-            idx = torch.from_numpy(O._grid_index(loc, off1 - off0, res)).to(x6.device) + off0
+            idx = torch.from_numpy(O._grid_index(loc, off1 - off0, res)).to(x01.device) + off0
             acc = acc + wgt[:, None] * table[idx]
         feats.append(torch.where(oob[:, None], torch.zeros_like(acc), acc))
-    enc = torch.cat(feats, -1)
-    h = torch.relu(enc @ w["sigma_net.0.weight"].T) @ w["sigma_net.1.weight"].T
-    sigma, geo = h[:, 0], h[:, 1:]
-    # the --detach_density_* options (models/mirror_nerf_tcnn.py:186-215): detach_mirror = True (all samples) or a (B,) bool
-    # tensor of the samples whose mirror head sees geo_feat.detach()
-    geo_n = geo.detach() if detach_normal else geo
-    pn = l2n(torch.relu(geo_n @ w["normal_net.0.weight"].T) @ w["normal_net.1.weight"].T)
+    return torch.cat(feats, -1)
+
+
+def sh4(d):
+    """Real spherical harmonics of degree 4 (16 values) of the raw direction: models/shencoder/src/shencoder.cu:49-79."""
     X, Y, Z = d[:, 0], d[:, 1], d[:, 2]
     xy, xz, yz, x2, y2, z2 = X * Y, X * Z, Y * Z, X * X, Y * Y, Z * Z
-    sh = torch.stack([
+    return torch.stack([
         torch.full_like(X, 0.28209479177387814), -0.48860251190291987 * Y, 0.48860251190291987 * Z, -0.48860251190291987 * X,
         1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
         -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
         0.59004358992664352 * Y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * Z, 0.45704579946446572 * Y * (1.0 - 5.0 * z2),
         0.3731763325901154 * Z * (5.0 * z2 - 3.0), 0.45704579946446572 * X * (1.0 - 5.0 * z2),
         1.4453057213202769 * Z * (x2 - y2), 0.59004358992664352 * X * (-x2 + 3.0 * y2)], -1)
+
+
+def tcnn_field_with_normal(w, x6, cfg):
+    """tcnn_field plus normal = l2n(-d sigma/dx) built with create_graph=True (models/mirror_nerf_tcnn.py:172-218,
+    utils/func.py:10-25): torch's double backward through it is the reference for the second-order kernel."""
+    if not x6.requires_grad:
+        x6 = x6.requires_grad_(True)
+    sigma, rgb, pn, m = tcnn_field(w, x6, cfg)
+    (grad,) = torch.autograd.grad(sigma, x6, torch.ones_like(sigma), create_graph=True, retain_graph=True)
+    return sigma, rgb, pn, m, l2n(-grad[:, :3])
+
+
+def tcnn_field(w, x6, cfg, detach_normal=False, detach_mirror=None):
+    """MirrorNeRFTcnn.forward (models/mirror_nerf_tcnn.py:220-259) with torch ops: the hash-grid cells and interpolation
+    weights follow the oracle (`hashgrid_encode` / `_grid_index`), the table look-up is a differentiable gather.
+    w: dict of torch tensors (state_dict names), x6 (B,6) = [xyz, raw direction].  Returns sigma (B), rgb, pred_normal,
+    is_mirror (B)."""
+    xyz, d = x6[:, :3], x6[:, 3:6]
+    bound = cfg["bound"]
+    # cell coordinates in fp32 like the kernel (a cell of the finest level is 2e-4 of the box: fp64 coordinates would
+    # differ from the kernel's by 1e-4 of a cell); everything after the interpolation weights runs in the dtype of w
+    xf = xyz.float()
+    x01 = (xf + bound) / torch.full_like(xf, 2 * bound)     # a tensor divisor: torch turns "/ scalar" into "* (1/scalar)" on the GPU
+    enc = hashgrid_encode(x01, w["encoder.embeddings"], cfg)
+    h = torch.relu(enc @ w["sigma_net.0.weight"].T) @ w["sigma_net.1.weight"].T
+    sigma, geo = h[:, 0], h[:, 1:]
+    # the --detach_density_* options (models/mirror_nerf_tcnn.py:186-215): detach_mirror = True (all samples) or a (B,) bool
+    # tensor of the samples whose mirror head sees geo_feat.detach()
+    geo_n = geo.detach() if detach_normal else geo
+    pn = l2n(torch.relu(geo_n @ w["normal_net.0.weight"].T) @ w["normal_net.1.weight"].T)
+    sh = sh4(d)
     hc = torch.relu(torch.cat([sh, geo], -1) @ w["color_net.0.weight"].T)
     hc = torch.relu(hc @ w["color_net.1.weight"].T)
     rgb = torch.sigmoid(hc @ w["color_net.2.weight"].T)
