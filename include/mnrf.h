@@ -12,12 +12,16 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every
- *     buffer.  The library allocates device memory once: 4 KiB per device at the first launch of the
- *     48-samples-per-wave field kernels (the counter pairs of their dynamic tile queue;
- *     MNRF_TILE_QUEUE=0 in the environment keeps the static grid and allocates nothing);
+ *     buffer and the library never allocates device memory.  A packed weight image is
+ *     read-write: its last 17 words are device state of the launches that use it (16
+ *     counters of the field kernels' dynamic tile queue, zero between launches, and the
+ *     range-guard word below); mnrf_pack_weights zeroes them;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return value 0 = ok, negative = error (see mnrf_last_error()); nothing throws;
- *   - re-entrant; no global stream or global device state.
+ *   - re-entrant; no global stream or global device state (host side: a cached CU count
+ *     per device and a rotating index into the 8 counter pairs of an image -- at most 8
+ *     tile-queue launches that share one image may be in flight on different streams);
+ *     every launch is capturable in a hipGraph.
  *   - the field architecture is the reference default (train.py:44-66): D=8, W=256,
  *     skip at layer 5, Embedding(10) for xyz (63 ch), Embedding(4) for dir (27 ch),
  *     normal_net and is_mirror_net present.

@@ -141,7 +141,7 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     build_parts(T);
     const int threads = 256;
     const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
-    mnrf::zero_fill((hipStream_t)stream, packed + PACKED_FLOATS - 1, sizeof(float));   // range-guard word (mnrf.h)
+    mnrf::zero_fill((hipStream_t)stream, packed + OFF_TILE_QUEUE, (1 + 2 * TQ_PAIRS) * sizeof(float));   // tile-queue pairs + range-guard word (mnrf.h)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
     launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
     if (split32_enabled()) launch_split32_pack(params, packed, (hipStream_t)stream);   // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)

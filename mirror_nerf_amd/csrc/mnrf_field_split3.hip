@@ -11,7 +11,6 @@
 #include <stdint.h>
 #include <type_traits>
 #include <stdlib.h>
-#include <mutex>
 
 #include "mnrf_layout.h"
 #include "mnrf_field_args.h"
@@ -37,14 +36,16 @@ bool split48_enabled() {
     return v;
 }
 
-// Dynamic tile queue of the h3 kernels (FieldArgs::tile_queue): a ring of {next, done} pairs per device, zeroed once -- every
-// launch leaves its pair at zero again (the last workgroup out resets it), so a pair can be handed out again as soon as the
-// launch that used it has finished; launches on one stream are ordered anyway, and 512 launches are never in flight at once.
+// Dynamic tile queue of the h3 kernels (FieldArgs::tile_queue).  The {next, done} counter pair of a launch lives in the
+// CALLER's packed weight image (mnrf_layout.h: OFF_TILE_QUEUE, TQ_PAIRS pairs before the range-guard word; zeroed by
+// mnrf_pack_weights): the library allocates nothing and keeps no device state.  Every launch leaves its pair at zero again (the
+// last workgroup out resets it); consecutive launches on an image rotate through the TQ_PAIRS pairs, so up to TQ_PAIRS launches
+// that share an image may be in flight on different streams (launches on one stream are ordered anyway).
 // MNRF_TILE_QUEUE=0 (read once) keeps the static one-workgroup-per-tile grid.
 namespace {
-constexpr int TQ_SLOTS = 512, TQ_DEVICES = 16;
-struct TileQueues { int* base = nullptr; int resident = 0; unsigned next = 0; };
-TileQueues g_tq[TQ_DEVICES];
+constexpr int TQ_DEVICES = 64;
+int g_resident[TQ_DEVICES];          // host-side cache of the CU count per device (0 = not asked yet)
+unsigned g_next_pair = 0;
 bool tile_queue_enabled() {
     static const bool v = [] { const char* e = getenv("MNRF_TILE_QUEUE"); return !(e && atoi(e) == 0); }();
     return v;
@@ -54,23 +55,17 @@ bool tile_queue_enabled() {
 static bool tile_queue_slot(FieldArgs& A) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TQ_DEVICES) return false;
-    TileQueues& q = g_tq[dev];
-    static std::mutex init_lock;      // (first use from two host threads at once)
-    std::lock_guard<std::mutex> hold(init_lock);
-    if (!q.base) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-        int* p = nullptr;
-        if (hipMalloc(&p, TQ_SLOTS * 2 * sizeof(int)) != hipSuccess) return false;
-        if (hipMemset(p, 0, TQ_SLOTS * 2 * sizeof(int)) != hipSuccess) return false;      // (synchronous, once per device)
-        q.resident = prop.multiProcessorCount;      // 150 KB of LDS and 512 registers per lane: one workgroup per CU
-        q.base = p;
+    int resident = __atomic_load_n(&g_resident[dev], __ATOMIC_RELAXED);
+    if (!resident) {
+        // 150 KB of LDS and 512 registers per lane: one workgroup per CU
+        if (hipDeviceGetAttribute(&resident, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || resident <= 0) return false;
+        __atomic_store_n(&g_resident[dev], resident, __ATOMIC_RELAXED);
     }
     const long long tiles = (A.B + h3::WG_SAMPLES - 1) / h3::WG_SAMPLES;
-    if (tiles <= q.resident || tiles > 0x7fffffff) return false;      // everything is resident at once: nothing to deal
-    A.tile_queue = q.base + 2 * (__atomic_fetch_add(&q.next, 1u, __ATOMIC_RELAXED) % TQ_SLOTS);
+    if (tiles <= resident || tiles > 0x7fffffff) return false;      // everything is resident at once: nothing to deal
+    A.tile_queue = (int*)(const_cast<float*>(A.packed) + OFF_TILE_QUEUE) + 2 * (__atomic_fetch_add(&g_next_pair, 1u, __ATOMIC_RELAXED) % TQ_PAIRS);
     A.n_tiles = (int)tiles;
-    A.resident = q.resident;
+    A.resident = resident;
     return true;
 }
 

@@ -150,6 +150,11 @@ __host__ __device__ inline int enc_col32(int T, int h, int e) {
 // tail pad: the split kernel's static LDS-DMA schedule reads two chunks (of up to 32 KiB) past the end of a stream
 constexpr int64_t SPLIT_TAIL_FLOATS = 2 * 16 * (PAIR_BYTES / 4);
 constexpr int64_t PACKED_FLOATS = OFF_SPLIT32_FWD + (int64_t)SPLIT32_FWD_PAIRS * (PAIR_BYTES / 4) + SPLIT_TAIL_FLOATS;
+// The last words of the image (inside the tail pad, whose contents no kernel consumes) are CALLER-OWNED device state of the
+// launches that use this image: [PACKED_FLOATS - 1] the range-guard word (mnrf.h), before it TQ_PAIRS {next, done} counter
+// pairs of the dynamic tile queue (mnrf_field_split3.hip).  mnrf_pack_weights zeroes all of them.
+constexpr int TQ_PAIRS = 8;
+constexpr int64_t OFF_TILE_QUEUE = PACKED_FLOATS - 1 - 2 * TQ_PAIRS;
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order
 constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)

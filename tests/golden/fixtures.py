@@ -79,7 +79,10 @@ def tcnn_weights(fx, prefix, which=0):
     cfg = O.hashgrid_config(t["bound"])
     seed = t["table_seeds"][which] if "table_seeds" in t else t["table_seed"]
     w = {k: fx.inputs[prefix + k].copy() for k in TCNN_MLP_NAMES}
-    w["encoder.embeddings"] = W.make_tcnn_table(cfg["offsets"][-1], seed, t["table_scale"], t.get("keep_levels"), cfg["offsets"])
+    if t.get("keep_levels") == "smooth":
+        w["encoder.embeddings"] = W.make_smooth_tcnn_table(t["bound"], seed, t["table_scale"])
+    else:
+        w["encoder.embeddings"] = W.make_tcnn_table(cfg["offsets"][-1], seed, t["table_scale"], t.get("keep_levels"), cfg["offsets"])
     w["_cfg"] = cfg
     return w
 

@@ -61,7 +61,10 @@ def ref_model(bound, seed, table_seed, table_scale, keep_levels=None, sigma_gain
     enc = m.encoder.encoding_config
     assert (enc["n_levels"], enc["n_features_per_level"], enc["log2_hashmap_size"], enc["base_resolution"]) == (16, 2, 19, 16)
     assert abs(np.log2(enc["per_level_scale"]) - cfg["S"]) < 1e-15 and np.array_equal(m.encoder.cfg["offsets"], cfg["offsets"])
-    table = W.make_tcnn_table(cfg["offsets"][-1], table_seed, table_scale, keep_levels, cfg["offsets"])
+    if keep_levels == "smooth":
+        table = W.make_smooth_tcnn_table(bound, table_seed, table_scale)
+    else:
+        table = W.make_tcnn_table(cfg["offsets"][-1], table_seed, table_scale, keep_levels, cfg["offsets"])
     with torch.no_grad():
         m.encoder.params.copy_(torch.from_numpy(table.reshape(-1)))
         m.sigma_net[1].weight[0] *= sigma_gain
@@ -189,11 +192,14 @@ def field_grads(name, bound, B, seed):
 RENDER = dict(bound=6.0, keep_levels=5, table_scale=0.1, sigma_gain=10.0)
 
 
-def pair(seed):
+TRAIN = dict(bound=6.0, keep_levels="smooth", table_scale=0.1, sigma_gain=10.0)
+
+
+def pair(seed, C=None):
+    C = C or RENDER
     mods, ws = [], []
     for i in range(2):
-        m, w, cfg = ref_model(RENDER["bound"], seed + i, 200 + seed + i, RENDER["table_scale"], RENDER["keep_levels"],
-                              RENDER["sigma_gain"])
+        m, w, cfg = ref_model(C["bound"], seed + i, 200 + seed + i, C["table_scale"], C["keep_levels"], C["sigma_gain"])
         mods.append(m)
         ws.append(w)
     return mods, ws, cfg
@@ -222,14 +228,59 @@ def render_case(name, test_time, n_rays=96, seed=31):
 
 
 # ------------------------------------------------------------------------------------------------ NeRFSystem + gradients
-def train_case(name, loss_fn, n_rays=64, seed=41):
+class DepthTap:
+    """Spy on the reference's `sample_pdf` (models/rendering.py:7-51, called once per render_rays): records the depths it
+    returns per call; in `pinned` mode returns the recorded ones instead (the fine sample positions of a recorded run)."""
+
+    def __init__(self):
+        import models.rendering as RR
+        self.RR, self.orig, self.rec, self.pinned, self.k = RR, RR.sample_pdf, [], None, 0
+        RR.sample_pdf = self
+
+    def __call__(self, bins, weights, n, det=False, eps=1e-5):
+        if self.pinned is not None:
+            out = self.pinned[self.k].to(bins.dtype)
+            self.k += 1
+            return out
+        out = self.orig(bins, weights, n, det=det, eps=eps)
+        self.rec.append(out.detach().clone())
+        return out
+
+    def close(self):
+        self.RR.sample_pdf = self.orig
+
+
+def train_case(name, loss_fn, n_rays=64, seed=None):
+    """NeRFSystem.forward + loss + every gradient, with the conditioning of the step measured on the reference itself.
+
+    The gradient of a hash-grid field with respect to a position jumps at cell faces (and its parameter gradient at ReLU
+    kinks), and the inverse-CDF depths of the fine pass move by 1e-6..1e-5 when the coarse weights move by 1e-7: the
+    reference's OWN gradients move by 2-80 % (of a tensor's largest entry) when its rays are perturbed by 1e-6 -- for every
+    ray set tried (seeds 41..79) -- because single reflected samples flip sides.  So the fixture stores
+      * the fine depths of both recursion levels (`z_fine_l0`, `z_fine_l1`): with them pinned (render_rays(_z_fine=...)) the
+        comparison is well conditioned, and `seed` None picks the first ray set from 41 on whose pinned-depth gradients move by
+        < 2e-3 under three 1e-6 perturbations of the rays and in float64;
+      * per tensor, how far the reference's gradients move under those perturbations with its own (free) sampling
+        (`grad_free_floors`): the tolerance of the un-pinned comparison."""
+    if seed is None:
+        for seed in range(41, 80):
+            ok = _train_case(None, first_order_loss, n_rays, seed)
+            print(f"    ray seed {seed}: pinned-depth gradient change under fp64 / 1e-6 ray perturbations {ok:.2e}")
+            if ok < 2e-3:
+                break
+        else:
+            raise RuntimeError("no well conditioned ray set found")
+    return _train_case(name, loss_fn, n_rays, seed), seed
+
+
+def _train_case(name, loss_fn, n_rays, seed):
     import train as ref_train
-    hp = R.get_hparams(model_type="nerf_tcnn", bound=RENDER["bound"], predict_normal=True, predict_mirror_mask=True,
+    hp = R.get_hparams(model_type="nerf_tcnn", bound=TRAIN["bound"], predict_normal=True, predict_mirror_mask=True,
                        trace_secondary_rays=True, N_samples=64, N_importance=64, perturb=0, noise_std=0,
                        only_trace_rays_in_mirrors=True, max_recursive_level=1)
     system = ref_train.NeRFSystem(hp)
     assert type(system.nerf_coarse) is MirrorNeRFTcnn and system.embedding_xyz.N_freqs == 0
-    mods, ws, cfg = pair(seed)
+    mods, ws, cfg = pair(seed, TRAIN)
     for mod, src in ((system.nerf_coarse, mods[0]), (system.nerf_fine, mods[1])):
         mod.load_state_dict(src.state_dict())
     system.train_dataset = types.SimpleNamespace(white_back=False)
@@ -237,9 +288,11 @@ def train_case(name, loss_fn, n_rays=64, seed=41):
     rs = np.random.RandomState(seed + 2)
     gt = (rs.uniform(size=n_rays) < 0.3).astype(np.float32)
     target = rs.uniform(size=(n_rays, 3)).astype(np.float32)
+    tap = DepthTap()
 
-    def run(dt):
+    def run(dt, rays=rays, pinned=None):
         system.zero_grad()
+        tap.pinned, tap.k, tap.rec = pinned, 0, []
         t = lambda a: torch.from_numpy(a.copy()).to(dt)  # noqa: E731
         res = system(t(rays), {"mirror_mask": t(gt), "is_eval": False, "train_geometry_stage": False})
         loss = loss_fn(res, t(target), t(gt))
@@ -248,7 +301,40 @@ def train_case(name, loss_fn, n_rays=64, seed=41):
                  for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)) for pn_, p_ in mod.named_parameters()}
         return MG.to_np(res), float(loss.item()), grads
 
-    ref, loss, g32 = run(torch.float32)
+    def perturbed(trial):
+        rp = np.random.RandomState(1000 + trial)
+        r2 = rays.copy()
+        r2[:, :3] += rp.normal(size=(n_rays, 3)).astype(np.float32) * 1e-6
+        d = r2[:, 3:6].astype(np.float64) + rp.normal(size=(n_rays, 3)) * 1e-6
+        r2[:, 3:6] = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+        return r2
+
+    def rel(a, b):
+        return {k: float(np.abs(a[k] - b[k]).max() / np.abs(b[k]).max()) for k in b if np.abs(b[k]).max() > 0}
+
+    try:
+        ref, loss, g32 = run(torch.float32)
+        new_depths = [z.clone() for z in tap.rec]              # sample_pdf's output per level (before the sort)
+        assert len(new_depths) == 2 and new_depths[1].shape[0] == int(gt.sum())
+        # the second level's sorted depths (the first level's are in `ref`): coarse depths of the reflected rays + the new ones
+        zs = torch.linspace(0, 1, 64)
+        z1c = (0.1 * (1 - zs) + 8.0 * zs).expand(new_depths[1].shape[0], 64)              # train.py:232-243: near 0.1, far inherited
+        z_l1 = torch.sort(torch.cat([z1c, new_depths[1]], -1), -1)[0].numpy()
+        assert np.array_equal(torch.sort(torch.cat([torch.from_numpy(ref["z_vals_coarse"]), new_depths[0]], -1), -1)[0].numpy(),
+                              ref["z_vals_fine"])
+        pin_fl, free_fl = {}, {}
+        for trial in range(3):
+            rp = perturbed(trial)
+            for fl, g in ((pin_fl, run(torch.float32, rp, new_depths)[2]), (free_fl, run(torch.float32, rp)[2])):
+                for k, v in rel(g, g32).items():
+                    fl[k] = max(fl.get(k, 0.0), v)
+        system.double()
+        res64, loss64, g64 = run(torch.float64, rays, new_depths)
+        gfl = rel(g32, g64)
+        if name is None:      # conditioning screen only
+            return max(max(pin_fl.values()), max(gfl.values()))
+    finally:
+        tap.close()
     hp_o = dict(N_samples=64, use_disp=False, perturb=0, noise_std=0, N_importance=64, chunk=hp.chunk,
                 trace_secondary_rays=True, only_one_field=False, max_recursive_level=1, only_trace_rays_in_mirrors=True,
                 for_vis=False)
@@ -258,16 +344,15 @@ def train_case(name, loss_fn, n_rays=64, seed=41):
     n_refl = int((ref["rgb_fine_direct"] != ref["rgb_fine"]).any(-1).sum())
     print(f"    rays whose colour changed by reflection: {n_refl}/{n_rays}; loss {loss:.6f}")
     assert n_refl > 0
-    system.double()
-    res64, loss64, g64 = run(torch.float64)
     floor = {k: float(np.max(np.abs(res64[k] - ref[k]))) if ref[k].size else 0.0 for k in ref}
-    gfl = {k: float(np.abs(g32[k] - g64[k]).max() / np.abs(g64[k]).max()) for k in g64 if np.abs(g64[k]).max() > 0}
     gfloor = max(gfl.values())
-    print("    per-tensor gradient floors > 1e-3:", {k: f"{v:.1e}" for k, v in gfl.items() if v > 1e-3})
-    print(f"    reference fp32-vs-fp64: forward floor > 2e-5 {({k: f'{v:.1e}' for k, v in floor.items() if v > 2e-5})}, "
-          f"gradient floor {gfloor:.2e}, loss {abs(loss - loss64):.1e}")
+    print("    gradient floors > 1e-3, fp32 vs fp64 (depths pinned):", {k: f"{v:.1e}" for k, v in gfl.items() if v > 1e-3})
+    print("    under 1e-6 ray perturbations, depths pinned:", {k: f"{v:.1e}" for k, v in pin_fl.items() if v > 1e-3})
+    print("    under 1e-6 ray perturbations, free sampling:", {k: f"{v:.1e}" for k, v in free_fl.items() if v > 1e-3})
+    print(f"    forward floor > 2e-5 {({k: f'{v:.1e}' for k, v in floor.items() if v > 2e-5})}, loss {abs(loss - loss64):.1e}")
     outs = dict(ref)
     outs["loss"] = np.array(loss)
+    outs["z_fine_l0"], outs["z_fine_l1"] = ref["z_vals_fine"], z_l1
     for k, g in g32.items():
         mn, pn_ = k.split("__")
         if pn_ == "encoder.params":
@@ -276,18 +361,21 @@ def train_case(name, loss_fn, n_rays=64, seed=41):
                          f"table_nnz__{mn}": np.array(n_nz)})
         else:
             outs[f"grad__{mn}__{pn_}"] = g
-    meta = dict(table=dict(RENDER, seeds=[seed, seed + 1], table_seeds=[200 + seed, 201 + seed]), hp=hp_o, floor=floor,
-                grad_floor=gfloor, grad_floors=gfl, loss=loss_fn.__name__)
+    meta = dict(table=dict(TRAIN, seeds=[seed, seed + 1], table_seeds=[200 + seed, 201 + seed]), hp=hp_o, floor=floor,
+                grad_floor=gfloor, grad_floors=gfl, grad_pinned_floors=pin_fl, grad_free_floors=free_fl,
+                loss=loss_fn.__name__, ray_seed=seed)
     ins = dict(rays=rays, gt_mask=gt, target=target, **mlp_arrays(ws[0], "coarse__"), **mlp_arrays(ws[1], "fine__"))
     MG.save(name, meta, ins, outs, keep_per_sample=False)
+    return gfloor
 
 
 if __name__ == "__main__":
-    grid_offsets()
-    field_case("g17_tcnn_field_b1", 1.0, 400, 3)
-    field_case("g17_tcnn_field_b6", 6.0, 400, 4)
-    field_grads("g17_tcnn_field_grads", 1.0, 300, 5)
-    render_case("g17_tcnn_render_train", False)
-    render_case("g17_tcnn_render_test", True)
-    train_case("g17_tcnn_train_grads", first_order_loss)
-    train_case("g17_tcnn_train_grads_full", full_loss)
+    if os.environ.get("ONLY_TRAIN") != "1":
+        grid_offsets()
+        field_case("g17_tcnn_field_b1", 1.0, 400, 3)
+        field_case("g17_tcnn_field_b6", 6.0, 400, 4)
+        field_grads("g17_tcnn_field_grads", 1.0, 300, 5)
+        render_case("g17_tcnn_render_train", False)
+        render_case("g17_tcnn_render_test", True)
+    _, ray_seed = train_case("g17_tcnn_train_grads", first_order_loss)
+    train_case("g17_tcnn_train_grads_full", full_loss, seed=ray_seed)

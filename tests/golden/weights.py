@@ -3,3 +3,32 @@
 from mirror_nerf_amd.synthetic import (ALL_MIRROR, OPAQUE, ROUGH, STRADDLE, apply_tweaks, checksum,  # noqa: F401
                                        make_tcnn_table,
                                        make_state_dict)
+
+
+def make_smooth_tcnn_table(bound, seed, amplitude=0.1, levels=4, waves=3, max_freq=1.5):
+    """A hash-grid table that encodes a SMOOTH field (tests only): the `levels` coarsest levels -- dense at every bound used
+    here, so each entry is one grid vertex -- hold, per feature, a sum of `waves` sinusoids of the vertex' world position with
+    random directions (|w| <= max_freq rad per unit length) and phases; the finer levels are zero.  A random table is white
+    noise: the slope of its trilinear interpolant jumps by O(1) at every cell face, and the gradients of a training step that
+    reflects rays off such a field move by tens of percent when a ray moves by 1e-6 (measured on the reference,
+    make_golden_tcnn.py).  With a smooth table the jumps are second order in the cell size, like a trained model's."""
+    import numpy as np
+    from oracle import mirror_nerf_oracle as O
+    cfg = O.hashgrid_config(bound)
+    table = np.zeros((int(cfg["offsets"][-1]), 2), np.float32)
+    rs = np.random.RandomState(seed)
+    for lv in range(levels):
+        off0, off1 = int(cfg["offsets"][lv]), int(cfg["offsets"][lv + 1])
+        scale = np.float32(np.exp2(np.float64(lv) * np.float64(cfg["S"])) * np.float64(cfg["H"]) - 1.0)
+        res = int(np.ceil(scale)) + 1
+        n = res + 1
+        assert n ** 3 <= off1 - off0, "level is hashed: entries are not grid vertices"
+        g = np.arange(n, dtype=np.uint32)
+        loc = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        idx = O._grid_index(loc, off1 - off0, res)
+        pos = ((loc.astype(np.float64) - 0.5) / np.float64(scale)) * 2 * bound - bound      # vertex i sits at x01 = (i - 0.5) / scale
+        for c in range(2):
+            w = rs.uniform(-max_freq, max_freq, (waves, 3))
+            ph = rs.uniform(0, 2 * np.pi, waves)
+            table[off0 + idx, c] = (amplitude * np.sin(pos @ w.T + ph).sum(-1)).astype(np.float32)
+    return table

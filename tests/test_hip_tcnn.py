@@ -593,13 +593,20 @@ def test_g17_render_rays(name):
     assert set(got) >= set(fx.outputs)
 
 
+@pytest.mark.parametrize("pinned", [False, True])
 @pytest.mark.parametrize("name", ["g17_tcnn_train_grads", "g17_tcnn_train_grads_full"])
-def test_g17_train_step_gradients(name):
+def test_g17_train_step_gradients(name, pinned, monkeypatch):
     """train.NeRFSystem(model_type="nerf_tcnn").forward (train.py:67-99, 102-348: GT mirror mask, compacted reflected rays
     starting at x_surface along the reflected normal, blend) + loss + the reference autograd's gradient of every parameter
-    of both models incl. the tables; `_full` adds the terms on the autograd normal (second order)."""
+    of both models incl. the tables; `_full` adds the terms on the autograd normal (second order).
+    The models hold a SMOOTH table (tests/golden/weights.make_smooth_tcnn_table) and the ray set was screened on the reference
+    (make_golden_tcnn.train_case): with a white-noise table the reference's own gradients move by tens of percent under 1e-6
+    perturbations of the rays.  Tolerance per tensor: 1e-3 of its largest entry, or 4 x what the reference's gradient moves in
+    float64 / under 1e-6 ray perturbations (stored per tensor).  `pinned`: the reference's fine depths of both recursion
+    levels are injected (render_rays(_z_fine=...)), which removes the inverse-CDF's sensitivity from the comparison."""
     from types import SimpleNamespace
     import mirror_nerf_amd as M
+    from mirror_nerf_amd import recursion as RC
     from tests.golden import fixtures as FX
     from tests.golden import make_golden_loss as GL
     fx = FX.Fixture(name)
@@ -613,10 +620,19 @@ def test_g17_train_step_gradients(name):
         mod.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     system.to(DEV)
     t = lambda k: torch.from_numpy(fx.inputs[k]).to(DEV)  # noqa: E731
+    if pinned:
+        orig, level = RC.render_rays, [0]
+
+        def with_reference_depths(models, emb, rays, *a, **k):
+            z = torch.from_numpy(fx.outputs[f"z_fine_l{level[0]}"]).to(DEV)
+            level[0] += 1
+            assert z.shape[0] == rays.shape[0]
+            return orig(models, emb, rays, *a, **dict(k, _z_fine=z))
+        monkeypatch.setattr(RC, "render_rays", with_reference_depths)
     res = system(t("rays"), {"mirror_mask": t("gt_mask"), "is_eval": False, "train_geometry_stage": False})
     n_cmp = 0
     for k, want in fx.outputs.items():
-        if k == "loss" or k.startswith(("grad__", "table_")) or k in FX.PER_SAMPLE_FINE or k not in res:
+        if k == "loss" or k.startswith(("grad__", "table_", "z_fine_l")) or k in FX.PER_SAMPLE_FINE or k not in res:
             continue
         d = float(np.max(np.abs(res[k].detach().cpu().numpy().astype(np.float64) - want))) if want.size else 0.0
         assert d <= FX.tolerance(k, fx.meta), (k, d)
@@ -625,15 +641,16 @@ def test_g17_train_step_gradients(name):
     loss = loss_fn(res, t("target"), t("gt_mask"))
     assert abs(loss.item() - float(fx.outputs["loss"])) <= (2e-3 if fx.meta["loss"] == "full_loss" else 2e-5)
     loss.backward()
-    floors = fx.meta["grad_floors"]
+    floors = [fx.meta["grad_floors"], fx.meta["grad_pinned_floors" if pinned else "grad_free_floors"]]
+    floor = lambda key: max(f.get(key, 0.0) for f in floors)  # noqa: E731
     report = []
     for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
         for pn_, p_ in mod.named_parameters():
             if pn_ == "encoder.embeddings":
                 lv, val, _nnz = FX.table_grad_summary(p_.grad.cpu().numpy(), cfg, fx.outputs[f"table_idx__{mname}"])
                 wl, wv = fx.outputs[f"table_levels__{mname}"], fx.outputs[f"table_val__{mname}"]
-                fl = floors.get(f"{mname}__encoder.params", 0.0)
-                report.append((np.max(np.abs(lv[:, 1] - wl[:, 1])) / wl[:, 1].max(), 1e-3, mname, "table level norms"))
+                fl = floor(f"{mname}__encoder.params")
+                report.append((np.max(np.abs(lv[:, 1] - wl[:, 1])) / wl[:, 1].max(), max(1e-3, 4 * fl), mname, "table level norms"))
                 report.append((np.max(np.abs(val - wv)) / np.abs(wv).max(), max(1e-3, 4 * fl), mname, "table entries"))
                 continue
             key = f"grad__{mname}__{pn_}"
@@ -642,8 +659,7 @@ def test_g17_train_step_gradients(name):
             if np.abs(want).max() == 0:
                 assert np.abs(g).max() == 0, key
                 continue
-            fl = floors.get(f"{mname}__{pn_}", 0.0)
-            report.append((np.max(np.abs(g - want)) / np.abs(want).max(), max(1e-3, 4 * fl), mname, pn_))
+            report.append((np.max(np.abs(g - want)) / np.abs(want).max(), max(1e-3, 4 * floor(f"{mname}__{pn_}")), mname, pn_))
     report.sort(key=lambda r: -r[0] / r[1])
     print("G17 relative gradient errors / tolerance, worst first:")
     for err, tol, mname, pn_ in report[:8]:
