@@ -229,13 +229,31 @@ class _Overlap:
         self.left = len(self.params)
         self.ready = False
         self.work = None          # (flat, handle, copied?) once issued in this step
+        self.enabled = True       # False under no_overlap(): hooks only count, allreduce_gradients() sends everything
         self.handles = [q.register_post_accumulate_grad_hook(self._hook) for q in self.params]
 
     def _hook(self, _param):
+        if not self.enabled:
+            return
+        if self.left <= 0 or self.work is not None:
+            # a second backward pass reached this module before allreduce_gradients() collected the first one's bucket
+            # (gradient accumulation, a recomputed step): its all-reduce runs -- or ran -- on the very buffer this pass is
+            # adding to.  Refuse loudly instead of reducing half-accumulated sums; recomputing callers call reset_overlap().
+            raise RuntimeError("mirror_nerf_amd.dist: a second backward pass started before allreduce_gradients() finished the "
+                               "overlapped all-reduce of the first; call dist.reset_overlap() to discard it (a recomputed "
+                               "step) or run the accumulation passes under dist.no_overlap()")
         self.left -= 1
         if self.left == 0:
             self.ready = True
-            _issue_ready_prefix()
+            if self.enabled:
+                _issue_ready_prefix()
+
+    def reset(self):
+        """Drain and discard this step's state (a pending all-reduce is waited for so that nobody writes under it)."""
+        w, self.work = self.work, None
+        if w is not None:
+            w[1].wait()
+        self.left, self.ready = len(self.params), False
 
     def issue(self):
         if self.work is None and dist.is_initialized():
@@ -271,6 +289,30 @@ def _issue_ready_prefix():
         if not ov.ready:
             break
         ov.issue()
+
+
+def reset_overlap():
+    """Discard the overlapped all-reduces of a backward pass whose gradients will not be used (train_step recomputing a step
+    after a range-guard trip): every pending collective is waited for, counters start over.  Collective-safe as long as every
+    rank calls it at the same point (train_step makes the recompute decision with an all-reduce)."""
+    for ov in _SEQ:
+        ov.reset()
+
+
+class no_overlap:
+    """Context manager for gradient accumulation: backward passes inside it do not send buckets from their hooks (and may
+    run more than once); allreduce_gradients() after the LAST pass sends the accumulated buffers."""
+
+    def __enter__(self):
+        for ov in _SEQ:
+            ov.enabled = False
+        return self
+
+    def __exit__(self, *exc):
+        for ov in _SEQ:
+            ov.enabled = True
+            ov.left, ov.ready = len(ov.params), False
+        return False
 
 
 def attach_overlap(modules, average=True):

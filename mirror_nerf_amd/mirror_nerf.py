@@ -132,7 +132,16 @@ def guard_async_begin(modules):
     host.copy_(dev_words, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    return modules, host, ev
+    return modules, host, ev, dev_words      # (dev_words: the flags on the device, for a device-side decision -- training.train_step)
+
+
+def pin_fp32(modules):
+    """Switch `modules` (or a NeRFSystem-like object's models) to the exact fp32 kernels, as a tripped guard does."""
+    if hasattr(modules, "models"):
+        modules = list(modules.models.values())
+    for m in modules:
+        if isinstance(m, MirrorNeRF):
+            m.__dict__["_mnrf_precision"] = "fp32"
 
 
 def guard_async_end(token):
@@ -140,7 +149,7 @@ def guard_async_end(token):
     True when a module tripped; it is then pinned to the fp32 kernels like check_guard does."""
     if token is None:
         return False
-    modules, host, ev = token
+    modules, host, ev = token[:3]
     ev.synchronize()
     tripped = False
     for m, w in zip(modules, host.tolist()):

@@ -56,21 +56,41 @@ def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
             "detach_density_for_normal_loss": getattr(hp, "detach_density_for_normal_loss", False)}
 
 
-GUARD_SYNC = os.environ.get("MNRF_GUARD_SYNC", "0") == "1"
+# What a training step does when the range guard of the split arithmetic trips (mirror_nerf.check_guard):
+#   "skip"  (default) the optimizer update of the tripping step is SKIPPED ON THE DEVICE -- torch's fused Adam takes the guard
+#           flag as its `found_inf` (the GradScaler mechanism), all-reduced (MAX) over the ranks first, so every rank skips the
+#           same step -- with no host read: nothing computed from saturated operands ever reaches the weights, the queue is
+#           not drained, and one batch is lost.  The host learns it one step later and pins the models to the fp32 kernels.
+#   "sync"  (MNRF_GUARD_SYNC=1 / MNRF_GUARD_MODE=sync; also the fall-back for optimizers without `found_inf`) the flag is
+#           read before the optimizer step (a queue drain, ~0.7 ms): a tripped step is recomputed on the fp32 kernels.
+#   "async" (MNRF_GUARD_MODE=async, the round-2/3 behaviour) the tripping step's update IS applied; a warning follows one
+#           step late.
+GUARD_MODE = os.environ.get("MNRF_GUARD_MODE") or ("sync" if os.environ.get("MNRF_GUARD_SYNC", "0") == "1" else "skip")
+
+
+def _takes_found_inf(optimizer):
+    return bool(getattr(optimizer, "defaults", {}).get("fused")) or hasattr(optimizer, "mnrf_found_inf")
 
 
 def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
-    """One optimisation step.  Range guard of the split arithmetic (mirror_nerf.check_guard): by default its flag is read
-    ASYNCHRONOUSLY and a trip is learnt one step late -- the update of the tripping step, computed from saturated
-    operands, has then been applied (a RuntimeWarning says so; every later step runs on the fp32 kernels).  With
-    MNRF_GUARD_SYNC=1 the flag is read before the optimizer step (a queue drain, ~6 % of the step): a tripped step is
-    recomputed on the fp32 kernels and nothing tainted ever reaches the weights."""
-    from .mirror_nerf import check_guard, guard_async_begin, guard_async_end
-    if guard_async_end(system.__dict__.pop("_mnrf_guard_token", None)):    # the previous step's range-guard words (no queue drain)
-        import warnings
-        warnings.warn("mirror_nerf_amd: the PREVIOUS optimizer update was computed with operands outside the range of the "
-                      "split-f16 arithmetic and has been applied (asynchronous guard); set MNRF_GUARD_SYNC=1 to recompute such a "
-                      "step on the fp32 kernels before it reaches the weights", RuntimeWarning, stacklevel=2)
+    """One optimisation step: forward (train semantics), loss, backward, gradient all-reduce, optimizer.  See GUARD_MODE for
+    what happens when the split-f16 arithmetic leaves its range during the step."""
+    from .mirror_nerf import check_guard, guard_async_begin, guard_async_end, pin_fp32
+    rank, world = D.world()
+    collective = world > 1 or D.forced()
+    mode = GUARD_MODE if (GUARD_MODE != "skip" or _takes_found_inf(optimizer)) else "sync"
+    token = system.__dict__.pop("_mnrf_guard_token", None)
+    if token is not None:       # the previous step's flags (their copy finished long ago: no queue drain)
+        tripped_here = guard_async_end(token[0])
+        tripped_any = tripped_here if token[1] is None else bool(token[1].item())
+        if tripped_any and not tripped_here:
+            pin_fp32(system)    # another rank left the range: every rank continues on the same (fp32) kernels
+        if tripped_any or tripped_here:
+            import warnings
+            warnings.warn("mirror_nerf_amd: the previous training step left the range of the split-f16 arithmetic; "
+                          + ("its optimizer update was skipped on every rank" if token[2] == "skip" else
+                             "its update HAS BEEN APPLIED (MNRF_GUARD_MODE=async)")
+                          + "; the models run on the fp32 kernels from now on", RuntimeWarning, stacklevel=2)
 
     def fwd_bwd():
         res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
@@ -79,11 +99,30 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
         loss.backward()
         return loss
     loss = fwd_bwd()
-    if GUARD_SYNC:
-        if check_guard(system):          # the models are pinned to fp32 now: this step again, exactly
-            loss = fwd_bwd()
+    if mode == "sync":
+        tripped = check_guard(system)          # (pins the tripping models to fp32)
+        if collective:                         # the decision must be the same on every rank: they all recompute, or none
+            flag = torch.tensor([1.0 if tripped else 0.0], device=rays.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if bool(flag.item()) and not tripped:
+                pin_fp32(system)
+                tripped = True
+        if tripped:
+            D.reset_overlap()                  # the first pass's bucket all-reduces (issued from inside backward) are discarded
+            loss = fwd_bwd()                   # this step again, exactly
     else:
-        system.__dict__["_mnrf_guard_token"] = guard_async_begin(system)   # forward + backward flags of THIS step, read at the next
+        tok = guard_async_begin(system)        # forward + backward flags of THIS step, read at the next
+        found_host = None
+        if tok is not None and (mode == "skip" or collective):
+            found = (tok[3] != 0).any().to(torch.float32)          # 0-dim, like GradScaler's found_inf
+            if collective:
+                torch.distributed.all_reduce(found, op=torch.distributed.ReduceOp.MAX)
+                found_host = torch.empty((), dtype=torch.float32, pin_memory=True)
+                found_host.copy_(found, non_blocking=True)
+                tok[2].record()                # (the event the next step waits for now also covers this copy)
+            if mode == "skip":
+                optimizer.grad_scale, optimizer.found_inf = None, found       # fused Adam: no update where found_inf != 0
+        system.__dict__["_mnrf_guard_token"] = (tok, found_host, mode)
     # RCCL over xGMI when world_size > 1: per-model flat buckets, the all-reduce of a model issued from inside the backward
     # pass as soon as its gradients are complete (dist.attach_overlap), only waited for here
     D.allreduce_gradients(params_of(system), modules=list(system.models.values()))

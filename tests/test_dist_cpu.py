@@ -148,6 +148,36 @@ def _bucket_worker(rank, ws, port, q):
             p_.grad = torch.full_like(p_, float(rank))
         D.allreduce_gradients(params_of(m), modules=[m])
         res.append(float(m.sigma.bias.grad[0]))
+
+        # ---- a RECOMPUTED step (training.train_step after a range-guard trip): the first pass's buckets went out
+        # from inside backward; reset_overlap() drains and discards them, the second pass is reduced normally
+        def backward_pass(fill):
+            for m_ in mods:
+                for p_ in m_.parameters():
+                    p_.grad = None
+            sum(_FakeFieldFn.apply(m_, float(fill + 10 * i + rank), *params_of(m_)) for i, m_ in enumerate(mods)).backward()
+        backward_pass(1000.0)
+        assert all(o.work is not None for o in ov)
+        raised = False
+        try:                       # a second backward pass without reset: refused, not silently reduced twice
+            sum(_FakeFieldFn.apply(m_, 0.0, *params_of(m_)) for m_ in mods).backward()
+        except RuntimeError as e:
+            raised = "second backward pass" in str(e)
+        D.reset_overlap()
+        assert all(o.work is None and o.left == len(o.params) for o in ov)
+        backward_pass(1.0)
+        D.allreduce_gradients([q_ for m_ in mods for q_ in params_of(m_)], modules=mods)
+        res.append((raised, [float(m_.sigma.weight.grad[0, 0]) for m_ in mods]))
+        # ---- gradient accumulation under no_overlap(): two passes, nothing sent from the hooks, one reduction at the end
+        for m_ in mods:
+            for p_ in m_.parameters():
+                p_.grad = None
+        with D.no_overlap():
+            for fill in (1.0, 2.0):
+                sum(_FakeFieldFn.apply(m_, float(fill + rank), *params_of(m_)) for m_ in mods).backward()
+                assert all(o.work is None for o in ov)
+        D.allreduce_gradients([q_ for m_ in mods for q_ in params_of(m_)], modules=mods)
+        res.append([float(m_.sigma.weight.grad[0, 0]) for m_ in mods])
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -175,3 +205,5 @@ def test_flat_gradient_buckets_and_overlapped_allreduce():
             assert eg == [1.5] * 3
         assert res[2] == [100.5, 100.0], res[2]        # mean(100, 101); mean(200 on rank 0, nothing on rank 1)
         assert res[3] == 0.5
+        assert res[4] == (True, [1.5, 11.5]), res[4]      # the recomputed pass only: mean(1 + 10 i + rank)
+        assert res[5] == [4.0, 4.0], res[5]               # (1 + 2) + mean over ranks of 2 * rank

@@ -185,13 +185,17 @@ def test_frame_driver_and_training_step_fall_back():
         def step(self):
             pass
     o1 = NoStep(s1.parameters())
-    # train_step reads the flag asynchronously: the tripping step itself passes silently, the NEXT one reports it and runs
-    # (from then on) on the exact kernels -- only the model that tripped
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        training.train_step(s1, o1, *batch)
-    with pytest.warns(RuntimeWarning, match="previous training step"):
-        l1 = training.train_step(s1, o1, *batch)
+    # MNRF_GUARD_MODE=async: train_step reads the flag asynchronously: the tripping step itself passes silently, the NEXT one
+    # reports it and runs (from then on) on the exact kernels -- only the model that tripped
+    old_mode, training.GUARD_MODE = training.GUARD_MODE, "async"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            training.train_step(s1, o1, *batch)
+        with pytest.warns(RuntimeWarning, match="previous training step"):
+            l1 = training.train_step(s1, o1, *batch)
+    finally:
+        training.GUARD_MODE = old_mode
     assert MN.precision_of(s1.nerf_fine) == "fp32" and MN.precision_of(s1.nerf_coarse) == "split"
     s2.nerf_fine.__dict__["_mnrf_precision"] = "fp32"
     l2 = training.train_step(s2, NoStep(s2.parameters()), *batch)
@@ -204,16 +208,45 @@ def test_frame_driver_and_training_step_fall_back():
     s4 = system()
     for k, v in hp.items():
         setattr(s4.hparams, k, v)
-    old_sync, training.GUARD_SYNC = training.GUARD_SYNC, True
+    old_mode, training.GUARD_MODE = training.GUARD_MODE, "sync"
     try:
         with pytest.warns(RuntimeWarning, match="affected work is repeated"):
             l4 = training.train_step(s4, NoStep(s4.parameters()), *batch)
     finally:
-        training.GUARD_SYNC = old_sync
+        training.GUARD_MODE = old_mode
     assert float(l4) == float(l2) and MN.precision_of(s4.nerf_fine) == "fp32"
     for (n, p), q in zip(s4.named_parameters(), s2.parameters()):
         if p.grad is not None:
             assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
+    # The DEFAULT ("skip"): with a fused Adam the tripping step's update is skipped on the device -- weights and optimizer
+    # state bit-identical afterwards, no host read in the step --, the next step reports it, runs on fp32 and does update
+    assert training.GUARD_MODE == "skip"
+    s5 = system()
+    for k, v in hp.items():
+        setattr(s5.hparams, k, v)
+    o5 = torch.optim.Adam(list(s5.parameters()), lr=5e-4, fused=True)
+    before = [q.detach().clone() for q in s5.parameters()]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        training.train_step(s5, o5, *batch)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, q.detach()) for a, q in zip(before, s5.parameters())), "the tainted update reached the weights"
+    assert all(float(st["step"]) == 0 for st in o5.state.values())
+    with pytest.warns(RuntimeWarning, match="update was skipped"):
+        l5 = training.train_step(s5, o5, *batch)
+    torch.cuda.synchronize()
+    assert float(l5) == float(l2) and MN.precision_of(s5.nerf_fine) == "fp32"
+    changed = sum(not torch.equal(a, q.detach()) for a, q in zip(before, s5.parameters()))
+    assert changed >= len(before) // 2 and all(float(st["step"]) == 1 for st in o5.state.values())
+    assert all(bool(torch.isfinite(q).all()) for q in s5.parameters())
+    # a clean model in the default mode: every step updates
+    s6 = M.NeRFSystem(training.default_hparams()).to(DEV)
+    o6 = torch.optim.Adam(list(s6.parameters()), lr=5e-4, fused=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(2):
+            training.train_step(s6, o6, *batch)
+    assert all(float(st["step"]) == 2 for st in o6.state.values())
     # NeRFSystem.forward on its own (validation, custom loops) checks synchronously and repeats the forward
     s3 = system()
     for k, v in hp.items():
