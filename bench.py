@@ -125,9 +125,14 @@ def cpu_baseline(sds, budget_s=20.0):
 def hash_grid_leg(dev, rays):
     """BASELINE config 5 for the record (not `value`): the hash-grid field (MirrorNeRFTcnn, bound 6, 2^19 x 16 x 2 table)
     on the same 800x800 rays -- one frame of primary rays through render_rays (64 sigma-only + 192 full samples), and the
-    1024-ray training step (forward + hand-written backward + Adam)."""
+    1024-ray training step (forward + hand-written backward + gradient all-reduce + Adam).  With N ranks (config 5 is worded
+    "... 8xMI355X"): every rank renders the whole frame (weak scaling, no data-path collective) and the training step reduces
+    the two table gradients in place and the MLP gradients as one blob per model (dist._module_messages)."""
     import torch
     import mirror_nerf_amd as M
+    from mirror_nerf_amd import dist as D
+    rank, world = D.world()
+    collective = world > 1 or D.forced()
     torch.manual_seed(0)
     models = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev)
               for k in ("coarse", "fine")}
@@ -142,10 +147,13 @@ def hash_grid_leg(dev, rays):
     torch.cuda.synchronize()
     from mirror_nerf_amd import mirror_nerf as MN
     MN.LAUNCH_LOG = []
+    if collective:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     frame()
     torch.cuda.synchronize()
-    dt_f = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
+    dt_f = D.max_over_ranks(dt_own, dev)
     log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
     full = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in log if (flags & 0x1000) and not (flags & 1)]
     ms_full = sum(t for _, t in full)
@@ -169,25 +177,64 @@ def hash_grid_leg(dev, rays):
         torch.cuda.synchronize()
         ceil[key] = 3 * n_thr * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9       # G gathers / s
     gathers_per_s = sum(B for B, _ in full) * 128 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
-    opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4)
+    params = [p for m in models.values() for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4)
     target = torch.rand(1024, 3, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)          # every rank draws its own batch (DistributedSampler semantics)
+    D.attach_overlap(models.values())  # (no-op on one rank) the all-reduces go out from inside the backward pass
+    ar_ms, touched = [], []
 
-    def step():
-        idx = torch.randint(0, rays.shape[0], (1024,), device=dev)
+    def step(measure=False):
+        idx = torch.randint(0, rays.shape[0], (1024,), device=dev, generator=gen)
         res = M.render_rays(models, emb, rays[idx], N_SAMPLES, False, 1, 1, N_IMPORTANCE, compute_normal=False)
         loss = ((res["rgb_coarse"] - target) ** 2).mean() + ((res["rgb_fine"] - target) ** 2).mean() \
             + 0.1 * ((res["mirror_mask_fine"] - 0.5) ** 2).mean() + 1e-4 * res["surface_normal_fine"].pow(2).sum(-1).mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if measure:      # (host reads: outside the timed loop)
+            touched.append([int((m.encoder.embeddings.grad != 0).any(-1).sum()) for m in models.values()])
+        if collective:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            D.allreduce_gradients(params, modules=list(models.values()))
+            e1.record()
+            ar_ms.append((e0, e1))
         opt.step()
     for _ in range(3):
         step()
+    step(measure=True)
     torch.cuda.synchronize()
+    del ar_ms[:]
+    if collective:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(10):
         step()
     torch.cuda.synchronize()
-    dt_t = (time.perf_counter() - t0) / 10
+    dt_t_own = (time.perf_counter() - t0) / 10
+    dt_t = D.max_over_ranks(dt_t_own, dev)
+    entries = int(models["fine"].encoder.embeddings.shape[0])
+    allreduce = None
+    if collective:
+        t_all = torch.tensor([dt_own, dt_t_own], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(t_all) for _ in range(world)]
+        torch.distributed.all_gather(parts, t_all)
+        per_rank = torch.stack(parts).cpu()
+        allreduce = {"messages_per_step": 4, "bytes_per_step": int(sum(q.numel() for q in params) * 4),
+                     "wait_ms_per_step_rank0": sum(a.elapsed_time(b) for a, b in ar_ms) / max(1, len(ar_ms)),
+                     "frame_s_per_rank": [round(float(v), 4) for v in per_rank[:, 0]],
+                     "train_ms_per_rank": [round(float(v) * 1e3, 3) for v in per_rank[:, 1]],
+                     "imbalance_train": float(per_rank[:, 1].max() / per_rank[:, 1].min()),
+                     "note": "per model: the table gradient (one tensor) all-reduced in place + one blob of the 11 MLP gradients, "
+                             "issued from the post-accumulate hooks of the backward pass; wait = time spent inside "
+                             "allreduce_gradients after the backward (what was not hidden behind it)"}
+    sparse = {"touched_entries_per_step": touched[0], "table_entries": entries,
+              "touched_fraction": [t / entries for t in touched[0]],
+              "dense_bytes_per_model": entries * 8, "sparse_index_value_bytes_per_model": [t * 12 for t in touched[0]],
+              "note": "a 1024-ray batch (196 608 + 65 536 samples) touches this many of the table's rows; a sparse index + float2 "
+                      "exchange (SURVEY 8e) would move 12 B per touched row -- but needs an all-gather of variable-size lists "
+                      "(world x that per rank) where the dense all-reduce moves 2 x 49 MB per rank whatever the world size"}
     # the same step with the table gradient of the big hashed levels accumulated in half2 by packed atomics (tinycudann's
     # gradient precision: models/mirror_nerf_tcnn.py:36-49 under train.py:586; module.table_grad_f16, off by default)
     for m in models.values():
@@ -203,8 +250,10 @@ def hash_grid_leg(dev, rays):
     for m in models.values():
         m.table_grad_f16 = False
     n = rays.shape[0]
-    return {"rays_per_s": n / dt_f, "samples_per_s": n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
-            "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": 1024 / dt_t,
+    return {"rays_per_s": world * n / dt_f, "samples_per_s": world * n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
+            "n_gpus": world, "scaling": "weak (every rank renders the frame / draws its own 1024-ray batch)",
+            "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
+            "table_gradient_sparsity": sparse,
             "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
             "gather_roofline": {"bound": "8-byte gathers served by the L2 (ceiling measured with mnrf_bench_gather on a 2 MiB window of the "
                                          "same table: independent loads, 1 M threads x 256)", "achieved": gathers_per_s,
@@ -516,8 +565,13 @@ def main():
         train_total = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
         train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline")
                                     if k in train_total}
+        # BASELINE config 3 as worded ("same config" as config 2: 64 coarse + 128 importance samples); the default above is
+        # run.sh:266's training schedule (--N_importance 64)
+        train_c3 = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, N_importance=128)
+        train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
+                                                                  "reflected_rays_per_step", "allreduce")}
 
-    hash_grid = hash_grid_leg(dev, rays) if (world == 1 and not a.no_train) else None
+    hash_grid = hash_grid_leg(dev, rays) if not a.no_train else None
     rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train) else None
 
     if rank == 0:

@@ -160,6 +160,11 @@ def _flat_bucket(module):
     return flat
 
 
+def _is_hashgrid(module):
+    from .mirror_nerf_tcnn import MirrorNeRFTcnn
+    return isinstance(module, MirrorNeRFTcnn)
+
+
 def _module_message(module):
     """-> (flat tensor to all-reduce, copied?).  EVERY rank sends one message of the same size and element order per module
     and step, whatever happened to its .grads locally: the in-place bucket when they still alias it, else a flat copy in
@@ -189,6 +194,31 @@ def _module_message(module):
             o, k = lay[full][0], q.numel()      # (a model with fewer encoding bands fills a prefix of its slot, on every rank alike)
             flat[o:o + k].copy_(q.grad.reshape(-1))
     return flat, True
+
+
+def _module_messages(module):
+    """-> list of (flat tensor to all-reduce, deliver(flat) or None).  One message for a field module (_module_message).
+    TWO for the hash-grid model (BASELINE config 5; reference: DDP over all parameters, train.py:577-584): its table gradient
+    -- 2 x 6.1 M floats that already ARE one tensor -- is reduced IN PLACE (no cat, no copy back), and the eleven small MLP
+    tensors (11 k floats) travel as one flat blob.  Every rank sends both, zeros where it holds no gradient."""
+    if _is_hashgrid(module):
+        table = module.encoder.embeddings
+        if table.grad is None or not table.grad.is_contiguous():
+            table.grad = torch.zeros_like(table) if table.grad is None else table.grad.contiguous()
+        mlp = [q for q in module.mlp_params() if q.requires_grad]
+        blob = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in mlp])
+
+        def deliver(flat, mlp=mlp):
+            off = 0
+            for q in mlp:
+                v = flat[off:off + q.numel()].view_as(q)
+                q.grad = v.clone() if q.grad is None else q.grad.copy_(v)
+                off += q.numel()
+        return [(table.grad, None), (blob, deliver)]
+    flat, copied = _module_message(module)
+    if flat is None:
+        return []
+    return [(flat, (lambda f, m=module: _scatter_message(m, f)) if copied else None)]
 
 
 def _scatter_message(module, flat):
@@ -228,7 +258,7 @@ class _Overlap:
         self.params = [q for q in params_of(module) if q.requires_grad]
         self.left = len(self.params)
         self.ready = False
-        self.work = None          # (flat, handle, copied?) once issued in this step
+        self.work = None          # [(flat, handle, deliver)] once issued in this step
         self.enabled = True       # False under no_overlap(): hooks only count, allreduce_gradients() sends everything
         self.handles = [q.register_post_accumulate_grad_hook(self._hook) for q in self.params]
 
@@ -251,28 +281,28 @@ class _Overlap:
     def reset(self):
         """Drain and discard this step's state (a pending all-reduce is waited for so that nobody writes under it)."""
         w, self.work = self.work, None
-        if w is not None:
-            w[1].wait()
+        for _flat, work, _deliver in (w or ()):
+            work.wait()
         self.left, self.ready = len(self.params), False
 
     def issue(self):
         if self.work is None and dist.is_initialized():
-            flat, copied = _module_message(self.module)
-            if flat is not None:
-                self.work = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), copied)
+            msgs = _module_messages(self.module)
+            if msgs:
+                self.work = [(flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), deliver) for flat, deliver in msgs]
 
     def finish(self):
-        """Wait for this module's all-reduce (issued by now) and deliver it; resets the per-step state."""
+        """Wait for this module's all-reduce(s) (issued by now) and deliver them; resets the per-step state."""
         w, self.work = self.work, None
         self.left, self.ready = len(self.params), False
         if w is None:
             return False
-        flat, work, copied = w
-        work.wait()
-        if self.average:
-            flat /= dist.get_world_size()
-        if copied:
-            _scatter_message(self.module, flat)
+        for flat, work, deliver in w:
+            work.wait()
+            if self.average:
+                flat /= dist.get_world_size()
+            if deliver is not None:
+                deliver(flat)
         return True
 
     def remove(self):
@@ -316,7 +346,8 @@ class no_overlap:
 
 
 def attach_overlap(modules, average=True):
-    """Install the overlapped bucket all-reduce on field modules (MirrorNeRF).  Idempotent; no-op without a process group.
+    """Install the overlapped bucket all-reduce on field modules (MirrorNeRF) or hash-grid models (MirrorNeRFTcnn: the table
+    gradient in place + one blob of the MLP gradients).  Idempotent; no-op without a process group.
     Pass the modules in FORWARD order (coarse, fine): their buckets go out in the reverse -- the order in which a backward
     pass completes them -- and that order must be the same on every rank (see _SEQ)."""
     out = []
@@ -352,20 +383,19 @@ def allreduce_gradients(params, average=True, modules=()):
         if ov in with_ov:
             ov.issue()
     plain = []
-    for m in modules:                    # modules without hooks: same uniform message, issued in the order given
+    for m in modules:                    # modules without hooks: same uniform message(s), issued in the order given
         if m.__dict__.get("_mnrf_overlap") is None:
-            flat, copied = _module_message(m)
-            if flat is not None:
-                plain.append((m, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), copied))
+            for flat, deliver in _module_messages(m):
+                plain.append((m, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), deliver))
     for ov in _SEQ:
         if ov in with_ov and ov.finish():
             done.update(id(q) for q in params_of(ov.module))
-    for m, flat, work, copied in plain:
+    for m, flat, work, deliver in plain:
         work.wait()
         if average:
             flat /= ws
-        if copied:
-            _scatter_message(m, flat)
+        if deliver is not None:
+            deliver(flat)
         done.update(id(q) for q in params_of(m))
     grads = [p.grad for p in params if p.grad is not None and id(p) not in done]
     if not grads:

@@ -130,11 +130,12 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     return loss
 
 
-def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0, loss_name="color_mask"):
-    """Returns dict(rays_per_s, ms_per_step, reflected_per_step, loss) for this process group."""
+def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0, loss_name="color_mask", **hp_over):
+    """Returns dict(rays_per_s, ms_per_step, reflected_per_step, loss) for this process group.  hp_over: hparams other than
+    default_hparams() (e.g. N_importance=128: BASELINE config 3 as worded)."""
     rank, world = D.world()
     torch.manual_seed(seed)
-    system = NeRFSystem(default_hparams()).to(dev)
+    system = NeRFSystem(default_hparams(**hp_over)).to(dev)
     with torch.no_grad():   # opaque density so that surfaces and reflections exist
         for m in (system.nerf_coarse, system.nerf_fine):
             m.sigma.weight.mul_(20.0)

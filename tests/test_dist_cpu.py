@@ -207,3 +207,68 @@ def test_flat_gradient_buckets_and_overlapped_allreduce():
         assert res[3] == 0.5
         assert res[4] == (True, [1.5, 11.5]), res[4]      # the recomputed pass only: mean(1 + 10 i + rank)
         assert res[5] == [4.0, 4.0], res[5]               # (1 + 2) + mean over ranks of 2 * rank
+
+
+# ---- hash-grid model (BASELINE config 5 "... 8xMI355X"): table gradient reduced in place, MLP gradients as one blob
+def _tcnn_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MNRF_FORCE_COLLECTIVES"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import mirror_nerf_amd as M
+        from mirror_nerf_amd.weights import params_of
+        torch.manual_seed(0)
+        m = M.MirrorNeRFTcnn(encoding="hashgrid", bound=1.0, predict_normal=True, predict_mirror_mask=True)
+        table = m.encoder.embeddings
+        res = []
+        # (a) plain path: .grads set by hand; rank 1 has no gradient for one MLP tensor and none for the table
+        rows = torch.tensor([3, 70000, 5000000]) + rank
+        if rank == 0:
+            table.grad = torch.zeros_like(table)
+            table.grad[rows] = 2.0
+        for i, p_ in enumerate(m.mlp_params()):
+            p_.grad = None if (rank == 1 and i == 4) else torch.full_like(p_, float(rank + 1 + i))
+        ptr = table.grad.data_ptr() if table.grad is not None else None
+        D.allreduce_gradients(params_of(m), modules=[m])
+        res.append((table.grad.data_ptr() == ptr if ptr is not None else True, float(table.grad[3, 0]), float(table.grad[4, 1]),
+                    int((table.grad != 0).sum()), [float(p_.grad.reshape(-1)[0]) for p_ in m.mlp_params()]))
+        # (b) overlapped: the all-reduces go out from the post-accumulate hooks of a real backward pass
+        ov = D.attach_overlap([m])
+        assert len(ov) == 1
+        for p_ in m.parameters():
+            p_.grad = None
+        loss = table[rows].sum() * float(rank + 1) + sum(p_.sum() for p_ in m.mlp_params()) * float(10 * (rank + 1))
+        loss.backward()
+        started = ov[0].work is not None and len(ov[0].work) == 2
+        tg = table.grad
+        D.allreduce_gradients(params_of(m), modules=[m])
+        res.append((started, table.grad is tg, float(table.grad[3, 0]), float(table.grad[4, 0]), float(m.sigma_net[0].weight.grad[0, 0]),
+                    float(m.is_mirror_net[2].bias.grad[0])))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hash_grid_model_gradient_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcnn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        a, b = out[rank]
+        in_place, g3, g4, nnz, mlp = a
+        assert in_place and g3 == 1.0 and g4 == 0.0 and nnz == 6      # mean(2, 0) on rank 0's three rows x 2 features
+        want = [1.5 + i for i in range(11)]
+        want[4] = 2.5                                                  # (5 + 0) / 2: rank 1 sent zeros for the tensor it has no gradient of
+        assert mlp == want, mlp
+        started, same_tensor, t3, t4, w, bias = b
+        assert started and same_tensor
+        assert (t3, t4) == (0.5, 1.0)       # row 3: rank 0 only (factor 1, / 2); row 4: rank 1 only (factor 2, / 2)
+        assert w == 15.0 and bias == 15.0

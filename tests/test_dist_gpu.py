@@ -54,6 +54,26 @@ WORKER = textwrap.dedent('''
     assert r["ms_per_step"] > 0
     # both models reduced through their flat gradient buffer in place, the all-reduce issued from inside the backward pass
     assert r["allreduce"] == dict(r["allreduce"], buckets_in_place=2, models=2, overlapped_with_backward=2), r["allreduce"]
+    # hash-grid models (BASELINE config 5 "... 8xMI355X"): the table gradient is all-reduced in place from inside the backward
+    # pass, the MLP gradients as one blob; every rank ends the step with the same averaged gradients
+    torch.manual_seed(0)
+    tm = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev) for k in ("coarse", "fine")}
+    ov = D.attach_overlap(tm.values())
+    assert len(ov) == 2
+    emb0 = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    g = torch.Generator(device=dev); g.manual_seed(1 + rank)
+    rr = SY.device_rays(32, 32, dev)
+    res = M.render_rays(tm, emb0, rr[torch.randint(0, rr.shape[0], (256,), device=dev, generator=g)], 32, False, 1, 1, 32, compute_normal=False)
+    (res["rgb_fine"].pow(2).mean() + res["rgb_coarse"].pow(2).mean() + 0.1 * res["mirror_mask_fine"].mean()).backward()
+    assert all(o.work is not None and len(o.work) == 2 for o in ov)
+    local = {k: m.encoder.embeddings.grad for k, m in tm.items()}
+    D.allreduce_gradients([q for m in tm.values() for q in m.parameters()], modules=list(tm.values()))
+    for k, m in tm.items():
+        assert m.encoder.embeddings.grad is local[k]                 # reduced in place: no cat, no copy back
+        chk = torch.stack([m.encoder.embeddings.grad.double().sum(), m.sigma_net[0].weight.grad.double().sum()])
+        parts = [torch.zeros_like(chk) for _ in range(ws)]
+        dist.all_gather(parts, chk)
+        assert all(torch.equal(parts[0], q) for q in parts) and float(chk[0].abs()) > 0
     dist.barrier()
     dist.destroy_process_group()
     print("RANK_OK", rank)
@@ -112,3 +132,7 @@ def test_bench_spawns_its_own_ranks():
     assert cm["reflected_rays_per_rank"] == [160000.0] and cm["primary_rays_per_rank"] == [640000.0]
     assert cm["time_imbalance_max_over_mean"] == 1.0 and cm["frame_s_per_rank"][0] > 0
     assert line["train_step"]["allreduce_bytes_per_step"] > 0 and line["train_step"]["allreduce"]["buckets_in_place"] == 2
+    assert line["train_step"]["config3_64_plus_192"]["samples_per_ray"] == 256      # BASELINE config 3 as worded
+    hg = line["hash_grid_variant"]                                                    # config 5 with its collectives
+    assert hg["allreduce"]["messages_per_step"] == 4 and hg["allreduce"]["bytes_per_step"] > 90e6 and hg["train_ms_per_step"] > 0
+    assert 0 < hg["table_gradient_sparsity"]["touched_fraction"][1] < 0.5
