@@ -232,9 +232,12 @@ def hash_grid_leg(dev, rays):
     sparse = {"touched_entries_per_step": touched[0], "table_entries": entries,
               "touched_fraction": [t / entries for t in touched[0]],
               "dense_bytes_per_model": entries * 8, "sparse_index_value_bytes_per_model": [t * 12 for t in touched[0]],
-              "note": "a 1024-ray batch (196 608 + 65 536 samples) touches this many of the table's rows; a sparse index + float2 "
-                      "exchange (SURVEY 8e) would move 12 B per touched row -- but needs an all-gather of variable-size lists "
-                      "(world x that per rank) where the dense all-reduce moves 2 x 49 MB per rank whatever the world size"}
+              "sparse_over_dense": [t * 12 / (entries * 8) for t in touched[0]],
+              "note": "rows of the table (coarse, fine model) that a 1024-ray batch (65 536 + 196 608 samples x 128 corner reads) "
+                      "touches.  A sparse index + float2 exchange (SURVEY 8e) moves 12 B per touched row PER RANK and needs an "
+                      "all-gather of variable-size lists (world x that, then a local merge); the dense in-place all-reduce moves "
+                      "8 B per row whatever the world size.  With half of the fine table touched by one rank's batch the sparse "
+                      "form is not smaller at 1 rank and strictly larger from 2 ranks on: the dense all-reduce is kept"}
     # the same step with the table gradient of the big hashed levels accumulated in half2 by packed atomics (tinycudann's
     # gradient precision: models/mirror_nerf_tcnn.py:36-49 under train.py:586; module.table_grad_f16, off by default)
     for m in models.values():
