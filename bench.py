@@ -177,6 +177,52 @@ def hash_grid_leg(dev, rays):
         torch.cuda.synchronize()
         ceil[key] = 3 * n_thr * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9       # G gathers / s
     gathers_per_s = sum(B for B, _ in full) * 128 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
+    # the ceiling WITH THE KERNEL'S OWN ACCESS PATTERN: the same launch geometry, positions and 16 x 8 gathers per sample on
+    # the fine-pass samples of one chunk, without MLPs and head outputs (mnrf_bench_tcnn_gather)
+    with torch.no_grad():
+        rc = M.render_rays(models, emb, rays[:CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, CHUNK, test_time=True, compute_normal=False)
+    zf = rc["z_vals_fine"].contiguous()
+    mfine = models["fine"]
+    from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
+    offs = _offsets17(mfine.cfg)
+    probe_out = torch.empty(zf.numel(), 4, device=dev)
+    pr = lambda: _lib.check(_lib.lib().mnrf_bench_tcnn_gather(  # noqa: E731
+        _lib.ptr(table), offs, mfine.cfg["S"], mfine.cfg["H"], float(mfine.bound), _lib.ptr(mfine._weights()), zf.numel(),
+        _lib.ptr(rays[:CHUNK].contiguous()), _lib.ptr(zf), zf.shape[1], _lib.ptr(probe_out), _lib.stream()), "probe")
+    pr()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        pr()
+    e1.record()
+    torch.cuda.synchronize()
+    probe_ms = e0.elapsed_time(e1) / 5
+    # the field kernel on exactly these samples
+    MN.LAUNCH_LOG = []
+    with torch.no_grad():
+        for _ in range(3):
+            mfine.field(zf.numel(), rays=rays[:CHUNK].contiguous(), z_vals=zf, spr=zf.shape[1])
+    torch.cuda.synchronize()
+    same_ms = sum(a_.elapsed_time(b_) for (_f, _B, a_, b_) in MN.LAUNCH_LOG) / 3
+    MN.LAUNCH_LOG = None
+    # single-pass f16 MLPs ("fp16 MLP on CDNA4 MFMA", BASELINE config 5; module.mlp_f16): the frame again
+    for m in models.values():
+        m.mlp_f16 = True
+    frame()
+    torch.cuda.synchronize()
+    MN.LAUNCH_LOG = []
+    t0 = time.perf_counter()
+    frame()
+    torch.cuda.synchronize()
+    dt_f16 = D.max_over_ranks(time.perf_counter() - t0, dev)
+    log16, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
+    full16 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log16 if (flags & 0x1000) and not (flags & 1)]
+    sig16 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log16 if (flags & 0x1000) and (flags & 1)]
+    sig32 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log if (flags & 0x1000) and (flags & 1)]
+    for m in models.values():
+        m.mlp_f16 = False
+    ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_mfma_kernel<0>")
     params = [p for m in models.values() for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=5e-4)
     target = torch.rand(1024, 3, device=dev)
@@ -258,21 +304,36 @@ def hash_grid_leg(dev, rays):
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
             "table_gradient_sparsity": sparse,
             "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
-            "gather_roofline": {"bound": "8-byte gathers served by the L2 (ceiling measured with mnrf_bench_gather on a 2 MiB window of the "
-                                         "same table: independent loads, 1 M threads x 256)", "achieved": gathers_per_s,
-                                "peak": ceil["l2_resident_8B"], "unit": "G gathers/s",
-                                "frac": gathers_per_s / ceil["l2_resident_8B"] if ceil["l2_resident_8B"] else None,
-                                "uniformly_random_over_the_53MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]},
-                                "note": "the field kernel issues 128 float2 gathers per sample (16 levels x 8 corners).  Uniformly random "
-                                        "gathers over the whole table each pull a line through the fabric out of the Infinity Cache and "
-                                        "run an order of magnitude slower -- and equally fast for 4- and 8-byte entries, so an fp16 table "
-                                        "would not raise that floor; the kernel beats it because the 8 corners of a cell and the "
-                                        "consecutive samples of a ray share lines.  The L2-served rate is the ceiling it can approach."},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
-                         "kernel": "mf::tcnn_mfma_kernel<false,false> (full evaluation, fine pass)",
+            "gather_roofline": {"bound": "the kernel's own gathers: mnrf_bench_tcnn_gather = mf::tcnn_mfma_kernel without MLPs and head "
+                                         "outputs (same launch geometry, positions, 16 levels x 8 corners per sample, lane <-> level "
+                                         "assignment) on the 6.29 M fine-pass samples of one chunk",
+                                "achieved": zf.numel() * 128 / (same_ms * 1e-3) / 1e9, "peak": zf.numel() * 128 / (probe_ms * 1e-3) / 1e9,
+                                "unit": "G gathers/s", "frac": probe_ms / same_ms if same_ms > 0 else None,
+                                "probe_ms": probe_ms, "field_kernel_ms_same_samples": same_ms,
+                                "context": {"independent_random_8B_gathers_in_a_2MiB_window": ceil["l2_resident_8B"],
+                                            "uniformly_random_over_the_49MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]},
+                                            "whole_frame_G_gathers_per_s": gathers_per_s},
+                                "note": "frac = time of the gathers alone / time of the field kernel on the same samples (<= 1 by "
+                                        "construction): what is left above it is the MLPs' share.  (Round 3 divided by the rate of "
+                                        "independent random gathers in a 2 MiB window and got 1.11: the 8 corners of a cell and the "
+                                        "consecutive samples of a ray share cache lines, which that yardstick does not model.)"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": ttr,
+                         "traffic_source": (f"static profile: profiles/traffic.json, commit {tcommit or 'unrecorded'}, {tsrc}") if ttr else None,
+                         "kernel": "mnrf::mf::tcnn_mfma_kernel<0> (full evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024,
-                         "note": "ALGORITHMIC gather bytes (128 float2 table reads per sample) over the kernel time; the table is "
-                                 "Infinity-Cache resident, so HBM traffic proper is far lower"},
+                         "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * 1024,
+                         "note": "ALGORITHMIC gather bytes (128 float2 table reads per sample) over the kernel time; the 49 MB table is "
+                                 "Infinity-Cache / L2 resident, so the bytes that reach HBM (`traffic`, PMC) are far fewer: this "
+                                 "fraction prices cache-served gathers against the HBM peak and is kept for the contract; "
+                                 "gather_roofline is the ceiling that binds"},
+            "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
+                        "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
+                        "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
+                        "sigma_only_launch_ms_fp32_valu_default": sum(t for _, t in sig32) / max(1, len(sig32)),
+                        "note": "module.mlp_f16 / MNRF_TCNN_F16: single-pass f16 MLPs on the matrix pipe (one MFMA per product, fp32 "
+                                "accumulation) -- \"fp16 MLP on CDNA4 MFMA\" as BASELINE config 5 words it, the arithmetic of tinycudann "
+                                "under precision=16 (train.py:586); ~1e-3 relative to the default (tests); sigma-only launches on "
+                                "the matrix pipe as well"},
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
                     "against tinycudann unpinned (DESIGN.md 4.3); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
                     "sigma-only launches: fp32 VALU kernel"}

@@ -56,6 +56,9 @@ extern "C" {
                                   half2 with ONE packed atomic per entry (global_atomic_pk_add_f16) instead of two fp32 atomics --
                                   tinycudann's gradient precision (models/mirror_nerf_tcnn.py:36-49 under train.py:586); the
                                   workspace then has mnrf_tcnn_backward_workspace_floats2() floats */
+#define MNRF_TCNN_F16 256u      /* mnrf_tcnn_forward: single-pass f16 MLPs -- operands rounded to f16, ONE MFMA per product, fp32 accumulation:
+                                  "fp16 MLP on CDNA4 MFMA" as BASELINE config 5 words it and as the reference computes under
+                                  tinycudann / precision=16 (train.py:586); ~1e-3 relative; sigma-only launches then take the matrix pipe too */
 #define MNRF_TCNN_VALU 8u       /* mnrf_tcnn_forward: evaluate the small MLPs with fp32 FMAs on the VALU, one thread per sample
                                   (the first implementation; default: hi/lo f16 tiles on the matrix pipe, ~1e-6 of it) */
 
@@ -241,6 +244,14 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* rays, const float* z_vals, int spr, const float* g_normal,
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
+
+/* Roofline probe of the hash-grid field kernel: the launch geometry, position arithmetic and table gathers of the matrix-pipe
+ * kernel of mnrf_tcnn_forward (16 levels x 8 corners per sample, ray-ordered samples from rays + z_vals) WITHOUT the MLPs and
+ * head outputs.  out: (B, 4) floats.  Its launch time is the floor that the table's access pattern sets for that kernel
+ * (bench.py `hash_grid_variant.gather_roofline`: frac = this / the field kernel's time <= 1 by construction). */
+int mnrf_bench_tcnn_gather(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                           int base_resolution, float bound, const float* weights, int64_t B, const float* rays,
+                           const float* z_vals, int spr, float* out, void* stream);
 
 /* Measurement aid for the hash-grid field: the rate of independent random gathers of 8 B (a float2 table entry) or 4 B (what
  * an fp16 table would fetch) from a table of `table_bytes` -- the ceiling that bounds that field's kernels once the table is

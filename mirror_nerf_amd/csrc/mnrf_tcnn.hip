@@ -447,9 +447,23 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// MODE of the matrix-pipe kernel: 0 = every fp32 operand as a hi/lo f16 pair, three MFMAs per product (~fp32 accuracy);
+// 1 = single-pass f16 (MNRF_TCNN_F16): operands rounded to nearest f16, ONE MFMA per product, fp32 accumulation -- what
+// tinycudann's FullyFusedMLP / the reference's precision=16 trainer compute (models/mirror_nerf_tcnn.py:36-49, train.py:586);
+// 2 = the gathers only (mnrf_bench_tcnn_gather: the roofline probe with the kernel's own access pattern)
+template <int MODE>
 __device__ __forceinline__ void to_b(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { unsigned h, l; split_pair(v[2 * w], v[2 * w + 1], h, l); hi[w] = h; lo[w] = l; }
+    for (int w = 0; w < 4; ++w) {
+        if (MODE == 1) {
+            typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+            const h2t h = {(_Float16)v[2 * w], (_Float16)v[2 * w + 1]};      // round to nearest even
+            hi[w] = __builtin_bit_cast(unsigned, h);
+            lo[w] = 0u;
+        } else {
+            unsigned h, l; split_pair(v[2 * w], v[2 * w + 1], h, l); hi[w] = h; lo[w] = l;
+        }
+    }
 }
 __device__ __forceinline__ f32x4 mfma3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), __builtin_bit_cast(h8, bh), c, 0, 0, 0);
@@ -466,7 +480,7 @@ __device__ __forceinline__ void read_pair(int id, int lane, u32x4& ah, u32x4& al
 }
 
 // One Linear for the NG groups of a wave: NB row blocks, NTK k-steps, tiles id0 .. in T-major order (id0 + T*NB + nb)
-template <int NB, int NTK>
+template <int MODE, int NB, int NTK>
 __device__ __forceinline__ void layer(int id0, int lane, const u32x4 (&bh)[NG][NTK], const u32x4 (&bl)[NG][NTK], f32x4 (&acc)[NG][NB]) {
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi)
@@ -477,13 +491,20 @@ __device__ __forceinline__ void layer(int id0, int lane, const u32x4 (&bh)[NG][N
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             u32x4 ah, al;
-            read_pair(id0 + T * NB + nb, lane, ah, al);
+            if (MODE == 1) {
+                ah = *(const u32x4*)(smem_mf + (id0 + T * NB + nb) * PAIR_B + lane * 16);
 #pragma unroll
-            for (int gi = 0; gi < NG; ++gi) acc[gi][nb] = mfma3(ah, al, bh[gi][T], bl[gi][T], acc[gi][nb]);
+                for (int gi = 0; gi < NG; ++gi)
+                    acc[gi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bh[gi][T]), acc[gi][nb], 0, 0, 0);
+            } else {
+                read_pair(id0 + T * NB + nb, lane, ah, al);
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) acc[gi][nb] = mfma3(ah, al, bh[gi][T], bl[gi][T], acc[gi][nb]);
+            }
         }
 }
 // accumulators of 2*NTK row blocks -> the next layer's NTK B operands (ACT: 0 none, 1 relu, 2 leaky relu 0.01 with bias)
-template <int NTK, int ACT>
+template <int MODE, int NTK, int ACT>
 __device__ __forceinline__ void next_b(const f32x4 (&acc)[NG][2 * NTK], u32x4 (&bh)[NG][NTK], u32x4 (&bl)[NG][NTK], const float* bias4) {
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi)
@@ -496,7 +517,7 @@ __device__ __forceinline__ void next_b(const f32x4 (&acc)[NG][2 * NTK], u32x4 (&
                 if (ACT == 2) { a += bias4[4 * (2 * T + (e >> 2)) + (e & 3)]; a = a > 0.f ? a : 0.01f * a; }
                 v[e] = ACT == 1 ? fmaxf(a, 0.f) : a;
             }
-            to_b(v, bh[gi][T], bl[gi][T]);
+            to_b<MODE>(v, bh[gi][T], bl[gi][T]);
         }
 }
 
@@ -544,6 +565,7 @@ __device__ __forceinline__ void encode_level_p(const float* table, const LevelP&
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -612,17 +634,20 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
                 float g0[3], g1[3];
                 encode_level_p<false>(A.table, lvl[q], u[gi], oob[gi], f8[2 * q], f8[2 * q + 1], g0, g1);
             }
-            to_b(f8, eh[gi][0], el[gi][0]);
+            to_b<MODE>(f8, eh[gi][0], el[gi][0]);
+            if (MODE == 2 && live[gi])       // the probe keeps the gathers alive with 16 B of output per sample (against 1 KiB of reads)
+                A.normal[idx[gi] * 4 + g] = ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
         }
+        if (MODE == 2) continue;
         // ---- sigma net: 32 -> 64 (ReLU) -> 16
         u32x4 sh_[NG][2], sl_[NG][2];
         {
             f32x4 acc[NG][4];
-            layer<4, 1>(0, lane, eh, el, acc);
-            next_b<2, 1>(acc, sh_, sl_, nullptr);
+            layer<MODE, 4, 1>(0, lane, eh, el, acc);
+            next_b<MODE, 2, 1>(acc, sh_, sl_, nullptr);
         }
         f32x4 s1[NG][1];      // row 0 = sigma (lane group 0, register 0), rows 1..15 = geo_feat
-        layer<1, 2>(4, lane, sh_, sl_, s1);
+        layer<MODE, 1, 2>(4, lane, sh_, sl_, s1);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (!live[gi]) continue;
@@ -641,7 +666,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 const float v[8] = {s1[gi][0][0], s1[gi][0][1], s1[gi][0][2], s1[gi][0][3], 0.f, 0.f, 0.f, 0.f};
-                to_b(v, qh[gi][0], ql[gi][0]);
+                to_b<MODE>(v, qh[gi][0], ql[gi][0]);
             }
         }
         // ---- predicted normal: 15 -> 64 (ReLU) -> 3, l2-normalised
@@ -649,11 +674,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
             u32x4 nh[NG][2], nl[NG][2];
             {
                 f32x4 acc[NG][4];
-                layer<4, 1>(6, lane, qh, ql, acc);
-                next_b<2, 1>(acc, nh, nl, nullptr);
+                layer<MODE, 4, 1>(6, lane, qh, ql, acc);
+                next_b<MODE, 2, 1>(acc, nh, nl, nullptr);
             }
             f32x4 o3[NG][1];
-            layer<1, 2>(10, lane, nh, nl, o3);
+            layer<MODE, 1, 2>(10, lane, nh, nl, o3);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 const float v0 = o3[gi][0][0], v1 = o3[gi][0][1], v2 = o3[gi][0][2];
@@ -666,16 +691,16 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
             u32x4 mh[NG][1], ml[NG][1];
             {
                 f32x4 acc[NG][2];
-                layer<2, 1>(12, lane, qh, ql, acc);
+                layer<MODE, 2, 1>(12, lane, qh, ql, acc);
                 float b4[8];
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) b4[4 * nb + r] = ws1[64 + 16 * nb + 4 * g + r];
-                next_b<1, 2>(acc, mh, ml, b4);
+                next_b<MODE, 1, 2>(acc, mh, ml, b4);
             }
             f32x4 o1[NG][1];
-            layer<1, 1>(14, lane, mh, ml, o1);
+            layer<MODE, 1, 1>(14, lane, mh, ml, o1);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
                 if (live[gi] && g == 0) TOUT(A.is_mirror + idx[gi], 1.f / (1.f + expf(-(o1[gi][0][0] + ws1[96]))));
@@ -705,22 +730,22 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
                     sh4[2] = 1.4453057213202769f * Z * (x2 - y2); sh4[3] = 0.59004358992664352f * X * (-x2 + 3.0f * y2);
                 }
                 const float v[8] = {s1[gi][0][0], s1[gi][0][1], s1[gi][0][2], s1[gi][0][3], sh4[0], sh4[1], sh4[2], sh4[3]};
-                to_b(v, ch[gi][0], cl[gi][0]);
+                to_b<MODE>(v, ch[gi][0], cl[gi][0]);
             }
             u32x4 h1[NG][2], l1[NG][2];
             {
                 f32x4 acc[NG][4];
-                layer<4, 1>(15, lane, ch, cl, acc);
-                next_b<2, 1>(acc, h1, l1, nullptr);
+                layer<MODE, 4, 1>(15, lane, ch, cl, acc);
+                next_b<MODE, 2, 1>(acc, h1, l1, nullptr);
             }
             u32x4 h2[NG][2], l2[NG][2];
             {
                 f32x4 acc[NG][4];
-                layer<4, 2>(19, lane, h1, l1, acc);
-                next_b<2, 1>(acc, h2, l2, nullptr);
+                layer<MODE, 4, 2>(19, lane, h1, l1, acc);
+                next_b<MODE, 2, 1>(acc, h2, l2, nullptr);
             }
             f32x4 o3[NG][1];
-            layer<1, 2>(27, lane, h2, l2, o3);
+            layer<MODE, 1, 2>(27, lane, h2, l2, o3);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
                 if (live[gi] && g == 0) {
@@ -1526,17 +1551,26 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     // The matrix-pipe kernel takes the full evaluations without the density-gradient normal (see its header for the
     // measurements); everything else, and tables with a hashed level whose size is not a power of two (integer modulo per
     // corner), stays on the VALU kernel.
-    const bool valu = env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || sigma_only || grad;
+    // MNRF_TCNN_F16: single-pass f16 MLPs (one MFMA per product); then the sigma-only launches run on the matrix pipe too
+    // (with three products they measured 1.11 ms against the VALU kernel's 0.98 ms per 2.1 M samples; with one they win)
+    const bool f16 = (flags & MNRF_TCNN_F16) != 0;
+    const bool probe = (flags & 0x80000000u) != 0;       // internal: mnrf_bench_tcnn_gather
+    const bool valu = !probe && (env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !f16) || grad);
+    if (probe && any_modulo) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_bench_tcnn_gather: hashed level of a non-power-of-two size");
     if (!valu) {
         const long long n_tiles = (B + mf::TILE - 1) / mf::TILE;
         if (n_tiles > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
         static const bool attr = [] {
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             return true;
         }();
         (void)attr;
         const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two 6-wave workgroups per CU
-        hipLaunchKernelGGL(mf::tcnn_mfma_kernel, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        if (probe) hipLaunchKernelGGL(mf::tcnn_mfma_kernel<2>, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        else if (f16) hipLaunchKernelGGL(mf::tcnn_mfma_kernel<1>, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
+        else hipLaunchKernelGGL(mf::tcnn_mfma_kernel<0>, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
         return mnrf_check_launch("mnrf_tcnn_forward");
     }
     const dim3 grid((unsigned)((B + TPB - 1) / TPB)), block(TPB);
@@ -1668,6 +1702,18 @@ __global__ __launch_bounds__(256) void gather_bench_kernel(const T* __restrict__
         }
     }
     if (acc == 123.456f) out[0] = acc;      // keep the loads alive
+}
+
+// Roofline probe of the hash-grid field kernel: the launch geometry, position arithmetic and table gathers of
+// mf::tcnn_mfma_kernel (16 levels x 8 corners per sample, ray-ordered samples, the lane <-> level assignment) WITHOUT the
+// MLPs and the head outputs; `out` receives 4 floats per sample (the lane groups' partial sums).  The time of this launch is
+// the floor the table's access pattern sets for the field kernel on this device.
+extern "C" int mnrf_bench_tcnn_gather(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                      int base_resolution, float bound, const float* weights, int64_t B, const float* rays,
+                                      const float* z_vals, int spr, float* out, void* stream) {
+    if (!out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_tcnn_gather: null output");
+    return mnrf_tcnn_forward(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, 0x80000000u, B, nullptr, 0,
+                             rays, z_vals, spr, nullptr, 3, nullptr, nullptr, nullptr, nullptr, out, nullptr, stream);
 }
 
 extern "C" int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gather, int64_t n_threads, int iters,

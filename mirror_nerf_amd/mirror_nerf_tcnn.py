@@ -50,6 +50,10 @@ def _offsets17(cfg):
 
 
 GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
+# module.mlp_f16 (env MNRF_TCNN_F16=1 sets the default): the MLPs of the forward kernel in single-pass f16 on the matrix pipe
+# (one MFMA per product, fp32 accumulation; ~1e-3 relative) instead of hi/lo pairs at fp32 accuracy -- "fp16 MLP on CDNA4 MFMA"
+# as BASELINE config 5 words it; the sigma-only launches then run on the matrix pipe too.  The backward recomputes in fp32.
+MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
 
 
 class TcnnFieldFn(torch.autograd.Function):
@@ -209,6 +213,8 @@ class MirrorNeRFTcnn(nn.Module):
         flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
         if getattr(self, "mlp_on_valu", False):     # the fp32 VALU kernel instead of hi/lo f16 tiles on the matrix pipe (~1e-6 apart)
             flags |= _lib.MNRF_TCNN_VALU
+        elif getattr(self, "mlp_f16", MLP_F16):     # single-pass f16 MLPs: tinycudann's / precision=16's arithmetic (train.py:586)
+            flags |= _lib.MNRF_TCNN_F16
         offs = _offsets17(self.cfg)
         p = _lib.ptr
         from . import mirror_nerf as _mn

@@ -667,3 +667,42 @@ def test_g17_train_step_gradients(name, pinned, monkeypatch):
     bad = [r for r in report if r[0] > r[1]]
     assert not bad, bad[:4]
     assert len(report) >= 22
+
+
+def test_tcnn_single_pass_f16_mlp_and_gather_probe():
+    """module.mlp_f16 (MNRF_TCNN_F16): the MLPs as single-pass f16 products on the matrix pipe -- "fp16 MLP on CDNA4 MFMA"
+    (BASELINE config 5; tinycudann under precision=16, train.py:586).  Against the fp32-accurate default on the same inputs:
+    f16 accuracy (a few 1e-3 of each output's scale), full AND sigma-only launches (the latter move to the matrix pipe).
+    And the roofline probe mnrf_bench_tcnn_gather (the kernel's gathers without its MLPs): per sample the sum of the 32
+    encoding channels, checked against the oracle's encoding."""
+    from mirror_nerf_amd import _lib
+    from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
+    m, w, cfg = _model(6.0, seed=2, table_scale=0.2)
+    rays = torch.from_numpy(O.synthetic_rays(16, 16)).to(DEV)
+    N, S = rays.shape[0], 48
+    z = (torch.linspace(0.3, 7.5, S, device=DEV)[None] + 0.05 * torch.rand(N, S, device=DEV)).contiguous()
+    with torch.no_grad():
+        ref = m.field(N * S, rays=rays, z_vals=z, spr=S, want_geo=True)
+        ref_s = m.field(N * S, rays=rays, z_vals=z, spr=S, sigma_only=True)
+        m.mlp_f16 = True
+        got = m.field(N * S, rays=rays, z_vals=z, spr=S, want_geo=True)
+        got_s = m.field(N * S, rays=rays, z_vals=z, spr=S, sigma_only=True)
+        m.mlp_f16 = False
+    assert torch.equal(ref["sigma"], m.field(N * S, rays=rays, z_vals=z, spr=S)["sigma"])      # the flag is per call
+    for k in ("sigma", "rgb", "is_mirror", "geo_feat"):
+        scale = max(1.0, float(ref[k].abs().max()))
+        err = float((got[k] - ref[k]).abs().max())
+        assert 0 < err <= 4e-3 * scale, (k, err, scale)              # f16 operands: different, and close
+    dp = (got["pred_normal"] - ref["pred_normal"]).abs().max(-1).values
+    assert float(dp.median()) <= 2e-3
+    assert float((got_s["sigma"] - ref_s["sigma"]).abs().max()) <= 4e-3 * max(1.0, float(ref_s["sigma"].abs().max()))
+    assert torch.equal(got_s["sigma"], got["sigma"])                 # sigma-only on the matrix pipe: the same arithmetic as the full launch
+    # probe
+    out = torch.empty(N * S, 4, device=DEV)
+    table = m.encoder.embeddings.detach().contiguous()
+    _lib.check(_lib.lib().mnrf_bench_tcnn_gather(_lib.ptr(table), _offsets17(m.cfg), m.cfg["S"], m.cfg["H"], float(m.bound),
+                                                 _lib.ptr(m._weights()), N * S, _lib.ptr(rays), _lib.ptr(z), S, _lib.ptr(out),
+                                                 _lib.stream()), "probe")
+    xyz = (rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3).cpu().numpy()
+    enc = O.hashgrid_encode(((xyz + np.float32(6.0)) / np.float32(12.0)).astype(np.float32), w["encoder.embeddings"], cfg)
+    assert np.max(np.abs(out.sum(-1).cpu().numpy() - enc.sum(-1))) <= 1e-4 * max(1.0, float(np.abs(enc).sum(-1).max()))
