@@ -54,6 +54,10 @@ GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
 # (one MFMA per product, fp32 accumulation; ~1e-3 relative) instead of hi/lo pairs at fp32 accuracy -- "fp16 MLP on CDNA4 MFMA"
 # as BASELINE config 5 words it; the sigma-only launches then run on the matrix pipe too.  The backward recomputes in fp32.
 MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
+# smallest launch (samples) that encodes level by level into scratch planes (module.enc_planes_min overrides; a huge value
+# keeps the one-launch form)
+LEVEL_MAJOR = os.environ.get("MNRF_TCNN_LEVEL_MAJOR", "1") != "0"
+ENC_PLANES_MIN = int(os.environ.get("MNRF_TCNN_PLANES_MIN", "32768"))
 
 
 class TcnnFieldFn(torch.autograd.Function):
@@ -107,7 +111,13 @@ class TcnnFieldFn(torch.autograd.Function):
         # table_grad_f16 (module attribute; env MNRF_TCNN_GRAD_F16=1 sets the default): the big hashed levels accumulate their
         # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
         flags = ctx.cut | (_lib.MNRF_TCNN_GRAD_F16 if getattr(m, "table_grad_f16", GRAD_F16) else 0)
-        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
+        # level_major (module attribute, default on; first-order passes): the table-gradient scatter as a second, level-major
+        # launch with every line of d_table owned by one XCD (include/mnrf.h MNRF_TCNN_LEVEL_MAJOR) -- its workspace is scratch
+        if getattr(m, "level_major", LEVEL_MAJOR) and g_normal is None:
+            flags |= _lib.MNRF_TCNN_LEVEL_MAJOR
+            ws = torch.empty(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats3(offs, flags, B)), dtype=torch.float32, device=dev)
+        else:
+            ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(
@@ -217,6 +227,12 @@ class MirrorNeRFTcnn(nn.Module):
             flags |= _lib.MNRF_TCNN_F16
         offs = _offsets17(self.cfg)
         p = _lib.ptr
+        # level-major encoding planes (include/mnrf.h: enc_workspace): the launches that take the matrix pipe encode level by
+        # level into 128 B per sample of scratch -- a third of the fabric traffic of the one-launch form at frame-sized batches
+        enc = None
+        on_pipe = not grad_normal and not (flags & _lib.MNRF_TCNN_VALU) and (not sigma_only or (flags & _lib.MNRF_TCNN_F16))
+        if on_pipe and B >= getattr(self, "enc_planes_min", ENC_PLANES_MIN):
+            enc = torch.empty(32 * B, dtype=torch.float32, device=dev)
         from . import mirror_nerf as _mn
         log = _mn.LAUNCH_LOG if B else None
         if log is not None:      # bench.py: kernel time from events on the launching stream
@@ -227,7 +243,7 @@ class MirrorNeRFTcnn(nn.Module):
                 p(table.contiguous()), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
                 p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3,
                 p(out["sigma"]), p(out.get("rgb")), p(out["pred_normal"]), p(out.get("is_mirror")), p(out.get("normal")),
-                p(out.get("geo_feat")), _lib.stream()), "mnrf_tcnn_forward")
+                p(out.get("geo_feat")), p(enc), _lib.stream()), "mnrf_tcnn_forward")
         if log is not None:
             e1.record()
             log.append((flags | 0x1000, B, e0, e1))       # 0x1000: hash-grid field

@@ -20,7 +20,9 @@ per = defaultdict(lambda: defaultdict(dict))      # kernel -> counter -> dispatc
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].replace("void ", "").split("(")[0].replace(", ", ",")
+            k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(", ", ",")
+            if k.startswith(("mf::", "tcnn_")):
+                k = "mnrf::" + k      # (the hash-grid kernels live in an anonymous namespace of mnrf_tcnn.hip)
             if "field" not in k and "tcnn" not in k and "dw_gemm" not in k:
                 continue
             d = per[k][row["Counter_Name"]]
