@@ -56,10 +56,6 @@ extern "C" {
                                   half2 with ONE packed atomic per entry (global_atomic_pk_add_f16) instead of two fp32 atomics --
                                   tinycudann's gradient precision (models/mirror_nerf_tcnn.py:36-49 under train.py:586); the
                                   workspace then has mnrf_tcnn_backward_workspace_floats2() floats */
-#define MNRF_TCNN_LEVEL_MAJOR 512u /* mnrf_tcnn_backward (first-order passes): the table-gradient scatter as a second, level-major launch in which
-                                  every 128-byte line of d_table is only ever touched from one XCD (its atomics run in that XCD's L2
-                                  instead of bouncing lines over the fabric); workspace: mnrf_tcnn_backward_workspace_floats3() floats,
-                                  need not be zeroed */
 #define MNRF_TCNN_F16 256u      /* mnrf_tcnn_forward: single-pass f16 MLPs -- operands rounded to f16, ONE MFMA per product, fp32 accumulation:
                                   "fp16 MLP on CDNA4 MFMA" as BASELINE config 5 words it and as the reference computes under
                                   tinycudann / precision=16 (train.py:586); ~1e-3 relative; sigma-only launches then take the matrix pipe too */
@@ -341,7 +337,6 @@ int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double 
  * models/mirror_nerf_tcnn.py:172-218 / utils/func.py:10-25 -- to d_table, d_weights and d_xyz. */
 int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host);
 int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags /* MNRF_TCNN_GRAD_F16 or 0 */);
-int64_t mnrf_tcnn_backward_workspace_floats3(const int64_t* offsets17_host, unsigned flags, int64_t B);
 int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                        int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,

@@ -854,12 +854,13 @@ struct TcnnBwdArgs {
     // of atomics (measured: with one of the two fp32 adds compiled out the 1024-ray step takes 3.02 instead of 4.09 ms).
     __half2* g16;                                // (entries) half2, zero-initialised by the caller; null: fp32 atomics
     float g16_scale;                             // gradients are multiplied by this on the way in, divided on the way out
-    // MNRF_TCNN_LEVEL_MAJOR (round 4): tcnn_bwd_kernel writes dL/d encoding as level-major planes [NL][B] float2 instead of
-    // scattering, and tcnn_scatter_kernel scatters them level by level with every table line owned by ONE XCD (see there)
-    float2* genc;                                // planes (caller's workspace) or null
-    int* queue;                                  // [NL][8] tile counters of tcnn_scatter_kernel (zeroed by the launcher)
 };
 
+// Round 4, measured and NOT kept: a level-major second launch in which every 128-byte line of d_table is only touched from one
+// XCD (owner = row bits, workgroups pick their owner from HW_REG_XCC_ID, global tile queues): the atomics of a 1024-ray step took
+// 2.2 ms there against 2.1 ms inside this kernel (and the 8x repeated index arithmetic another 1.8 ms) -- the fp32 atomics run
+// at ~32 G/s whether their lines are L2-resident or not, so the bound is the L2's atomic units, not line traffic; without the
+// scatter this kernel takes 0.92 of its 3.0 ms.  What does help is fewer atomics (run aggregation below; packed f16 pairs).
 __device__ __forceinline__ void fadd(float* p, float v) { unsafeAtomicAdd(p, v); }
 
 // acc[r] += sum over the tile's samples of G[g0 + 4*(lane>>4) + r][s] * X[x0 + (lane&15)][s]
@@ -945,8 +946,6 @@ __device__ __forceinline__ void sh4_backward(const float (&d)[3], const float* g
 // Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): on levels whose cell
 // key fits 3 x 10 bits each run of lanes with equal cell is summed into its first lane (segmented suffix sum, 6 shuffle
 // steps) and only that lane scatters.  Every lane of the wave must call it (shuffles).
-// own >= 0: only the corners whose table LINE (128 B: 16 float2 rows, or 32 half2 rows of the f16 table) belongs to owner
-// `own` of 8 are added (tcnn_scatter_kernel).
 __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, const unsigned (&pg)[3], float (&v0)[8], float (&v1)[8],
                                                 bool active, int lane, float* dtab, unsigned hsize, unsigned res, int own = -1) {
     const TcnnArgs& A = P.f;
@@ -976,14 +975,12 @@ __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, co
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
-            if (own >= 0 && (int)(((A.off[lv] + idx) >> 5) & 7u) != own) continue;
             unsafeAtomicAdd(h + idx, __floats2half2_rn(v0[c] * k, v1[c] * k));
         }
     } else if (active && head && !P.exp_noscatter) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
-            if (own >= 0 && (int)(((A.off[lv] + idx) >> 4) & 7u) != own) continue;
             fadd(dtab + 2ll * idx, v0[c]);
 #ifndef MNRF_EXP_TCNN_HALF_SCATTER      // experiment (wrong gradients): is the scatter bound by the NUMBER of atomics?  If so, one packed
             fadd(dtab + 2ll * idx + 1, v1[c]);      // 2 x f16 atomic per entry (tinycudann's choice) would halve it.
@@ -1279,14 +1276,8 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
         for (int k = 0; k < 32; ++k) GR(k) = g_enc[k];           // (own column; indexed by level below)
         float gx[3] = {0.f, 0.f, 0.f};
         const bool active = live && !oob;
-        if (P.genc && live) {      // level-major mode: hand dL/d encoding to tcnn_scatter_kernel
-#pragma unroll 1
-            for (int lv = 0; lv < NL; ++lv)
-                P.genc[(long long)lv * A.B + i] = active ? float2{GR(2 * lv), GR(2 * lv + 1)} : float2{0.f, 0.f};
-        }
 #pragma unroll 1
         for (int lv = 0; lv < NL; ++lv) {
-            if (P.genc && !P.d_xyz) break;      // (nothing left to do per level here; with d_xyz: the gathers below, no scatter)
             const float e0 = active ? GR(2 * lv) : 0.f, e1 = active ? GR(2 * lv + 1) : 0.f;
             const float scale = A.scale[lv];
             const unsigned res = A.res[lv];
@@ -1321,7 +1312,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                     gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
                 }
             }
-            if (!P.genc) scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
+            scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
         }
         if (P.d_xyz && live) {
             const float s = 1.f / (2.f * A.bound);
@@ -1527,76 +1518,6 @@ __global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
 #undef GR
 
 // d_table[level entries] += sum of the level's private copies
-// Level-major table-gradient scatter (MNRF_TCNN_LEVEL_MAJOR).  The gradient of a sample lands on 128 random lines of a 49 MB
-// table; with every workgroup walking all 16 levels (the scatter inside tcnn_bwd_kernel) each atomic misses the 4 MB L2 of its
-// XCD, pulls the line over the fabric and pushes it back dirty -- and lines another XCD holds bounce: 3.0 of the 4.1 ms of a
-// 1024-ray step.  Here
-//   * the grid's y dimension is the level (a few levels are in flight at a time),
-//   * every 128-byte line of the table gradient has ONE owner among 8 (bits 4..6 of its row index): the atomics of owner o are
-//     issued by workgroups running on XCD o (s_getreg XCC_ID), so a line lives in one L2 for the whole launch and the atomics
-//     run at L2 rate.  Each XCD therefore visits every (sample, level) and keeps the corners it owns (the index arithmetic is
-//     repeated 8x; it is cheap next to a fabric round trip per atomic),
-//   * correctness does not rest on the workgroup -> XCD mapping: the (level, owner) tile queues are global counters, and a
-//     workgroup that has drained its own XCD's queue helps with the others (coherent device-scope atomics either way).
-__device__ __forceinline__ unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }      // HW_REG_XCC_ID[3:0]
-
-__global__ __launch_bounds__(256) void tcnn_scatter_kernel(TcnnBwdArgs P, int ntiles) {
-    const TcnnArgs& A = P.f;
-    const int lv = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    __shared__ int s_tile;
-    const float scale = A.scale[lv];
-    const unsigned res = A.res[lv];
-    const unsigned hsize = A.off[lv + 1] - A.off[lv];
-    float* dtab = P.d_table + 2ll * A.off[lv];
-    const unsigned home = xcc_id();
-#pragma unroll 1
-    for (int k = 0; k < 8; ++k) {
-        const int own = (int)((home + k) & 7u);
-        for (;;) {
-            if (threadIdx.x == 0) s_tile = atomicAdd(P.queue + lv * 8 + own, 1);
-            __syncthreads();
-            const int tile = s_tile;
-            __syncthreads();
-            if (tile >= ntiles) break;
-            long long i = (long long)tile * 256 + threadIdx.x;
-            const bool live = i < A.B;
-            if (!live) i = A.B - 1;
-            const float2 e = P.genc[(long long)lv * A.B + i];
-            const bool active = live && (e.x != 0.f || e.y != 0.f);      // (samples outside the box and samples no loss reaches: zeros)
-            if (!__any(active)) continue;                                  // (wave-uniform: the shuffles below need every lane)
-            float x[3];
-            if (A.xyz) {
-                const float* p = A.xyz + i * A.xyz_stride;
-                x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
-            } else {
-                const float* r = A.rays + (i / A.spr) * 8;
-                const float z = A.z_vals[i];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) x[a] = r[a] + r[3 + a] * z;
-            }
-            unsigned pg[3];
-            float fr[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float u = (x[a] + A.bound) / (2.f * A.bound);
-                const float pos = u * scale + 0.5f;
-                const float fl = floorf(pos);
-                pg[a] = active ? (unsigned)fl : 0u;
-                fr[a] = pos - fl;
-            }
-            float v0[8], v1[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float w = ((c & 1) ? fr[0] : 1.f - fr[0]) * ((c & 2) ? fr[1] : 1.f - fr[1]) * ((c & 4) ? fr[2] : 1.f - fr[2]);
-                v0[c] = w * e.x;
-                v1[c] = w * e.y;
-            }
-            scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res, own);
-        }
-    }
-}
-
 __global__ void tcnn_fold_kernel(TcnnBwdArgs P) {
     const TcnnArgs& A = P.f;
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1742,13 +1663,6 @@ extern "C" int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17
     return base + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] : 0);
 }
 
-// MNRF_TCNN_LEVEL_MAJOR: [128 queue counters][32 * B floats of dL/d encoding planes][half2 table with MNRF_TCNN_GRAD_F16]
-extern "C" int64_t mnrf_tcnn_backward_workspace_floats3(const int64_t* offsets17_host, unsigned flags, int64_t B) {
-    if (!offsets17_host) return 0;
-    if (!(flags & MNRF_TCNN_LEVEL_MAJOR)) return mnrf_tcnn_backward_workspace_floats2(offsets17_host, flags);
-    return 128 + 32 * B + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] : 0);
-}
-
 extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                                   int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
@@ -1783,21 +1697,8 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     P.copies = workspace;
     P.g16 = nullptr;
     P.g16_scale = 1.f;
-    P.genc = nullptr;
-    P.queue = nullptr;
-    // level-major scatter: first-order passes only (the second-order kernel adds to the copies of the one-launch form)
-    const bool level_major = (flags & MNRF_TCNN_LEVEL_MAJOR) && workspace && !g_normal;
-    if (level_major) {
-        P.queue = (int*)workspace;
-        P.genc = (float2*)(workspace + 128);
-        P.copies = nullptr;
-        if (hipMemsetAsync(P.queue, 0, 128 * sizeof(int), (hipStream_t)stream) != hipSuccess)
-            return mnrf_fail(MNRF_ERR_LAUNCH, "mnrf_tcnn_backward: hipMemsetAsync");
-    }
     if ((flags & MNRF_TCNN_GRAD_F16) && workspace) {
-        P.g16 = (__half2*)(workspace + (level_major ? 128 + 32 * B : mnrf_tcnn_backward_workspace_floats(offsets17_host)));
-        if (level_major && hipMemsetAsync(P.g16, 0, (size_t)offsets17_host[NL] * sizeof(__half2), (hipStream_t)stream) != hipSuccess)
-            return mnrf_fail(MNRF_ERR_LAUNCH, "mnrf_tcnn_backward: hipMemsetAsync");
+        P.g16 = (__half2*)(workspace + mnrf_tcnn_backward_workspace_floats(offsets17_host));
         static const float scale = [] { const char* e = getenv("MNRF_TCNN_GRAD_SCALE"); return e && atof(e) > 0 ? (float)atof(e) : 1024.f; }();
         P.g16_scale = scale;       // tinycudann's loss scale is 128; 1024 keeps 1e-7-sized contributions above f16's subnormal step
     }
@@ -1809,7 +1710,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     while (P.agg_levels < NL && (int)A.res[P.agg_levels] <= agg_res && A.res[P.agg_levels] < 1023u) ++P.agg_levels;
     long long folded = 0;
     plan_copies(offsets17_host, P.cp_n, P.cp_off, &folded);
-    if (!workspace || level_major || getenv("MNRF_TCNN_NO_COPIES")) {         // (null workspace: every level straight into d_table)
+    if (!workspace || getenv("MNRF_TCNN_NO_COPIES")) {         // (null workspace: every level straight into d_table)
         for (int l = 0; l < NL; ++l) P.cp_n[l] = 0;
         folded = 0;
     }
@@ -1817,11 +1718,6 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256)), block(BT);      // persistent: one workgroup per CU of the MI355X
     const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
-    if (level_major) {
-        if (ntiles > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: too many samples for one launch");
-        const unsigned per_level = (unsigned)(8 * ntiles < 512 ? 8 * ntiles : 512);      // two workgroups per CU drain a level's 8 queues
-        hipLaunchKernelGGL(tcnn_scatter_kernel, dim3(per_level, NL), dim3(256), 0, (hipStream_t)stream, P, (int)ntiles);
-    }
     if (g_normal) hipLaunchKernelGGL(tcnn_bwd2_kernel, grid, block, lds, (hipStream_t)stream, P);     // adds the second-order term
     if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     if (P.g16) {      // everything from the first level without copies on (copied levels in between only add the zeros they hold)

@@ -56,7 +56,6 @@ GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
 MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
 # smallest launch (samples) that encodes level by level into scratch planes (module.enc_planes_min overrides; a huge value
 # keeps the one-launch form)
-LEVEL_MAJOR = os.environ.get("MNRF_TCNN_LEVEL_MAJOR", "1") != "0"
 ENC_PLANES_MIN = int(os.environ.get("MNRF_TCNN_PLANES_MIN", "32768"))
 
 
@@ -111,13 +110,7 @@ class TcnnFieldFn(torch.autograd.Function):
         # table_grad_f16 (module attribute; env MNRF_TCNN_GRAD_F16=1 sets the default): the big hashed levels accumulate their
         # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
         flags = ctx.cut | (_lib.MNRF_TCNN_GRAD_F16 if getattr(m, "table_grad_f16", GRAD_F16) else 0)
-        # level_major (module attribute, default on; first-order passes): the table-gradient scatter as a second, level-major
-        # launch with every line of d_table owned by one XCD (include/mnrf.h MNRF_TCNN_LEVEL_MAJOR) -- its workspace is scratch
-        if getattr(m, "level_major", LEVEL_MAJOR) and g_normal is None:
-            flags |= _lib.MNRF_TCNN_LEVEL_MAJOR
-            ws = torch.empty(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats3(offs, flags, B)), dtype=torch.float32, device=dev)
-        else:
-            ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
+        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(

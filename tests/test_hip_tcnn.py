@@ -706,40 +706,3 @@ def test_tcnn_single_pass_f16_mlp_and_gather_probe():
     xyz = (rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3).cpu().numpy()
     enc = O.hashgrid_encode(((xyz + np.float32(6.0)) / np.float32(12.0)).astype(np.float32), w["encoder.embeddings"], cfg)
     assert np.max(np.abs(out.sum(-1).cpu().numpy() - enc.sum(-1))) <= 1e-4 * max(1.0, float(np.abs(enc).sum(-1).max()))
-
-
-@pytest.mark.parametrize("f16", [False, True])
-def test_tcnn_level_major_scatter_agrees_with_the_fused_scatter(f16):
-    """MNRF_TCNN_LEVEL_MAJOR (default): dL/d encoding goes out as level-major planes and a second launch scatters it with every
-    line of the table gradient owned by one XCD.  Same gradients as the one-launch scatter up to the order of the fp32 sums
-    (f16: the packed-atomic variant of both), identical untouched entries, identical everything else."""
-    from mirror_nerf_amd.mirror_nerf_tcnn import TcnnFieldFn
-    m, _w, cfg = _model(6.0, seed=8, table_scale=0.2)
-    m.table_grad_f16 = f16
-    g = torch.Generator().manual_seed(21)
-    N, S = 83, 96                                                     # 7968 samples: ragged last tile
-    rays = torch.from_numpy(O.synthetic_rays(10, 10)[:N]).to(DEV)
-    z = (torch.linspace(0.3, 7.9, S)[None] + 0.02 * torch.rand(N, S, generator=g)).to(DEV)   # runs through the box and out of it
-    seeds = [torch.randn(N * S, generator=g).to(DEV), torch.randn(N * S, 3, generator=g).to(DEV),
-             torch.randn(N * S, 3, generator=g).to(DEV), torch.randn(N * S, generator=g).to(DEV)]
-    seeds[0][::7] = 0                                                 # (some samples without any gradient)
-
-    def grads(level_major):
-        m.level_major = level_major
-        m.zero_grad()
-        r = rays.clone().requires_grad_(True)
-        outs = TcnnFieldFn.apply(m, S, None, r, z, None, False, m.encoder.embeddings, *m.mlp_params())
-        sum((o_ * s_).sum() for o_, s_ in zip(outs[:4], seeds)).backward()
-        out = {k: v.grad.clone() for k, v in m.named_parameters()}
-        out["rays"] = r.grad.clone()
-        return out
-    a, b = grads(True), grads(False)
-    m.level_major = True
-    for k in a:
-        scale = float(b[k].abs().max()) + 1e-12
-        tol = (2e-3 if f16 else 2e-5) if k == "encoder.embeddings" else 1e-6
-        assert float((a[k] - b[k]).abs().max()) <= tol * scale, (k, float((a[k] - b[k]).abs().max()), scale)
-    ta, tb = a["encoder.embeddings"], b["encoder.embeddings"]
-    if not f16:
-        assert torch.equal(ta != 0, tb != 0)
-    assert int((ta != 0).any(-1).sum()) > 1000
