@@ -159,7 +159,7 @@ def hash_grid_leg(dev, rays):
     ms_full = sum(t for _, t in full)
     # the dominant kernel of this variant is gather-bound: 16 levels x 8 corners x 8 B (float2) = 1 KiB of table reads per
     # sample, from a 53 MB table (Infinity-Cache resident: the HBM peak is the contract's yardstick, not the binding limit)
-    gbs = sum(B for B, _ in full) * 1024 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
+    gbs = sum(B for B, _ in full) * (1024 + 256) / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
     # the binding limit: random gathers out of the Infinity Cache, measured on this very table (mnrf_bench_gather)
     from mirror_nerf_amd import _lib
     table = models["fine"].encoder.embeddings.detach()
@@ -177,18 +177,18 @@ def hash_grid_leg(dev, rays):
         torch.cuda.synchronize()
         ceil[key] = 3 * n_thr * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9       # G gathers / s
     gathers_per_s = sum(B for B, _ in full) * 128 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
-    # the ceiling WITH THE KERNEL'S OWN ACCESS PATTERN: the same launch geometry, positions and 16 x 8 gathers per sample on
-    # the fine-pass samples of one chunk, without MLPs and head outputs (mnrf_bench_tcnn_gather)
+    # the level-major encoding launch on its own (mnrf_tcnn_encode) and the whole field evaluation on the same fine-pass samples
     with torch.no_grad():
         rc = M.render_rays(models, emb, rays[:CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, CHUNK, test_time=True, compute_normal=False)
     zf = rc["z_vals_fine"].contiguous()
     mfine = models["fine"]
     from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
     offs = _offsets17(mfine.cfg)
-    probe_out = torch.empty(zf.numel(), 4, device=dev)
-    pr = lambda: _lib.check(_lib.lib().mnrf_bench_tcnn_gather(  # noqa: E731
-        _lib.ptr(table), offs, mfine.cfg["S"], mfine.cfg["H"], float(mfine.bound), _lib.ptr(mfine._weights()), zf.numel(),
-        _lib.ptr(rays[:CHUNK].contiguous()), _lib.ptr(zf), zf.shape[1], _lib.ptr(probe_out), _lib.stream()), "probe")
+    planes = torch.empty(32 * zf.numel(), device=dev)
+    rchunk = rays[:CHUNK].contiguous()
+    pr = lambda: _lib.check(_lib.lib().mnrf_tcnn_encode(  # noqa: E731
+        _lib.ptr(table), offs, mfine.cfg["S"], mfine.cfg["H"], float(mfine.bound), zf.numel(), None, 0,
+        _lib.ptr(rchunk), _lib.ptr(zf), zf.shape[1], _lib.ptr(planes), _lib.stream()), "encode")
     pr()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,15 +197,29 @@ def hash_grid_leg(dev, rays):
         pr()
     e1.record()
     torch.cuda.synchronize()
-    probe_ms = e0.elapsed_time(e1) / 5
-    # the field kernel on exactly these samples
+    enc_ms = e0.elapsed_time(e1) / 5
+    planes = None
     MN.LAUNCH_LOG = []
     with torch.no_grad():
         for _ in range(3):
-            mfine.field(zf.numel(), rays=rays[:CHUNK].contiguous(), z_vals=zf, spr=zf.shape[1])
+            mfine.field(zf.numel(), rays=rchunk, z_vals=zf, spr=zf.shape[1])
     torch.cuda.synchronize()
     same_ms = sum(a_.elapsed_time(b_) for (_f, _B, a_, b_) in MN.LAUNCH_LOG) / 3
     MN.LAUNCH_LOG = None
+    one_launch_ms = None
+    for m in models.values():
+        m.enc_planes_min = 1 << 62
+    MN.LAUNCH_LOG = []
+    with torch.no_grad():
+        for _ in range(3):
+            mfine.field(zf.numel(), rays=rchunk, z_vals=zf, spr=zf.shape[1])
+    torch.cuda.synchronize()
+    one_launch_ms = sum(a_.elapsed_time(b_) for (_f, _B, a_, b_) in MN.LAUNCH_LOG) / 3
+    MN.LAUNCH_LOG = None
+    for m in models.values():
+        del m.enc_planes_min
+    pmc = _pmc("mnrf::mf::tcnn_encode_kernel")
+    l2_bytes = pmc.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0 if pmc else None      # 128-byte lines requested from the L2 per launch
     # single-pass f16 MLPs ("fp16 MLP on CDNA4 MFMA", BASELINE config 5; module.mlp_f16): the frame again
     for m in models.values():
         m.mlp_f16 = True
@@ -222,7 +236,7 @@ def hash_grid_leg(dev, rays):
     sig32 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log if (flags & 0x1000) and (flags & 1)]
     for m in models.values():
         m.mlp_f16 = False
-    ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_mfma_kernel<0>")
+    ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_encode_kernel")
     params = [p for m in models.values() for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=5e-4)
     target = torch.rand(1024, 3, device=dev)
@@ -304,28 +318,33 @@ def hash_grid_leg(dev, rays):
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
             "table_gradient_sparsity": sparse,
             "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
-            "gather_roofline": {"bound": "the kernel's own gathers: mnrf_bench_tcnn_gather = mf::tcnn_mfma_kernel without MLPs and head "
-                                         "outputs (same launch geometry, positions, 16 levels x 8 corners per sample, lane <-> level "
-                                         "assignment) on the 6.29 M fine-pass samples of one chunk",
-                                "achieved": zf.numel() * 128 / (same_ms * 1e-3) / 1e9, "peak": zf.numel() * 128 / (probe_ms * 1e-3) / 1e9,
-                                "unit": "G gathers/s", "frac": probe_ms / same_ms if same_ms > 0 else None,
-                                "probe_ms": probe_ms, "field_kernel_ms_same_samples": same_ms,
+            "gather_roofline": {"bound": "l2", "kernel": "mnrf::mf::tcnn_encode_kernel (level-major encoding: 16 levels x 8 corners per sample; "
+                                          "the dominant launch of the two-launch field evaluation)",
+                                "achieved": (l2_bytes / (enc_ms * 1e-3) / 1e9) if l2_bytes else None, "peak": 34500.0, "unit": "GB/s",
+                                "frac": (l2_bytes / (enc_ms * 1e-3) / 1e9 / 34500.0) if l2_bytes else None,
+                                "l2_read_bytes_per_launch": l2_bytes, "l2_hit_rate": (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]))
+                                if pmc and "TCC_HIT_sum" in pmc else None,
+                                "tcp_hit_rate": (1.0 - pmc["TCP_TCC_READ_REQ_sum"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"])
+                                if pmc and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc else None,
+                                "encode_ms": enc_ms, "field_ms_same_samples": same_ms, "encode_share_of_field": enc_ms / same_ms if same_ms else None,
+                                "one_launch_form_ms": one_launch_ms, "G_gathers_per_s": zf.numel() * 128 / (enc_ms * 1e-3) / 1e9,
                                 "context": {"independent_random_8B_gathers_in_a_2MiB_window": ceil["l2_resident_8B"],
-                                            "uniformly_random_over_the_49MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]},
-                                            "whole_frame_G_gathers_per_s": gathers_per_s},
-                                "note": "frac = time of the gathers alone / time of the field kernel on the same samples (<= 1 by "
-                                        "construction): what is left above it is the MLPs' share.  (Round 3 divided by the rate of "
-                                        "independent random gathers in a 2 MiB window and got 1.11: the 8 corners of a cell and the "
-                                        "consecutive samples of a ray share cache lines, which that yardstick does not model.)"},
+                                            "uniformly_random_over_the_49MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]}},
+                                "counters_source": "static profile: profiles/traffic.json \"pmc\" (scripts/pmc_tcnn.sh), per launch of one 32768-ray chunk",
+                                "note": "every gather that misses the 32 KB vector L1 pulls a 128-byte line out of the L2 for 8 useful bytes; "
+                                        "achieved = those lines (PMC: TCP_TCC_READ_REQ x 128 B per launch) over the live launch time, against "
+                                        "the L2's ~34.5 TB/s (MI355X_MICROARCH.md).  Round 3's one-launch kernel walked all 16 levels per wave: "
+                                        "54 % of its lines missed the L2 too and 20.7 GB per launch crossed the fabric at 7.5 TB/s "
+                                        "(profiles/r04b_pmc_tcnn); level by level the L2 holds the level (hit rate above)."},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": ttr,
                          "traffic_source": (f"static profile: profiles/traffic.json, commit {tcommit or 'unrecorded'}, {tsrc}") if ttr else None,
-                         "kernel": "mnrf::mf::tcnn_mfma_kernel<0> (full evaluation, fine pass)",
-                         "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024,
-                         "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * 1024,
-                         "note": "ALGORITHMIC gather bytes (128 float2 table reads per sample) over the kernel time; the 49 MB table is "
-                                 "Infinity-Cache / L2 resident, so the bytes that reach HBM (`traffic`, PMC) are far fewer: this "
-                                 "fraction prices cache-served gathers against the HBM peak and is kept for the contract; "
-                                 "gather_roofline is the ceiling that binds"},
+                         "kernel": "mnrf::mf::tcnn_encode_kernel + mnrf::mf::tcnn_mfma_kernel<0,true> (full evaluation, fine pass)",
+                         "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024 + 256,
+                         "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * (1024 + 256),
+                         "note": "ALGORITHMIC bytes (128 float2 table reads + the 128-byte encoding planes written and read once, per "
+                                 "sample) over the time of the two launches; `traffic` = what reached the fabric in the encoding launch "
+                                 "(PMC).  The table is cache-resident: gather_roofline (L2) is the ceiling that binds, this fraction "
+                                 "is kept for the contract"},
             "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
                         "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
                         "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
@@ -441,6 +460,15 @@ def _build_commit():
             return f.read().strip()
     except OSError:
         return None
+
+
+def _pmc(kernel):
+    """Counters of `kernel` (one launch of a 32768-ray chunk) from the static profile, {} when absent."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return json.load(f).get("pmc", {}).get(kernel, {})
+    except (OSError, ValueError):
+        return {}
 
 
 def _traffic(kernel):

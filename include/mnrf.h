@@ -245,13 +245,13 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
 
-/* Roofline probe of the hash-grid field kernel: the launch geometry, position arithmetic and table gathers of the matrix-pipe
- * kernel of mnrf_tcnn_forward (16 levels x 8 corners per sample, ray-ordered samples from rays + z_vals) WITHOUT the MLPs and
- * head outputs.  out: (B, 4) floats.  Its launch time is the floor that the table's access pattern sets for that kernel
- * (bench.py `hash_grid_variant.gather_roofline`: frac = this / the field kernel's time <= 1 by construction). */
-int mnrf_bench_tcnn_gather(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
-                           int base_resolution, float bound, const float* weights, int64_t B, const float* rays,
-                           const float* z_vals, int spr, float* out, void* stream);
+/* The multiresolution hash encoding alone (what tinycudann's Encoding.forward returns, models/mirror_nerf_tcnn.py:225-227), level
+ * by level: planes[level * B + sample] = the level's two features (float2), 32 * B floats.  Samples: rows of `xyz` (stride >= 3)
+ * or rays + z_vals.  The first of the two launches of mnrf_tcnn_forward(enc_workspace != null); bench.py prices it against the
+ * L2 roofline (`hash_grid_variant.gather_roofline`). */
+int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double log2_per_level_scale, int base_resolution,
+                     float bound, int64_t B, const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals,
+                     int spr, float* planes, void* stream);
 
 /* Measurement aid for the hash-grid field: the rate of independent random gathers of 8 B (a float2 table entry) or 4 B (what
  * an fp16 table would fetch) from a table of `table_bytes` -- the ceiling that bounds that field's kernels once the table is

@@ -73,8 +73,8 @@ SIGNATURES = {
     "mnrf_dw_planes": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                               ctypes.POINTER(ctypes.c_void_p), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
     "mnrf_bench_gather": (_int, [ctypes.c_void_p, _i64, _int, _i64, _int, _c_f, _str]),
-    "mnrf_bench_tcnn_gather": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _c_f, _int,
-                                      _c_f, _str]),
+    "mnrf_tcnn_encode": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,
+                                _c_f, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),

@@ -450,8 +450,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 }
 // MODE of the matrix-pipe kernel: 0 = every fp32 operand as a hi/lo f16 pair, three MFMAs per product (~fp32 accuracy);
 // 1 = single-pass f16 (MNRF_TCNN_F16): operands rounded to nearest f16, ONE MFMA per product, fp32 accumulation -- what
-// tinycudann's FullyFusedMLP / the reference's precision=16 trainer compute (models/mirror_nerf_tcnn.py:36-49, train.py:586);
-// 2 = the gathers only (mnrf_bench_tcnn_gather: the roofline probe with the kernel's own access pattern)
+// tinycudann's FullyFusedMLP / the reference's precision=16 trainer compute (models/mirror_nerf_tcnn.py:36-49, train.py:586)
 template <int MODE>
 __device__ __forceinline__ void to_b(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -678,10 +677,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
                 }
             }
             to_b<MODE>(f8, eh[gi][0], el[gi][0]);
-            if (MODE == 2 && live[gi])       // the probe keeps the gathers alive with 16 B of output per sample (against 1 KiB of reads)
-                A.normal[idx[gi] * 4 + g] = ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
         }
-        if (MODE == 2) continue;
         // ---- sigma net: 32 -> 64 (ReLU) -> 16
         u32x4 sh_[NG][2], sl_[NG][2];
         {
@@ -1603,27 +1599,26 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     // MNRF_TCNN_F16: single-pass f16 MLPs (one MFMA per product); then the sigma-only launches run on the matrix pipe too
     // (with three products they measured 1.11 ms against the VALU kernel's 0.98 ms per 2.1 M samples; with one they win)
     const bool f16 = (flags & MNRF_TCNN_F16) != 0;
-    const bool probe = (flags & 0x80000000u) != 0;       // internal: mnrf_bench_tcnn_gather
-    const bool valu = !probe && (env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !f16) || grad);
-    if (probe && any_modulo) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_bench_tcnn_gather: hashed level of a non-power-of-two size");
+    const bool encode_only = (flags & 0x80000000u) != 0;       // internal: mnrf_tcnn_encode
+    const bool valu = !encode_only && (env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !f16) || grad);
+    if (encode_only && any_modulo) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_tcnn_encode: hashed level of a non-power-of-two size");
     if (!valu) {
         const long long n_tiles = (B + mf::TILE - 1) / mf::TILE;
         if (n_tiles > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
         static const bool attr = [] {
             (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)mf::tcnn_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mf::LDS_BYTES);
             return true;
         }();
         (void)attr;
         const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two 6-wave workgroups per CU
-        if (probe) hipLaunchKernelGGL(mf::tcnn_mfma_kernel<2>, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
-        else if (A.enc) {      // level-major encoding into the caller's planes, then the MLPs from the planes
+        if (A.enc) {      // level-major encoding into the caller's planes, then the MLPs from the planes
             const long long nb = (B + 255) / 256;
             if (nb > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
             hipLaunchKernelGGL(mf::tcnn_encode_kernel, dim3((unsigned)nb, NL), dim3(256), 0, s, A);
+            if (encode_only) return mnrf_check_launch("mnrf_tcnn_encode");
             if (f16) hipLaunchKernelGGL((mf::tcnn_mfma_kernel<1, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
             else hipLaunchKernelGGL((mf::tcnn_mfma_kernel<0, true>), g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
         } else if (f16) hipLaunchKernelGGL(mf::tcnn_mfma_kernel<1>, g2, b2, mf::LDS_BYTES, s, A, (int)n_tiles);
@@ -1761,16 +1756,16 @@ __global__ __launch_bounds__(256) void gather_bench_kernel(const T* __restrict__
     if (acc == 123.456f) out[0] = acc;      // keep the loads alive
 }
 
-// Roofline probe of the hash-grid field kernel: the launch geometry, position arithmetic and table gathers of
-// mf::tcnn_mfma_kernel (16 levels x 8 corners per sample, ray-ordered samples, the lane <-> level assignment) WITHOUT the
-// MLPs and the head outputs; `out` receives 4 floats per sample (the lane groups' partial sums).  The time of this launch is
-// the floor the table's access pattern sets for the field kernel on this device.
-extern "C" int mnrf_bench_tcnn_gather(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
-                                      int base_resolution, float bound, const float* weights, int64_t B, const float* rays,
-                                      const float* z_vals, int spr, float* out, void* stream) {
-    if (!out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_tcnn_gather: null output");
-    return mnrf_tcnn_forward(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, 0x80000000u, B, nullptr, 0,
-                             rays, z_vals, spr, nullptr, 3, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, stream);
+// The multiresolution hash encoding alone (tcnn_encode_kernel): planes[level][sample] = the level's two features, for samples
+// given as rows of `xyz` or as rays + z_vals.  This is the first of the two launches of mnrf_tcnn_forward(enc_workspace != null);
+// exposed for measurement (bench.py times it against the L2 roofline) and for callers that want the encoding itself.
+extern "C" int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                int base_resolution, float bound, int64_t B, const float* xyz, int64_t xyz_stride,
+                                const float* rays, const float* z_vals, int spr, float* planes, void* stream) {
+    if (!planes) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_encode: null output");
+    return mnrf_tcnn_forward(table, offsets17_host, log2_per_level_scale, base_resolution, bound, table /* unused */, 0x80000000u | MNRF_SIGMA_ONLY,
+                             B, xyz, xyz_stride, rays, z_vals, spr, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             planes, stream);
 }
 
 extern "C" int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gather, int64_t n_threads, int iters,

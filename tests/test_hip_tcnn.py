@@ -669,12 +669,12 @@ def test_g17_train_step_gradients(name, pinned, monkeypatch):
     assert len(report) >= 22
 
 
-def test_tcnn_single_pass_f16_mlp_and_gather_probe():
+def test_tcnn_single_pass_f16_mlp_and_level_major_encoding():
     """module.mlp_f16 (MNRF_TCNN_F16): the MLPs as single-pass f16 products on the matrix pipe -- "fp16 MLP on CDNA4 MFMA"
     (BASELINE config 5; tinycudann under precision=16, train.py:586).  Against the fp32-accurate default on the same inputs:
     f16 accuracy (a few 1e-3 of each output's scale), full AND sigma-only launches (the latter move to the matrix pipe).
-    And the roofline probe mnrf_bench_tcnn_gather (the kernel's gathers without its MLPs): per sample the sum of the 32
-    encoding channels, checked against the oracle's encoding."""
+    And mnrf_tcnn_encode (the level-major encoding launch) against the oracle's encoding; the two-launch forward against the
+    one-launch form."""
     from mirror_nerf_amd import _lib
     from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
     m, w, cfg = _model(6.0, seed=2, table_scale=0.2)
@@ -697,12 +697,21 @@ def test_tcnn_single_pass_f16_mlp_and_gather_probe():
     assert float(dp.median()) <= 2e-3
     assert float((got_s["sigma"] - ref_s["sigma"]).abs().max()) <= 4e-3 * max(1.0, float(ref_s["sigma"].abs().max()))
     assert torch.equal(got_s["sigma"], got["sigma"])                 # sigma-only on the matrix pipe: the same arithmetic as the full launch
-    # probe
-    out = torch.empty(N * S, 4, device=DEV)
+    # the encoding on its own (mnrf_tcnn_encode: the level-major first launch of the two-launch forward) against the oracle's
+    planes = torch.empty(16, N * S, 2, device=DEV)
     table = m.encoder.embeddings.detach().contiguous()
-    _lib.check(_lib.lib().mnrf_bench_tcnn_gather(_lib.ptr(table), _offsets17(m.cfg), m.cfg["S"], m.cfg["H"], float(m.bound),
-                                                 _lib.ptr(m._weights()), N * S, _lib.ptr(rays), _lib.ptr(z), S, _lib.ptr(out),
-                                                 _lib.stream()), "probe")
+    _lib.check(_lib.lib().mnrf_tcnn_encode(_lib.ptr(table), _offsets17(m.cfg), m.cfg["S"], m.cfg["H"], float(m.bound), N * S, None, 0,
+                                           _lib.ptr(rays), _lib.ptr(z), S, _lib.ptr(planes), _lib.stream()), "encode")
     xyz = (rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3).cpu().numpy()
     enc = O.hashgrid_encode(((xyz + np.float32(6.0)) / np.float32(12.0)).astype(np.float32), w["encoder.embeddings"], cfg)
-    assert np.max(np.abs(out.sum(-1).cpu().numpy() - enc.sum(-1))) <= 1e-4 * max(1.0, float(np.abs(enc).sum(-1).max()))
+    got_enc = planes.permute(1, 0, 2).reshape(N * S, 32).cpu().numpy()
+    assert np.max(np.abs(got_enc - enc)) <= 2e-6 * max(1.0, float(np.abs(enc).max()))
+    # ... and the two-launch forward (default from 32768 samples on) equals the one-launch form bit for bit
+    with torch.no_grad():
+        m.enc_planes_min = 1
+        two = m.field(N * S, rays=rays, z_vals=z, spr=S)
+        m.enc_planes_min = 1 << 62
+        one = m.field(N * S, rays=rays, z_vals=z, spr=S)
+        del m.enc_planes_min
+    for k in ("sigma", "rgb", "pred_normal", "is_mirror"):
+        assert torch.equal(two[k], one[k]), k
