@@ -253,6 +253,11 @@ int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double l
                      float bound, int64_t B, const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals,
                      int spr, float* planes, void* stream);
 
+/* Measurement aid for the weight-gradient GEMM (mnrf_dw_planes): the rate at which one persistent 8-wave workgroup per CU reads
+ * `bytes` of `buf` with the instruction that GEMM streams its operand planes with (global_load_lds_dwordx4, 1 KiB per
+ * wave-instruction, `depth` = 8 or 16 in flight per wave, aux = 0 default policy / 2 non-temporal), computing nothing. */
+int mnrf_bench_stream(const void* buf, int64_t bytes, int aux, int depth, void* stream);
+
 /* Measurement aid for the hash-grid field: the rate of independent random gathers of 8 B (a float2 table entry) or 4 B (what
  * an fp16 table would fetch) from a table of `table_bytes` -- the ceiling that bounds that field's kernels once the table is
  * Infinity-Cache resident (bench.py `hash_grid_variant.roofline`).  n_threads (multiple of 256) threads x iters gathers. */

@@ -50,8 +50,10 @@ constexpr int PL_BOOST_LOG2 = 4;
 #ifndef MNRF_EXP_STORE_AUX
 #define MNRF_EXP_STORE_AUX 2
 #endif
+// ... and of the GEMM's LDS-DMA loads of them: nt (2) measured 1.365 against 1.40-1.43 ms for the two evaluations of a training
+// step and 0.1-0.2 ms per step in alternating runs (round 4; the streaming probe reads 6.87 TB/s with nt, 6.06 without)
 #ifndef MNRF_EXP_LOAD_AUX
-#define MNRF_EXP_LOAD_AUX 0
+#define MNRF_EXP_LOAD_AUX 2
 #endif
 constexpr int PL_LOAD_AUX = MNRF_EXP_LOAD_AUX;      // the same operand of the GEMM's LDS-DMA loads of the planes
 constexpr int PL_STORE_AUX = MNRF_EXP_STORE_AUX;

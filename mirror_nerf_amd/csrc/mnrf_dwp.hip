@@ -152,37 +152,45 @@ __device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, con
     }
 }
 
-// ---- the same segment with a DEEPER prefetch: an experiment (MNRF_DWP_HALF=1), NOT the default.  With whole stages the two
-// 64-KiB buffers hold the stage being multiplied and ONE stage in flight, and the kernel's throughput scales with the number of
-// workgroups (2.9 TB/s at 128, 4.5 TB/s at 256) -- which looked like a bound by bytes in flight.  Here a stage travels as two
-// HALF-STAGES -- rows 0-15 and rows 16-31 of every tile, 512 B each -- through a ring of four 32-KiB buffers: one is multiplied
-// (v_mfma_f32_16x16x16_f16: a k step of 16 samples = ONE transposing read per operand) while THREE are in flight, 96 KiB per CU.
-// Measured (scripts/bw_probe.py, one box): 1.65 ms against 1.39 ms of the two-buffer version -- the K = 16 MFMA runs at half the
-// rate of the K = 32 one and binds this loop (with two of its three products compiled out: 1.32 ms = 4.85 TB/s; reading 1-KiB
-// contiguous runs instead of 512-byte halves changes nothing).  So even with the matrix work out of the way, 96 KiB in flight
-// buy 5 % over 64: the memory system is saturated at 4.6-4.9 TB/s on these boxes, the two-buffer kernel is there, and stays.  One LDS-DMA instruction brings the hi and the lo half-tile of a
-// feature block (lanes 0-31 / 32-63: two 512-byte runs in memory, 1 KiB lane-linear in LDS).  Every wave issues the same number
-// of instructions per half-stage (a wave without work re-loads a pair: identical bytes), so the wait for the oldest half-stage
-// is a counted s_waitcnt (VMEM operations complete in order).
-constexpr int DWP_HBUF = 32 * 1024;        // one half-stage: [dY half-tiles: 16 KiB][X half-tiles: 16 KiB]
-constexpr int DWP_HXOFF = 16 * 1024;
-static_assert(4 * DWP_HBUF == DWP_LDS, "the ring of four half-stage buffers fills the same LDS");
+// ---- the same segment through a RING of half-stages (round 4; the default).  What capped the two-buffer version above was not
+// the memory system: a streaming reader with the same instruction gets 6.06 TB/s (default policy) / 6.87 TB/s (nt) out of these
+// buffers (mnrf_bench_stream, scripts/bw_probe.py) where that loop got 4.5 -- and 4.67 with its LDS reads and MFMAs compiled out.
+// It refills a whole stage at a time: nothing new is requested until the LAST byte of a stage has landed and every wave has
+// passed the barrier, so the bytes in flight swing between 0 and one stage (64 KiB for the big jobs, 18 KiB for the small ones)
+// and the memory pipe of the CU runs dry once per stage.  Here a stage travels as two HALF-STAGES (rows 0-15 / 16-31 of every
+// tile: one LDS-DMA instruction brings the hi and the lo half-tile of a feature block, lanes 0-31 / 32-63, two 512-byte runs in
+// memory, 1 KiB lane-linear in LDS) through a ring of D slots of NP KiB; the stage being multiplied occupies two slots (its two
+// halves are read by ONE transposing operand read each and multiplied with the K = 32 MFMA, as above -- a first build of this
+// ring multiplied half-stages with the K = 16 MFMA, which runs at half the rate and then bound the loop), D - 2 half-stages are
+// on their way, and two more are requested as soon as a stage has been consumed: the bytes in flight swing between D - 4 and
+// D - 2 half-stages.  D = 5 for the 16 x 16-block jobs (160 KiB of LDS), up to 12 for the small ones.  Every wave issues the
+// same number Q of instructions per half-stage (a wave without work re-loads a pair: identical bytes), so "the two halves of
+// stage st have landed" is a counted s_waitcnt (VMEM operations complete in order).
+constexpr int DWP_RING_LDS = 160 * 1024;
 
-__device__ __forceinline__ f32x4 mfma_h16(const u32x2& a, const u32x2& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ u32x2 read_operand16(const char* half_tile, int lane8) {
-    typedef __attribute__((address_space(3))) h4 lds_h4;
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(half_tile + lane8)));
-}
 template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 24, "add the immediate");
+#define MNRF_WAIT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "add the immediate");
+    MNRF_WAIT_CASE(1) MNRF_WAIT_CASE(2) MNRF_WAIT_CASE(3) MNRF_WAIT_CASE(4) MNRF_WAIT_CASE(5) MNRF_WAIT_CASE(6) MNRF_WAIT_CASE(7)
+    MNRF_WAIT_CASE(8) MNRF_WAIT_CASE(9) MNRF_WAIT_CASE(10) MNRF_WAIT_CASE(11) MNRF_WAIT_CASE(12) MNRF_WAIT_CASE(13) MNRF_WAIT_CASE(14)
+    MNRF_WAIT_CASE(15) MNRF_WAIT_CASE(16) MNRF_WAIT_CASE(17) MNRF_WAIT_CASE(18) MNRF_WAIT_CASE(19) MNRF_WAIT_CASE(20) MNRF_WAIT_CASE(21)
+    MNRF_WAIT_CASE(22) MNRF_WAIT_CASE(23) MNRF_WAIT_CASE(24)
+#undef MNRF_WAIT_CASE
+}
+// at most R half-stages (of Q instructions each) may still be on their way: R is a run-time number in [0, RMAX]
+template <int Q, int RMAX> __device__ __forceinline__ void wait_half_stages(int r) {
+    if (r >= RMAX) wait_vm<RMAX * Q>();
+    else if constexpr (RMAX > 0) wait_half_stages<Q, RMAX - 1>(r);
+}
+
+// operand of the K = 32 MFMA from the two half-tiles of a feature block that sit in two ring slots: rows 0-15 | rows 16-31
+__device__ __forceinline__ u32x4 read_operand2(const char* half0, const char* half1, int lane8) {
+    typedef __attribute__((address_space(3))) h4 lds_h4;
+    const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(half0 + lane8));
+    const h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(half1 + lane8));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l.x, l.y, h.x, h.y};
 }
 
 template <int MB, int KB, int NA, int NX>
@@ -193,15 +201,13 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
     const int wn = wave & 3, wk = wave >> 2;
     const int lane8 = lane * 8;
     const bool has_a = wn * MB < NA;
-    constexpr int NP = NA + NX;                  // feature blocks = (hi, lo) half-tile pairs per half-stage
+    constexpr int NP = NA + NX;                  // feature blocks = (hi, lo) half-tile pairs per half-stage = KiB per ring slot
     constexpr int Q = (NP + 7) / 8;              // LDS-DMA instructions per wave and half-stage
-    static_assert(NA * 1024 <= DWP_HXOFF && NX * 1024 <= DWP_HBUF - DWP_HXOFF, "a half-stage fits its buffer");
+    constexpr int SLOT = NP * 1024;
+    constexpr int D = DWP_RING_LDS / SLOT < 12 ? DWP_RING_LDS / SLOT : 12;      // ring slots
+    static_assert(D >= 5 && (D - 4) * Q <= 24, "ring depth / wait immediates");
     char* const lds = dwp_smem;
-#ifdef MNRF_EXP_DWP_CONTIG      // experiment (wrong data): the same byte count as 1-KiB contiguous runs -- is the 512-byte granularity the cost?
-    const int lsrc = lane * 16;
-#else
     const int lsrc = (lane >> 5) * PL_TILE_BYTES + (lane & 31) * 16;      // hi tile (lanes 0-31) / lo tile (32-63) of the block
-#endif
 
     f32x4 acc[MB][KB], bacc[MB];
 #pragma unroll
@@ -210,78 +216,77 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
 #pragma unroll
         for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const u32x2 ones = u32x2{0x3c003c00u, 0x3c003c00u};
+    const u32x4 ones = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
 
     const int n_hs = 2 * (s_hi - s_lo);
-    auto issue = [&](int hs) {      // half-stage hs = rows 16 (hs & 1) .. of sample block s_lo + hs / 2, into ring slot hs & 3
+    auto issue = [&](int hs, int ring_slot) {      // half-stage hs = rows 16 (hs & 1) .. of sample block s_lo + hs / 2
         const int s = s_lo + (hs >> 1);
-#ifdef MNRF_EXP_DWP_CONTIG
-        const char* ya = Yb + (long long)s * PLY_SB_BYTES + (hs & 1) * PL_TILE_BYTES + lsrc;
-        const char* xa = Xb + (long long)s * PLX_SB_BYTES + (hs & 1) * PL_TILE_BYTES + lsrc;
-#else
         const char* ya = Yb + (long long)s * PLY_SB_BYTES + (hs & 1) * 512 + lsrc;
         const char* xa = Xb + (long long)s * PLX_SB_BYTES + (hs & 1) * 512 + lsrc;
-#endif
-        char* base = lds + (hs & 3) * DWP_HBUF;
+        char* base = lds + ring_slot * SLOT;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             int pr = wave + 8 * q;
             if (pr >= NP) pr -= NP;              // (no work left for this wave: an identical re-load keeps the counts uniform)
             const char* src = pr < NA ? ya + pr * PL_FB_BYTES : xa + (pr - NA) * PL_FB_BYTES;
-            char* dst = pr < NA ? base + pr * 1024 : base + DWP_HXOFF + (pr - NA) * 1024;
+            char* dst = base + pr * 1024;        // [dY half-tile pairs: NA KiB][X half-tile pairs: NX KiB]
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, PL_LOAD_AUX);
         }
     };
-    static_assert(NP >= 8 || 2 * NP >= 8 + 1 || true, "");
 
-    __syncthreads();                 // the previous segment's last half-stage has been read by every wave
-    if (n_hs > 0) issue(0);
-    if (n_hs > 1) issue(1);
-    if (n_hs > 2) issue(2);
-    for (int hs = 0; hs < n_hs; ++hs) {
-        // the two half-stages issued after hs may still be on their way: 2 Q instructions of this wave (fewer at the end)
-        if (hs + 2 < n_hs) wait_vm<2 * Q>();
-        else if (hs + 1 < n_hs) wait_vm<Q>();
-        else wait_vm<0>();
-        // a RAW barrier: __syncthreads() waits for vmcnt(0) first and would drain the three half-stages in flight (the first
-        // build of this loop did, and ran at 3.0 TB/s).  LDS reads of half-stage hs - 1 were consumed by its MFMAs.
-        __builtin_amdgcn_s_barrier();                         // everybody's tiles of hs are there; slot (hs - 1) & 3 has been read
-        if (hs + 3 < n_hs) issue(hs + 3);
-        const char* A = lds + (hs & 3) * DWP_HBUF;
-        const char* X = A + DWP_HXOFF;
+    __syncthreads();                 // the previous segment's last stage has been read by every wave
+    int next_hs = 0, next_slot = 0;  // next half-stage to request and the slot it goes to (hs mod D)
+#pragma unroll 1
+    for (; next_hs < D - 2 && next_hs < n_hs; ++next_hs) { issue(next_hs, next_slot); next_slot = next_slot + 1 == D ? 0 : next_slot + 1; }
+    int cur = 0;                     // ring slot of half-stage 2 st
+#pragma unroll 1
+    for (int st = 0; 2 * st < n_hs; ++st) {
+        // half-stages 2 st and 2 st + 1 must have landed; the ones requested after them may still be on their way
+        wait_half_stages<Q, D - 4>(next_hs - (2 * st + 2));
+        // a RAW barrier: __syncthreads() waits for vmcnt(0) first and would drain the ring.  After it everybody's tiles of stage
+        // st are there and stage st - 1 has been read (its LDS reads were consumed by its MFMAs): its two slots are free
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int k = 0; k < 2 && next_hs < n_hs; ++k, ++next_hs) { issue(next_hs, next_slot); next_slot = next_slot + 1 == D ? 0 : next_slot + 1; }
+        const int cur1 = cur + 1 == D ? 0 : cur + 1;
+        const char* A0 = lds + cur * SLOT;
+        const char* A1 = lds + cur1 * SLOT;
+        const char* X0 = A0 + NA * 1024;
+        const char* X1 = A1 + NA * 1024;
+#ifdef MNRF_EXP_DWP_NOMATH      // experiment (no sums): the LDS-DMA stream, counted waits and barriers alone -- what the plane reads cost
+        if (false) {
+#else
         if (has_a) {
-            u32x2 ah[MB], al[MB];
+#endif
+            u32x4 ah[MB], al[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                ah[mb] = read_operand16(A + (wn * MB + mb) * 1024, lane8);
-                al[mb] = read_operand16(A + (wn * MB + mb) * 1024 + 512, lane8);
+                ah[mb] = read_operand2(A0 + (wn * MB + mb) * 1024, A1 + (wn * MB + mb) * 1024, lane8);
+                al[mb] = read_operand2(A0 + (wn * MB + mb) * 1024 + 512, A1 + (wn * MB + mb) * 1024 + 512, lane8);
             }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const u32x2 bh = read_operand16(X + (wk * KB + kb) * 1024, lane8);
-                const u32x2 bl = read_operand16(X + (wk * KB + kb) * 1024 + 512, lane8);
+                const u32x4 bh = read_operand2(X0 + (wk * KB + kb) * 1024, X1 + (wk * KB + kb) * 1024, lane8);
+                const u32x4 bl = read_operand2(X0 + (wk * KB + kb) * 1024 + 512, X1 + (wk * KB + kb) * 1024 + 512, lane8);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     f32x4 c = acc[mb][kb];
-#ifdef MNRF_EXP_DWP_ONE_MFMA      // experiment (wrong sums): is the half-stage version bound by the K = 16 MFMA rate?
-                    c = mfma_h16(ah[mb], bh, c);
-#else
-                    c = mfma_h16(al[mb], bh, c);
-                    c = mfma_h16(ah[mb], bl, c);
-                    c = mfma_h16(ah[mb], bh, c);
-#endif
+                    c = mfma_h(al[mb], bh, c);      // lo . hi
+                    c = mfma_h(ah[mb], bl, c);      // hi . lo
+                    c = mfma_h(ah[mb], bh, c);      // hi . hi
                     acc[mb][kb] = c;
                 }
             }
             if (bias && wk == 0) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    bacc[mb] = mfma_h16(al[mb], ones, bacc[mb]);
-                    bacc[mb] = mfma_h16(ah[mb], ones, bacc[mb]);
+                    bacc[mb] = mfma_h(al[mb], ones, bacc[mb]);
+                    bacc[mb] = mfma_h(ah[mb], ones, bacc[mb]);
                 }
             }
         }
+        cur = cur1 + 1 == D ? 0 : cur1 + 1;
     }
     if (has_a) {
 #pragma unroll
@@ -498,13 +503,13 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     A.part = ws;
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
-        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_RING_LDS);
         return true;
     }();
     (void)once;
-    // MNRF_DWP_HALF=1 (read once): the half-stage ring (experiment, see dwp_segment_run_h) instead of whole stages through two buffers
-    static const bool half = [] { const char* e = getenv("MNRF_DWP_HALF"); return e && atoi(e) == 1; }();
-    if (half) hipLaunchKernelGGL(dwp_gemm_kernel<true>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    // the ring of half-stages (dwp_segment_run_h) is the default; MNRF_DWP_RING=0 (read once) selects the two-buffer version
+    static const bool ring = [] { const char* e = getenv("MNRF_DWP_RING"); return !(e && atoi(e) == 0); }();
+    if (ring) hipLaunchKernelGGL(dwp_gemm_kernel<true>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_RING_LDS, s, A);
     else hipLaunchKernelGGL(dwp_gemm_kernel<false>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
 
     DwpFinishArgs F;
@@ -568,3 +573,44 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
 }
 
 }  // namespace mnrf
+
+// ---------------------------------------------------------------------------------------------------------- streaming-read probe
+// What does the memory system deliver to the instruction dwp_gemm_kernel streams with?  One persistent 8-wave workgroup per CU
+// reads its contiguous share of `buf` with global_load_lds_dwordx4 (1 KiB per wave-instruction, lane-linear), `depth`
+// instructions in flight per wave, into a ring it never reads; aux = 0 (default policy) or 2 (nt).  scripts/bw_probe.py prints
+// the rate next to the GEMM's (MI355X_MICROARCH.md quotes 6.4 TB/s default / 6.5-6.8 nt for this instruction chip-wide).
+namespace mnrf {
+template <int AUX, int DEPTH>
+__global__ __launch_bounds__(512, 1) void stream_probe_kernel(const char* __restrict__ buf, long long share) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* src = buf + (long long)blockIdx.x * share + wave * 1024 + lane * 16;
+    char* dst = dwp_smem + wave * (DEPTH * 1024);
+    const int n = (int)(share / 8192);
+    for (int k = 0; k < n; ++k) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)k * 8192),
+                                         (__attribute__((address_space(3))) void*)(dst + (k % DEPTH) * 1024), 16, 0, AUX);
+        if (k >= DEPTH - 1) {
+            if constexpr (DEPTH == 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+}  // namespace mnrf
+
+extern "C" int mnrf_bench_stream(const void* buf, int64_t bytes, int aux, int depth, void* stream) {
+    using namespace mnrf;
+    if (!buf || bytes < (int64_t)256 * 8192) return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_stream: buffer too small");
+    if ((aux != 0 && aux != 2) || (depth != 8 && depth != 16)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_stream: aux 0|2, depth 8|16");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long share = bytes / cus / 8192 * 8192;
+    const size_t lds = (size_t)8 * depth * 1024;
+    hipStream_t s = (hipStream_t)stream;
+    if (aux == 0 && depth == 8) hipLaunchKernelGGL((stream_probe_kernel<0, 8>), dim3(cus), dim3(512), lds, s, (const char*)buf, share);
+    else if (aux == 2 && depth == 8) hipLaunchKernelGGL((stream_probe_kernel<2, 8>), dim3(cus), dim3(512), lds, s, (const char*)buf, share);
+    else if (aux == 0) hipLaunchKernelGGL((stream_probe_kernel<0, 16>), dim3(cus), dim3(512), lds, s, (const char*)buf, share);
+    else hipLaunchKernelGGL((stream_probe_kernel<2, 16>), dim3(cus), dim3(512), lds, s, (const char*)buf, share);
+    return mnrf_check_launch("mnrf_bench_stream");
+}

@@ -39,6 +39,12 @@ print(f"torch sum over {big.numel() * 4 / 1e9:.2f} GB: {big.numel() * 4 / t / 1e
 dst = torch.empty_like(big)
 t = timed(lambda: dst.copy_(big))
 print(f"torch copy of the same (read + write): {2 * big.numel() * 4 / t / 1e12:.2f} TB/s")
+# (d) the GEMM's own instruction: global_load_lds_dwordx4 streaming reads of the same buffer, nothing computed
+for aux in (0, 2):
+    for depth in (8, 16):
+        t = timed(lambda: _lib.check(L.mnrf_bench_stream(ctypes.c_void_p(xs[0].data_ptr()), xs[0].numel(), aux, depth, _lib.stream()), "stream"))
+        print(f"LDS-DMA streaming read ({'nt' if aux else 'default'} policy, {depth} x 1 KiB in flight per wave) of {xs[0].numel() / 1e9:.2f} GB: "
+              f"{xs[0].numel() // 256 // 8192 * 8192 * 256 / t / 1e12:.2f} TB/s")
 n = len(Bs)
 bs = (ctypes.c_int64 * n)(*Bs)
 seed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in Bs]
