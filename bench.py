@@ -354,7 +354,7 @@ def hash_grid_leg(dev, rays):
                                 "under precision=16 (train.py:586); ~1e-3 relative to the default (tests); sigma-only launches on "
                                 "the matrix pipe as well"},
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
-                    "against tinycudann unpinned (DESIGN.md 4.3); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
+                    "downstream of the encoder pinned by fixtures G17, the encoder's interpolation unpinned (DESIGN.md 2.2); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
                     "sigma-only launches: fp32 VALU kernel"}
 
 
@@ -717,7 +717,7 @@ def main():
                          "board_power_cap_w": tele["power_cap_w"],
                          "power_note": "medians of the 200 ms samples taken through the timed frames (`telemetry` has min/median/max, "
                                        "throttle bits and the power-limit residency); the split-f16 kernels run at the package power "
-                                       "limit and get ~2.1-2.2 GHz instead of the 2.4 GHz `peak` assumes (DESIGN.md 9.1)",
+                                       "limit and get ~2.1-2.2 GHz instead of the 2.4 GHz `peak` assumes (profiles/DIARY.md 9.1)",
                          "sigma_only_kernel_tflops": sig_tf,
                          "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
         }

@@ -2,7 +2,7 @@
 throttle state of one GPU, sampled every ~200 ms on a background thread while a timed region runs.
 
 Why it exists: the dominant kernel runs at the package power limit, so the clock a box grants -- not the 2.4 GHz the MFMA
-peak is quoted at -- sets its speed, and boxes of the pool differ by 14-17 %.  A bench line has to say
+peak is quoted at -- sets its speed, and boxes of the pool differ by 14-17 % (profiles/DIARY.md 9.1).  A bench line has to say
 whether a slow number is the box or the code: `summary()` gives min / median / max over the region, the OR of the
 throttle bits and the fraction of the region spent at the power limit (ppt residency), for EACH timed leg.
 
