@@ -358,6 +358,62 @@ def hash_grid_leg(dev, rays):
                     "sigma-only launches: fp32 VALU kernel"}
 
 
+def trained_leg(dev):
+    """Scene-dependent effects need trained weights: the pair of fixture G11 (tests/golden/g11_trained_weights.npz: trained on the
+    analytic mirror scene of make_golden_trained.py through this package, 19.1 dB held-out) rendered at 800x800 from a view of
+    that scene (the scene_views camera at angle 0.2), eval rules with the PREDICTED mirror mask -- plain frame and ray-fused
+    maps-only frame, with mean power x time = energy per frame and the clock.  Not `value` (random-init weights stay the headline)."""
+    import numpy as np
+    import torch
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN, synthetic as SY
+    from mirror_nerf_amd.telemetry import SmiSampler
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g11_trained_weights.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    models = {}
+    for name in ("coarse", "fine"):
+        m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+        m.load_state_dict({k[len(name) + 2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "__")})
+        models[name] = m.to(dev)
+    emb = {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
+    a = 0.2
+    pose = SY.look_at_pose(eye=(2.6 * np.sin(a), -2.6 * np.cos(a) + 0.2, 0.9 + 0.5), target=(0.1, 0.6, 0.6))
+    rays = SY.device_rays(H, W, dev, pose=pose, camera_angle_x=0.9)
+    out = {}
+    for key, kw in (("plain", {}), ("maps_only_fused", {"maps_only": True})):
+        f = lambda: M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,  # noqa: E731
+                                        trace_secondary_rays=True, to_cpu=False, **kw)
+        r = f()
+        torch.cuda.synchronize()
+        MN.LAUNCH_LOG = []
+        smi = SmiSampler(dev.index or 0, 0.2)
+        with smi:
+            t0 = time.perf_counter()
+            for _ in range(2):
+                r = f()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+        n_launch = len(MN.LAUNCH_LOG) / 2
+        MN.LAUNCH_LOG = None
+        tele = smi.summary()
+        pw = (tele.get("power_w") or {}).get("median")
+        mask = r["mirror_mask_fine"]
+        n_refl = float((mask > 0.5).sum())
+        out[key] = {"rays_per_s": (H * W + n_refl) / dt, "ms_per_frame": dt * 1e3, "field_launches_per_frame": n_launch,
+                    "power_w_median": pw, "energy_j_per_frame": pw * dt if pw else None,
+                    "sclk_mhz_median": (tele.get("sclk_mhz") or {}).get("median")}
+        out["reflected_rays_per_frame"] = n_refl
+        if key == "plain":
+            w = r.get("weights_fine")
+            out["fine_samples_with_zero_weight"] = float((w == 0).float().mean()) if w is not None else None
+    out["note"] = ("G11 trained pair, 800x800 view of its analytic scene, eval rules (predicted mask: reflected rays = mirror pixels "
+                   "of chunks that hold any); fine_samples_with_zero_weight = the share of samples whose heads exact head skipping "
+                   "(models/rendering.py:190-213: w_i = 0) could leave out -- not built, DESIGN.md 8")
+    return out
+
+
 def roughness_leg(dev, models, emb):
     """BASELINE config 4 at the shape run.sh:185-208 runs it (mode 5, control_mirror_roughness): 480x360 (run.sh:47-48),
     64 coarse + 64 importance samples, chunk 16384, one bounce, trace_ray_times = 64 jittered reflections per mirror ray,
@@ -665,6 +721,7 @@ def main():
 
     hash_grid = hash_grid_leg(dev, rays) if not a.no_train else None
     rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train) else None
+    trained = trained_leg(dev) if (world == 1 and not a.no_train) else None
 
     if rank == 0:
         split = a.precision == "split"
@@ -741,6 +798,8 @@ def main():
             res["hash_grid_variant"] = hash_grid
         if rough is not None:
             res["roughness_variant"] = rough
+        if trained is not None:
+            res["trained_weights_variant"] = trained
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
         print(json.dumps(res), flush=True)
