@@ -186,9 +186,11 @@ class FieldFn(torch.autograd.Function):
         mod.__dict__["_mnrf_uses"] = uses
         fold = FOLD_GRADS or ctx.planes
         st = mod.__dict__.get("_mnrf_pending") if fold else None
+        standalone = False
         if st is not None and st.shapes != ctx.param_shapes:
-            st = None                        # (tensors of another parameter set pending: this evaluation stands alone)
-            fold = False
+            st = None                        # (tensors of another parameter set pending: this evaluation stands alone and
+            fold = False                     #  leaves that set -- its partial sums and its tape -- where it is)
+            standalone = True
         first = st is None
         if first:
             st = _Pending(ctx.param_names, ctx.param_shapes, dev)
@@ -244,7 +246,8 @@ class FieldFn(torch.autograd.Function):
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)
         d_params = None
         if hand_over:
-            mod.__dict__.pop("_mnrf_pending", None)
+            if not standalone:
+                mod.__dict__.pop("_mnrf_pending", None)
             d_params = st.finish()            # the weight-gradient GEMM over the tape (planes route); complete now
             mod.__dict__["_mnrf_flat_grad"] = st.flat     # dist.allreduce_gradients reduces this buffer in place when .grad aliases it
             st = None
