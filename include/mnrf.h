@@ -342,6 +342,8 @@ int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double 
  * models/mirror_nerf_tcnn.py:172-218 / utils/func.py:10-25 -- to d_table, d_weights and d_xyz. */
 int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host);
 int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags /* MNRF_TCNN_GRAD_F16 or 0 */);
+/* With MNRF_TCNN_GRAD_F16 the LAST FOUR floats of that workspace are an overflow word (uint32, first of the four): non-zero after
+ * the call when a half2 sum left the f16 range (it was clamped to +-65504 / scale, not inf) -- fall back to fp32 atomics then. */
 int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                        int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,

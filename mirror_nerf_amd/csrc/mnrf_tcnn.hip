@@ -1635,10 +1635,19 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
 }
 
 // d_table += g16 / scale for the entries [e0, e1) of the levels that accumulated in half2 (MNRF_TCNN_GRAD_F16)
-__global__ void tcnn_fold16_kernel(const __half2* __restrict__ g16, float2* __restrict__ d_table, long long e0, long long e1, float inv) {
+// A sum that left the f16 range (|scaled gradient| > 65504: tinycudann pairs its f16 gradients with a loss scale and an inf check)
+// is clamped to the largest finite value instead of carrying inf / nan into d_table and the optimizer state, and raises *overflow
+// (the word behind the half2 table in the workspace; the Python shim reads it one step late, warns and falls back to fp32 atomics).
+__global__ void tcnn_fold16_kernel(const __half2* __restrict__ g16, float2* __restrict__ d_table, long long e0, long long e1, float inv,
+                                   unsigned* __restrict__ overflow) {
     const long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= e1) return;
-    const float2 v = __half22float2(g16[e]);
+    float2 v = __half22float2(g16[e]);
+    if (!(fabsf(v.x) <= 65504.f) || !(fabsf(v.y) <= 65504.f)) {
+        v.x = v.x != v.x ? 0.f : fminf(fmaxf(v.x, -65504.f), 65504.f);
+        v.y = v.y != v.y ? 0.f : fminf(fmaxf(v.y, -65504.f), 65504.f);
+        atomicOr(overflow, 1u);
+    }
     float2 d = d_table[e];
     d.x += v.x * inv;
     d.y += v.y * inv;
@@ -1655,7 +1664,7 @@ extern "C" int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_
 extern "C" int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags) {
     if (!offsets17_host) return 0;
     const int64_t base = mnrf_tcnn_backward_workspace_floats(offsets17_host);
-    return base + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] : 0);
+    return base + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] + 4 : 0);      // (+ the overflow word, 16-byte padded)
 }
 
 extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
@@ -1722,7 +1731,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
         const long long e1 = A.off[NL];
         if (e0 >= 0 && e1 > e0)
             hipLaunchKernelGGL(tcnn_fold16_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P.g16,
-                               (float2*)d_table, e0, e1, 1.f / P.g16_scale);
+                               (float2*)d_table, e0, e1, 1.f / P.g16_scale, (unsigned*)(P.g16 + offsets17_host[NL]));
     }
     return mnrf_check_launch("mnrf_tcnn_backward");
 }

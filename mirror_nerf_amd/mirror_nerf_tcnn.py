@@ -59,6 +59,24 @@ MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
 ENC_PLANES_MIN = int(os.environ.get("MNRF_TCNN_PLANES_MIN", "32768"))
 
 
+def _check_f16_overflow(module):
+    """Read the overflow words of earlier packed-f16 backward passes of `module` (include/mnrf.h): a table-gradient sum left the
+    f16 range -- it was clamped, not inf, so the optimizer state is intact -- and the module goes back to fp32 atomics."""
+    pend = module.__dict__.pop("_mnrf_f16_overflow", None)
+    if not pend:
+        return False
+    hit = False
+    for host, ev in pend:
+        ev.synchronize()
+        hit |= bool(host.item())
+    if hit:
+        import warnings
+        warnings.warn("mirror_nerf_amd: a packed-f16 table-gradient sum left the f16 range in an earlier step (clamped); this model "
+                      "accumulates its table gradient with fp32 atomics from now on (table_grad_f16 = False)", RuntimeWarning, stacklevel=3)
+        module.table_grad_f16 = False
+    return hit
+
+
 class TcnnFieldFn(torch.autograd.Function):
     """mnrf_tcnn_forward / mnrf_tcnn_backward.
     apply(module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *mlp_params) ->
@@ -111,6 +129,8 @@ class TcnnFieldFn(torch.autograd.Function):
         # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
         flags = ctx.cut | (_lib.MNRF_TCNN_GRAD_F16 if getattr(m, "table_grad_f16", GRAD_F16) else 0)
         ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
+        if flags & _lib.MNRF_TCNN_GRAD_F16:
+            _check_f16_overflow(m)      # the previous backward's overflow word (its copy finished long ago: no queue drain)
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(
@@ -118,6 +138,12 @@ class TcnnFieldFn(torch.autograd.Function):
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
                 p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), flags,
                 _lib.stream()), "mnrf_tcnn_backward")
+        if B and (flags & _lib.MNRF_TCNN_GRAD_F16):
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(ws[-4:-3].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            m.__dict__.setdefault("_mnrf_f16_overflow", []).append((host, ev))
         grads, off = [], 0
         for _name, rows, used, padded in _BLOB:
             if padded:

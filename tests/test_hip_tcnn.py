@@ -1,6 +1,8 @@
 """Hash-grid field (BASELINE config 5): the HIP kernel against the oracle restatement.
 Parity against tinycudann itself is UNPINNED (not installable here); these tests pin the kernel to this
 repository's own CPU restatement of gridencoder.cu / shencoder.cu / mirror_nerf_tcnn.py."""
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -715,3 +717,28 @@ def test_tcnn_single_pass_f16_mlp_and_level_major_encoding():
         del m.enc_planes_min
     for k in ("sigma", "rgb", "pred_normal", "is_mirror"):
         assert torch.equal(two[k], one[k]), k
+
+
+def test_tcnn_packed_f16_gradient_overflow_is_clamped_and_reported():
+    """MNRF_TCNN_GRAD_F16: a table-gradient sum beyond the f16 range (|g| * 2^10 > 65504) is clamped -- no inf / nan in
+    d_table -- and reported one backward later, when the module falls back to fp32 atomics."""
+    m, _w, _cfg = _model(1.0, seed=4, table_scale=0.2)
+    m.table_grad_f16 = True
+    g = torch.Generator().manual_seed(3)
+    B = 512
+    x6 = torch.cat([torch.rand(B, 3, generator=g) * 0.02 + 0.4, torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)], 1).to(DEV)
+
+    def step(scale):
+        m.zero_grad()
+        out = m(x6.clone().requires_grad_(True), compute_normal=False)
+        (out["sigma"].sum() * scale).backward()
+        return m.encoder.embeddings.grad
+    gtab = step(1e4)                                   # all samples in a few cells of the finest levels: sums far beyond 64
+    assert bool(torch.isfinite(gtab).all()) and float(gtab.abs().max()) <= 65504.0 / 1024 * 1.001
+    assert m.table_grad_f16 is True
+    with pytest.warns(RuntimeWarning, match="left the f16 range"):
+        step(1.0)
+    assert m.table_grad_f16 is False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert bool(torch.isfinite(step(1e4)).all())   # fp32 atomics now
