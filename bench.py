@@ -348,14 +348,14 @@ def hash_grid_leg(dev, rays):
             "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
                         "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
                         "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
-                        "sigma_only_launch_ms_fp32_valu_default": sum(t for _, t in sig32) / max(1, len(sig32)),
+                        "sigma_only_launch_ms_default_arithmetic": sum(t for _, t in sig32) / max(1, len(sig32)),
                         "note": "module.mlp_f16 / MNRF_TCNN_F16: single-pass f16 MLPs on the matrix pipe (one MFMA per product, fp32 "
                                 "accumulation) -- \"fp16 MLP on CDNA4 MFMA\" as BASELINE config 5 words it, the arithmetic of tinycudann "
                                 "under precision=16 (train.py:586); ~1e-3 relative to the default (tests); sigma-only launches on "
                                 "the matrix pipe as well"},
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
                     "downstream of the encoder pinned by fixtures G17, the encoder's interpolation unpinned (DESIGN.md 2.2); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
-                    "sigma-only launches: fp32 VALU kernel"}
+                    "sigma-only launches: the same two launches since round 4 (fp32 VALU kernel below 32768 samples)"}
 
 
 def trained_leg(dev):

@@ -1596,11 +1596,12 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     // The matrix-pipe kernel takes the full evaluations without the density-gradient normal (see its header for the
     // measurements); everything else, and tables with a hashed level whose size is not a power of two (integer modulo per
     // corner), stays on the VALU kernel.
-    // MNRF_TCNN_F16: single-pass f16 MLPs (one MFMA per product); then the sigma-only launches run on the matrix pipe too
-    // (with three products they measured 1.11 ms against the VALU kernel's 0.98 ms per 2.1 M samples; with one they win)
+    // MNRF_TCNN_F16: single-pass f16 MLPs (one MFMA per product); then the sigma-only launches run on the matrix pipe too.  With three
+    // products the ONE-launch form measured 1.11 ms against the VALU kernel's 0.98 ms per 2.1 M samples and stays on the VALU
+    // kernel; behind the level-major encoding launch (enc_workspace) the sigma-only MLPs take the matrix pipe in both arithmetics
     const bool f16 = (flags & MNRF_TCNN_F16) != 0;
     const bool encode_only = (flags & 0x80000000u) != 0;       // internal: mnrf_tcnn_encode
-    const bool valu = !encode_only && (env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !f16) || grad);
+    const bool valu = !encode_only && (env_valu || (flags & MNRF_TCNN_VALU) || any_modulo || (sigma_only && !f16 && !enc_workspace) || grad);
     if (encode_only && any_modulo) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_tcnn_encode: hashed level of a non-power-of-two size");
     if (!valu) {
         const long long n_tiles = (B + mf::TILE - 1) / mf::TILE;

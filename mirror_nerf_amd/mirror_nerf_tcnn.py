@@ -249,7 +249,7 @@ class MirrorNeRFTcnn(nn.Module):
         # level-major encoding planes (include/mnrf.h: enc_workspace): the launches that take the matrix pipe encode level by
         # level into 128 B per sample of scratch -- a third of the fabric traffic of the one-launch form at frame-sized batches
         enc = None
-        on_pipe = not grad_normal and not (flags & _lib.MNRF_TCNN_VALU) and (not sigma_only or (flags & _lib.MNRF_TCNN_F16))
+        on_pipe = not grad_normal and not (flags & _lib.MNRF_TCNN_VALU)
         if on_pipe and B >= getattr(self, "enc_planes_min", ENC_PLANES_MIN):
             enc = torch.empty(32 * B, dtype=torch.float32, device=dev)
         from . import mirror_nerf as _mn
