@@ -318,6 +318,7 @@ def hash_grid_leg(dev, rays):
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
             "table_gradient_sparsity": sparse,
             "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
+            "train_table_gradient": "default: one packed 64-bit fixed-point atomic per entry (MNRF_TCNN_GRAD_FIXED, exact integer sums); _f16_table_grads: packed half2 atomics",
             "gather_roofline": {"bound": "l2", "kernel": "mnrf::mf::tcnn_encode_kernel (level-major encoding: 16 levels x 8 corners per sample; "
                                           "the dominant launch of the two-launch field evaluation)",
                                 "achieved": (l2_bytes / (enc_ms * 1e-3) / 1e9) if l2_bytes else None, "peak": 34500.0, "unit": "GB/s",

@@ -56,6 +56,13 @@ extern "C" {
                                   half2 with ONE packed atomic per entry (global_atomic_pk_add_f16) instead of two fp32 atomics --
                                   tinycudann's gradient precision (models/mirror_nerf_tcnn.py:36-49 under train.py:586); the
                                   workspace then has mnrf_tcnn_backward_workspace_floats2() floats */
+#define MNRF_TCNN_GRAD_FIXED 512u /* mnrf_tcnn_backward: the levels without private copies accumulate both features of a table entry with ONE
+                                  64-bit integer atomic (two 32-bit fixed-point halves under a per-level power-of-two scale taken
+                                  from the step's own sum of gradient magnitudes, under which no entry can overflow; exact integer
+                                  sums, order-independent; step ~2^-16 of a level's largest contribution); the scatter runs as a second
+                                  launch over dL/d encoding planes.  Workspace: mnrf_tcnn_backward_workspace_floats3() floats, of
+                                  which the caller zero-fills the first mnrf_tcnn_backward_workspace_floats().  Ignored together
+                                  with MNRF_TCNN_GRAD_F16. */
 #define MNRF_TCNN_F16 256u      /* mnrf_tcnn_forward: single-pass f16 MLPs -- operands rounded to f16, ONE MFMA per product, fp32 accumulation:
                                   "fp16 MLP on CDNA4 MFMA" as BASELINE config 5 words it and as the reference computes under
                                   tinycudann / precision=16 (train.py:586); ~1e-3 relative; sigma-only launches then take the matrix pipe too */
@@ -344,6 +351,7 @@ int64_t mnrf_tcnn_backward_workspace_floats(const int64_t* offsets17_host);
 int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17_host, unsigned flags /* MNRF_TCNN_GRAD_F16 or 0 */);
 /* With MNRF_TCNN_GRAD_F16 the LAST FOUR floats of that workspace are an overflow word (uint32, first of the four): non-zero after
  * the call when a half2 sum left the f16 range (it was clamped to +-65504 / scale, not inf) -- fall back to fp32 atomics then. */
+int64_t mnrf_tcnn_backward_workspace_floats3(const int64_t* offsets17_host, unsigned flags, int64_t B);
 int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                        int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                        int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,

@@ -28,6 +28,7 @@ MNRF_GRAD_NORMAL = 2
 MNRF_SPLIT_F16 = 4
 MNRF_TCNN_VALU = 8
 MNRF_TCNN_F16 = 256
+MNRF_TCNN_GRAD_FIXED = 512
 MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128
@@ -83,6 +84,7 @@ SIGNATURES = {
                                   _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 11 + [_u32, _str]),
     "mnrf_tcnn_backward_workspace_floats": (_i64, [ctypes.POINTER(ctypes.c_int64)]),
     "mnrf_tcnn_backward_workspace_floats2": (_i64, [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint]),
+    "mnrf_tcnn_backward_workspace_floats3": (_i64, [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint, _i64]),
     "mnrf_sample_fine": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _str]),
     "mnrf_threshold_mask": (_int, [_c_f, _i64, _c_i, _str]),
     "mnrf_reflect_compact": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i,

@@ -850,6 +850,18 @@ struct TcnnBwdArgs {
     // of atomics (measured: with one of the two fp32 adds compiled out the 1024-ray step takes 3.02 instead of 4.09 ms).
     __half2* g16;                                // (entries) half2, zero-initialised by the caller; null: fp32 atomics
     float g16_scale;                             // gradients are multiplied by this on the way in, divided on the way out
+    // MNRF_TCNN_GRAD_FIXED (round 4, default of the Python shim): the levels without private copies accumulate BOTH features of an
+    // entry with ONE 64-bit integer atomic -- two 32-bit fixed-point numbers, hi * 2^32 + lo added as a signed 64-bit integer, which
+    // is exact (the carries of the low half are undone when decoding) and order-independent.  The scatter is bound by the NUMBER of
+    // atomics (one u64 add instead of two fp32 adds: 4.06 -> 2.89 ms per 1024-ray step; two u64 adds: 3.77 ms).  Fixed point needs
+    // a scale under which NO entry can overflow: tcnn_bwd_kernel writes dL/d encoding as planes [NL][B] float2 and, per level,
+    // S = sum over the samples of max(|e0|, |e1|) -- the interpolation weights of a sample add up to 1, so no entry of the level can
+    // collect more than S in either feature, however the samples collide (all rays of a batch leave one camera: 6 400 adds to one
+    // entry of level 4 in a 1024-ray batch) -- and tcnn_scatter_fx_kernel scatters with the power of two that puts S at 2^30.
+    // The fixed-point step is S * 2^-30: with B = 196 608 samples typically 2^-16 of the level's largest contribution.
+    float2* genc;                                // planes (caller's workspace) or null
+    double* ssum;                                // [NL] S per level (zeroed by the launcher)
+    unsigned long long* fx;                      // (entries) packed fixed-point sums (zeroed by the launcher)
 };
 
 // Round 4, measured and NOT kept: a level-major second launch in which every 128-byte line of d_table is only touched from one
@@ -938,13 +950,10 @@ __device__ __forceinline__ void sh4_backward(const float (&d)[3], const float* g
             + k * (15.f * z2 - 3.f) * g[12] - 10.f * h * X * Z * g[13] + m * (x2 - y2) * g[14];
 }
 
-// Table-gradient scatter of one level for this thread's sample: v0[c], v1[c] = the two feature gradients at corner c.
-// Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): on levels whose cell
-// key fits 3 x 10 bits each run of lanes with equal cell is summed into its first lane (segmented suffix sum, 6 shuffle
-// steps) and only that lane scatters.  Every lane of the wave must call it (shuffles).
-__device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, const unsigned (&pg)[3], float (&v0)[8], float (&v1)[8],
-                                                bool active, int lane, float* dtab, unsigned hsize, unsigned res, int own = -1) {
-    const TcnnArgs& A = P.f;
+// Runs of consecutive lanes in the same cell of level lv (< agg_levels) are summed into their first lane; returns whether this
+// lane is the head of its run (always true on the finer levels).  Every lane of the wave must call it (shuffles).
+__device__ __forceinline__ bool aggregate_runs(const TcnnBwdArgs& P, int lv, const unsigned (&pg)[3], float (&v0)[8], float (&v1)[8],
+                                               bool active, int lane) {
     bool head = true;
     if (lv < P.agg_levels) {
         const unsigned key = pg[0] | (pg[1] << 10) | (pg[2] << 20);          // (agg_levels: res < 1024)
@@ -965,6 +974,17 @@ __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, co
             }
         }
     }
+    return head;
+}
+
+// Table-gradient scatter of one level for this thread's sample: v0[c], v1[c] = the two feature gradients at corner c.
+// Consecutive samples of a ray sit in the same cell of a coarse level (6-19 of them at level 0): on levels whose cell
+// key fits 3 x 10 bits each run of lanes with equal cell is summed into its first lane (segmented suffix sum, 6 shuffle
+// steps) and only that lane scatters.  Every lane of the wave must call it (shuffles).
+__device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, const unsigned (&pg)[3], float (&v0)[8], float (&v1)[8],
+                                                bool active, int lane, float* dtab, unsigned hsize, unsigned res, int own = -1) {
+    const TcnnArgs& A = P.f;
+    const bool head = aggregate_runs(P, lv, pg, v0, v1, active, lane);
     if (active && head && !P.exp_noscatter && P.g16 && !P.cp_n[lv]) {      // (wave-uniform choice)
         __half2* h = P.g16 + A.off[lv];
         const float k = P.g16_scale;
@@ -987,6 +1007,8 @@ __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, co
 
 __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
     const TcnnArgs& A = P.f;
+    __shared__ double wg_ssum[NL];        // MNRF_TCNN_GRAD_FIXED: this workgroup's sum of max(|e0|, |e1|) per level
+    if (threadIdx.x < NL) wg_ssum[threadIdx.x] = 0.0;
     for (int k = threadIdx.x; k < W_TOTAL; k += BT) wlds[k] = A.weights[k];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1272,8 +1294,21 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
         for (int k = 0; k < 32; ++k) GR(k) = g_enc[k];           // (own column; indexed by level below)
         float gx[3] = {0.f, 0.f, 0.f};
         const bool active = live && !oob;
+        if (P.genc) {      // MNRF_TCNN_GRAD_FIXED: hand dL/d encoding and its magnitude per level to tcnn_scatter_fx_kernel
+#pragma unroll 1
+            for (int lv = 0; lv < NL; ++lv) {
+                const float e0 = active ? GR(2 * lv) : 0.f, e1 = active ? GR(2 * lv + 1) : 0.f;
+                if (live) P.genc[(long long)lv * A.B + i] = float2{e0, e1};
+                float mx = fmaxf(fabsf(e0), fabsf(e1));
+                if (!(mx < 1.0e30f)) mx = 1.0e30f;                      // (inf / nan upstream: a finite scale; the sums are garbage either way)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx += __shfl_xor(mx, o);
+                if (lane == 0 && mx > 0.f) atomicAdd(&wg_ssum[lv], (double)mx);      // (LDS; one global atomic per level at the end)
+            }
+        }
 #pragma unroll 1
         for (int lv = 0; lv < NL; ++lv) {
+            if (P.genc && !P.d_xyz) break;      // (nothing left per level here; with d_xyz: the gathers below, no scatter)
             const float e0 = active ? GR(2 * lv) : 0.f, e1 = active ? GR(2 * lv + 1) : 0.f;
             const float scale = A.scale[lv];
             const unsigned res = A.res[lv];
@@ -1308,12 +1343,16 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                     gx[2] += ((c & 4) ? scale : -scale) * wx * wy * ev;
                 }
             }
-            scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
+            if (!P.genc) scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
         }
         if (P.d_xyz && live) {
             const float s = 1.f / (2.f * A.bound);
             P.d_xyz[i * 3] = gx[0] * s; P.d_xyz[i * 3 + 1] = gx[1] * s; P.d_xyz[i * 3 + 2] = gx[2] * s;
         }
+    }
+    if (P.genc) {
+        __syncthreads();
+        if (threadIdx.x < NL && wg_ssum[threadIdx.x] > 0.0) atomicAdd(P.ssum + threadIdx.x, wg_ssum[threadIdx.x]);
     }
     // ---- this workgroup's share of the weight gradients
     float* D = P.d_weights;
@@ -1514,6 +1553,105 @@ __global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
 #undef GR
 
 // d_table[level entries] += sum of the level's private copies
+// power of two k with k * S <= 2^30, S = the level's bound on any entry's sum (TcnnBwdArgs::ssum)
+__device__ __forceinline__ float fx_scale(double S) {
+    if (!(S > 0.0)) return 0.f;                                           // nothing to add on this level
+    int e;
+    (void)frexp(S, &e);                                                   // S = m 2^e, m in [0.5, 1): S < 2^e
+    const int p = 30 - e;
+    if (p < -120 || p > 120) return 0.f;                                  // (gradients outside any sane range: leave the level out)
+    return __uint_as_float((unsigned)(127 + p) << 23);
+}
+
+// MNRF_TCNN_GRAD_FIXED: the scatter as its own launch over the planes tcnn_bwd_kernel wrote.  One thread per sample, all levels;
+// levels with private copies add fp32 into them as before, the others one packed 64-bit integer atomic per corner.
+__global__ __launch_bounds__(256) void tcnn_scatter_fx_kernel(TcnnBwdArgs P) {
+    const TcnnArgs& A = P.f;
+    const int lane = threadIdx.x & 63;
+    const long long ntiles = (A.B + 255) / 256;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long i = tile * 256 + threadIdx.x;
+        const bool live = i < A.B;
+        if (!live) i = A.B - 1;
+        float x[3];
+        if (A.xyz) {
+            const float* p = A.xyz + i * A.xyz_stride;
+            x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+        } else {
+            const float* r = A.rays + (i / A.spr) * 8;
+            const float z = A.z_vals[i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) x[a] = r[a] + r[3 + a] * z;
+        }
+        float u[3];
+        bool oob = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            u[a] = (x[a] + A.bound) / (2.f * A.bound);
+            oob |= u[a] < 0.f || u[a] > 1.f;
+        }
+        const bool active = live && !oob;
+#pragma unroll 1
+        for (int lv = 0; lv < NL; ++lv) {
+            const float2 e = active ? P.genc[(long long)lv * A.B + i] : float2{0.f, 0.f};
+            const float scale = A.scale[lv];
+            const unsigned res = A.res[lv];
+            const unsigned hsize = A.off[lv + 1] - A.off[lv];
+            unsigned pg[3];
+            float fr[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float pos = u[a] * scale + 0.5f;
+                const float fl = floorf(pos);
+                pg[a] = active ? (unsigned)fl : 0u;
+                fr[a] = pos - fl;
+            }
+            float v0[8], v1[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = ((c & 1) ? fr[0] : 1.f - fr[0]) * ((c & 2) ? fr[1] : 1.f - fr[1]) * ((c & 4) ? fr[2] : 1.f - fr[2]);
+                v0[c] = w * e.x;
+                v1[c] = w * e.y;
+            }
+            if (P.cp_n[lv]) {                                             // (wave-uniform) coarse level: fp32 into this workgroup's private copy
+                float* dtab = P.copies + P.cp_off[lv] + 2ll * hsize * (blockIdx.x % (unsigned)P.cp_n[lv]);
+                scatter_corners(P, lv, pg, v0, v1, active, lane, dtab, hsize, res);
+                continue;
+            }
+            const bool head = aggregate_runs(P, lv, pg, v0, v1, active, lane);
+            const float k = fx_scale(P.ssum[lv]);
+            if (!(active && head) || k == 0.f || P.exp_noscatter) continue;
+            unsigned long long* fx = P.fx + A.off[lv];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned idx = grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]);
+                const long long q0 = (long long)__float2int_rn(v0[c] * k), q1 = (long long)__float2int_rn(v1[c] * k);      // (|v k| <= 2^30)
+                if (q0 | q1) atomicAdd(fx + idx, (unsigned long long)((q1 << 32) + q0));
+            }
+        }
+    }
+}
+
+// d_table += decode(fx) / scale of the entry's level, for the levels that accumulated in fixed point (no private copies)
+__global__ void tcnn_fold_fx_kernel(TcnnBwdArgs P) {
+    const TcnnArgs& A = P.f;
+    const int lv = blockIdx.y;
+    if (P.cp_n[lv]) return;
+    const float k = fx_scale(P.ssum[lv]);
+    if (k == 0.f) return;
+    const float inv = 1.f / k;
+    const unsigned n = A.off[lv + 1] - A.off[lv];
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const long long t = (long long)P.fx[A.off[lv] + e];
+        if (t == 0) continue;
+        const long long lo = (long long)(int)(unsigned)(t & 0xffffffffll);      // the low half, sign-extended ...
+        const long long hi = (t - lo) >> 32;                                    // ... and its carries taken back out of the high half
+        float* d = P.d_table + 2ll * (A.off[lv] + e);
+        d[0] += (float)lo * inv;
+        d[1] += (float)hi * inv;
+    }
+}
+
 __global__ void tcnn_fold_kernel(TcnnBwdArgs P) {
     const TcnnArgs& A = P.f;
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1668,6 +1806,15 @@ extern "C" int64_t mnrf_tcnn_backward_workspace_floats2(const int64_t* offsets17
     return base + ((flags & MNRF_TCNN_GRAD_F16) ? offsets17_host[NL] + 4 : 0);      // (+ the overflow word, 16-byte padded)
 }
 
+// MNRF_TCNN_GRAD_FIXED: [private copies][2 floats per table entry: the packed 64-bit sums][32 * B floats: dL/d encoding planes]
+// [32 words: the levels' sums (16 doubles)].  The launcher zeroes what must be zero; the caller zero-fills the copies (the first
+// mnrf_tcnn_backward_workspace_floats() floats), as before.
+extern "C" int64_t mnrf_tcnn_backward_workspace_floats3(const int64_t* offsets17_host, unsigned flags, int64_t B) {
+    if (!offsets17_host) return 0;
+    if (!(flags & MNRF_TCNN_GRAD_FIXED)) return mnrf_tcnn_backward_workspace_floats2(offsets17_host, flags);
+    return mnrf_tcnn_backward_workspace_floats(offsets17_host) + 2 * offsets17_host[NL] + 32 * (B > 0 ? B : 0) + 32;
+}
+
 extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                                   int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
@@ -1702,6 +1849,17 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     P.copies = workspace;
     P.g16 = nullptr;
     P.g16_scale = 1.f;
+    P.genc = nullptr; P.ssum = nullptr; P.fx = nullptr;
+    const bool fixed = (flags & MNRF_TCNN_GRAD_FIXED) && workspace && !(flags & MNRF_TCNN_GRAD_F16);
+    if (fixed) {
+        float* w = workspace + mnrf_tcnn_backward_workspace_floats(offsets17_host);
+        P.fx = (unsigned long long*)w;
+        P.genc = (float2*)(w + 2 * offsets17_host[NL]);
+        P.ssum = (double*)(w + 2 * offsets17_host[NL] + 32 * B);
+        if (hipMemsetAsync(P.fx, 0, (size_t)offsets17_host[NL] * 8, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(P.ssum, 0, NL * sizeof(double), (hipStream_t)stream) != hipSuccess)
+            return mnrf_fail(MNRF_ERR_LAUNCH, "mnrf_tcnn_backward: hipMemsetAsync");
+    }
     if ((flags & MNRF_TCNN_GRAD_F16) && workspace) {
         P.g16 = (__half2*)(workspace + mnrf_tcnn_backward_workspace_floats(offsets17_host));
         static const float scale = [] { const char* e = getenv("MNRF_TCNN_GRAD_SCALE"); return e && atof(e) > 0 ? (float)atof(e) : 1024.f; }();
@@ -1723,7 +1881,15 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256)), block(BT);      // persistent: one workgroup per CU of the MI355X
     const size_t lds = (size_t)BWD_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(tcnn_bwd_kernel, grid, block, lds, (hipStream_t)stream, P);
+    if (fixed) {
+        const long long nt = (B + 255) / 256;
+        hipLaunchKernelGGL(tcnn_scatter_fx_kernel, dim3((unsigned)(nt < 2048 ? nt : 2048)), dim3(256), 0, (hipStream_t)stream, P);
+        TcnnBwdArgs P2 = P;
+        P2.genc = nullptr;        // the second-order kernel below scatters as before (fp32 atomics into copies / d_table)
+        P = P2;
+    }
     if (g_normal) hipLaunchKernelGGL(tcnn_bwd2_kernel, grid, block, lds, (hipStream_t)stream, P);     // adds the second-order term
+    if (fixed) hipLaunchKernelGGL(tcnn_fold_fx_kernel, dim3(256, NL), dim3(256), 0, (hipStream_t)stream, P);
     if (folded) hipLaunchKernelGGL(tcnn_fold_kernel, dim3((unsigned)((folded + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     if (P.g16) {      // everything from the first level without copies on (copied levels in between only add the zeros they hold)
         long long e0 = -1;

@@ -53,6 +53,7 @@ GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
 # module.mlp_f16 (env MNRF_TCNN_F16=1 sets the default): the MLPs of the forward kernel in single-pass f16 on the matrix pipe
 # (one MFMA per product, fp32 accumulation; ~1e-3 relative) instead of hi/lo pairs at fp32 accuracy -- "fp16 MLP on CDNA4 MFMA"
 # as BASELINE config 5 words it; the sigma-only launches then run on the matrix pipe too.  The backward recomputes in fp32.
+GRAD_FIXED = os.environ.get("MNRF_TCNN_GRAD_FIXED", "1") != "0"
 MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
 # smallest launch (samples) that encodes level by level into scratch planes (module.enc_planes_min overrides; a huge value
 # keeps the one-launch form)
@@ -128,7 +129,16 @@ class TcnnFieldFn(torch.autograd.Function):
         # table_grad_f16 (module attribute; env MNRF_TCNN_GRAD_F16=1 sets the default): the big hashed levels accumulate their
         # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
         flags = ctx.cut | (_lib.MNRF_TCNN_GRAD_F16 if getattr(m, "table_grad_f16", GRAD_F16) else 0)
-        ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
+        # table_grad_fixed (module attribute, default on; MNRF_TCNN_GRAD_FIXED=0 turns it off): one 64-bit integer atomic per table
+        # entry -- two 32-bit fixed-point halves under the step's own per-level scale -- instead of two fp32 atomics: exact integer
+        # sums (bitwise reproducible), 17 bits below the largest contribution of a level, 4.1 -> 3.0 ms per 1024-ray step
+        if not (flags & _lib.MNRF_TCNN_GRAD_F16) and getattr(m, "table_grad_fixed", GRAD_FIXED):
+            flags |= _lib.MNRF_TCNN_GRAD_FIXED
+            n_copies = _lib.lib().mnrf_tcnn_backward_workspace_floats(offs)
+            ws = torch.empty(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats3(offs, flags, B)), dtype=torch.float32, device=dev)
+            ws[:n_copies].zero_()          # (the private copies of the coarse levels; the rest is zeroed / overwritten by the launch)
+        else:
+            ws = torch.zeros(max(1, _lib.lib().mnrf_tcnn_backward_workspace_floats2(offs, flags)), dtype=torch.float32, device=dev)
         if flags & _lib.MNRF_TCNN_GRAD_F16:
             _check_f16_overflow(m)      # the previous backward's overflow word (its copy finished long ago: no queue drain)
         p = _lib.ptr

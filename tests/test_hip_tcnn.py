@@ -148,7 +148,8 @@ def test_tcnn_backward_matches_torch_autograd(bound, B, which):
             rel = ((gv - wv).abs().max(-1).values / (wv.abs().max(-1).values + 1e-3 * scale))
             assert float(rel.median()) <= 1e-4 and float((rel < 1e-2).float().mean()) > 0.97, (k, float(rel.median()))
         else:
-            assert err <= 2e-5 * scale + 1e-7, (k, err, scale)
+            # table: the default scatter is fixed point, 2^-17 of a level's largest contribution per add (MNRF_TCNN_GRAD_FIXED)
+            assert err <= (6e-5 if k == "encoder.embeddings" else 2e-5) * scale + 1e-7, (k, err, scale)
     # untouched table entries stay exactly zero
     assert int((got["encoder.embeddings"] != 0).sum()) <= B * 16 * 8 * 2
 
@@ -169,6 +170,7 @@ def test_tcnn_backward_packed_f16_table_gradient():
              "pred_normal": 1e-3 * torch.randn(B, 3, generator=g).to(DEV), "is_mirror": 1e-3 * torch.randn(B, generator=g).to(DEV)}
     which = ("sigma", "rgb", "pred_normal", "is_mirror")
     m.table_grad_f16 = False
+    m.table_grad_fixed = False          # the baseline of this comparison: two fp32 atomics per entry
     want, _ = _grads_of(m, x6, seeds, which)
     m.table_grad_f16 = True
     got, _ = _grads_of(m, x6, seeds, which)
@@ -236,12 +238,12 @@ def test_tcnn_backward_detach_density_options(mode):
     for q, wv in w.items():
         wv = (wv.grad if wv.grad is not None else torch.zeros_like(wv)).float()
         scale = float(wv.abs().max()) + 1e-12
-        assert float((got[q] - wv).abs().max()) <= 2e-5 * scale + 1e-7, (mode, q)
+        assert float((got[q] - wv).abs().max()) <= (6e-5 if q == "encoder.embeddings" else 2e-5) * scale + 1e-7, (mode, q)      # (table: fixed-point scatter)
         moved = max(moved, float((got[q] - plain[q]).abs().max()) / scale)
     assert moved > 0.05, (mode, moved)       # the option changed some gradient by more than 5 % of its tensor's largest entry
     # the cut head's own weights are unaffected
     head = "normal_net.1.weight" if mode == "normal" else "is_mirror_net.2.weight"
-    assert torch.equal(got[head], plain[head])
+    assert float((got[head] - plain[head]).abs().max()) <= 1e-6 * float(plain[head].abs().max())      # (sums of atomics over workgroups)
 
 
 def test_tcnn_training_step_through_render_rays():
@@ -312,7 +314,7 @@ def test_tcnn_backward_run_aggregation_is_order_independent():
     a, b = grads("rays"), grads("shuffled")
     for k in a:
         scale = float(a[k].abs().max()) + 1e-12
-        assert float((a[k] - b[k]).abs().max()) <= 2e-5 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+        assert float((a[k] - b[k]).abs().max()) <= (6e-5 if k == "encoder.embeddings" else 2e-5) * scale, (k, float((a[k] - b[k]).abs().max()), scale)
 
 
 def test_tcnn_train_recursion_matches_torch_field(monkeypatch):
@@ -561,7 +563,7 @@ def test_g17_field_gradients(variant):
         assert err <= tol * scale + 1e-8, (variant, k, err, scale)
     lv, val, nnz = FX.table_grad_summary(m.encoder.embeddings.grad.cpu().numpy(), cfg, o[f"{variant}__table_idx"])
     wl, wv = o[f"{variant}__table_levels"], o[f"{variant}__table_val"]
-    assert abs(nnz - int(o[f"{variant}__table_nnz"])) <= 0.002 * int(o[f"{variant}__table_nnz"])    # (a weight that is exactly 0)
+    assert abs(nnz - int(o[f"{variant}__table_nnz"])) <= 0.015 * int(o[f"{variant}__table_nnz"])    # (contributions below the fixed-point step of the default scatter)
     assert np.max(np.abs(lv[:, 1] - wl[:, 1])) <= tol * wl[:, 1].max(), (lv[:, 1], wl[:, 1])
     assert np.max(np.abs(val - wv)) <= tol * np.abs(wv).max() * (5 if second else 1)
     gx, wx = x.grad.cpu().numpy(), o[f"{variant}__grad__x6"]
@@ -745,3 +747,51 @@ def test_tcnn_packed_f16_gradient_overflow_is_clamped_and_reported():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert bool(torch.isfinite(step(1e4)).all())   # fp32 atomics now
+
+
+def test_tcnn_fixed_point_table_gradient():
+    """MNRF_TCNN_GRAD_FIXED (default): one packed 64-bit integer atomic per table entry under a per-level power-of-two scale taken
+    from the step's own largest |dL/d encoding|.  Against the fp32-atomic scatter on the same inputs: everything that is not the
+    table is unchanged, the same entries are touched (but for contributions below the fixed-point step), the table gradient agrees to
+    4e-5 of each level's largest entry;
+    and the integer sums are ORDER-INDEPENDENT: two runs give bit-identical gradients (fp32 atomics do not)."""
+    from mirror_nerf_amd.mirror_nerf_tcnn import TcnnFieldFn
+    m, _w, cfg = _model(6.0, seed=8, table_scale=0.2)
+    g = torch.Generator().manual_seed(21)
+    N, S = 83, 96                                                     # 7968 samples: ragged last tile
+    rays = torch.from_numpy(O.synthetic_rays(10, 10)[:N]).to(DEV)
+    z = (torch.linspace(0.3, 7.9, S)[None] + 0.02 * torch.rand(N, S, generator=g)).to(DEV)   # through the box and out of it
+    seeds = [torch.randn(N * S, generator=g).to(DEV), torch.randn(N * S, 3, generator=g).to(DEV),
+             torch.randn(N * S, 3, generator=g).to(DEV), torch.randn(N * S, generator=g).to(DEV)]
+    seeds[0][::7] = 0
+
+    def grads(fixed):
+        m.table_grad_fixed = fixed
+        m.zero_grad()
+        r = rays.clone().requires_grad_(True)
+        outs = TcnnFieldFn.apply(m, S, None, r, z, None, False, m.encoder.embeddings, *m.mlp_params())
+        sum((o_ * s_).sum() for o_, s_ in zip(outs[:4], seeds)).backward()
+        out = {k: v.grad.clone() for k, v in m.named_parameters()}
+        out["rays"] = r.grad.clone()
+        return out
+    a, a2, b = grads(True), grads(True), grads(False)
+    del m.table_grad_fixed
+    for k in a:
+        if k != "encoder.embeddings":      # (the MLP gradients are sums of fp32 atomics over workgroups: order-dependent in the last bits)
+            assert float((a[k] - b[k]).abs().max()) <= 1e-5 * (float(b[k].abs().max()) + 1e-12), k
+    ta, tb = a["encoder.embeddings"], b["encoder.embeddings"]
+    off = cfg["offsets"]
+    first_fx = int(off[min(l for l in range(16) if off[l + 1] - off[l] > 262144)])     # (the coarse levels keep fp32 private copies)
+    assert torch.equal(ta[first_fx:], a2["encoder.embeddings"][first_fx:])             # exact integer sums: reproducible bit for bit
+    n_fixed = 0
+    for lv in range(16):
+        sa, sb = ta[off[lv]:off[lv + 1]], tb[off[lv]:off[lv + 1]]
+        scale = float(sb.abs().max())
+        if scale == 0:
+            continue
+        err = float((sa - sb).abs().max())
+        assert err <= 4e-5 * scale, (lv, err, scale)                  # (step = S 2^-30, S = the level's sum of gradient magnitudes)
+        if off[lv + 1] - off[lv] > 262144:
+            n_fixed += 1
+            assert int(((sa != 0) != (sb != 0)).sum()) <= 1e-2 * int((sb != 0).sum()) + 1      # (contributions below the fixed-point step)
+    assert n_fixed >= 8
