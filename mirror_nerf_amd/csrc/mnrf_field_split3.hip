@@ -72,7 +72,11 @@ static bool tile_queue_slot(FieldArgs& A) {
 int launch_split48(const FieldArgs& A0, bool sigma_only, hipStream_t s) {
     FieldArgs A = A0;
     A.tile_queue = nullptr;
-    if (tile_queue_enabled()) (void)tile_queue_slot(A);
+    if (tile_queue_enabled() && tile_queue_slot(A)) {
+        // the pair is zeroed on the launch stream and not only by the last workgroup of the previous launch that used it: a kernel
+        // that aborted would otherwise leave it non-zero and the next launch on that pair would skip or repeat tiles
+        if (hipMemsetAsync(A.tile_queue, 0, 2 * sizeof(int), s) != hipSuccess) A.tile_queue = nullptr;
+    }
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)h3::field_split_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h3::LDS_BYTES);
