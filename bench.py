@@ -745,6 +745,9 @@ def main():
                                    "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
                                    "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
                        "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames",
+                       "train_step_workload": "1024 rays per GPU, perturb = noise_std = 1, 25 % GT mirror rays reflected once; train_step: "
+                                              "run.sh:266's schedule (64 coarse + 128 fine samples, --N_importance 64); "
+                                              "train_step.config3_64_plus_192: BASELINE config 3 as worded (64 + 192, --N_importance 128)",
                        "collective_backend": (dist.get_backend() + " (RCCL)") if multi else None,
                        "rccl_world_size": dist.get_world_size() if multi else None},
             "samples_per_s": value * evals_per_ray,
