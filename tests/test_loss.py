@@ -146,3 +146,34 @@ def test_device_psnr_matches_oracle():
     want_m = -10 * np.log10(np.mean((a[m].astype(np.float64) - b[m]) ** 2))
     assert abs(float(metrics.psnr(ta, tb, torch.from_numpy(m).cuda())) - want_m) <= 1e-4
     assert torch.isnan(metrics.psnr(ta, tb, torch.zeros(640000, dtype=torch.bool).cuda()))
+
+
+@pytest.mark.gpu
+def test_training_color_mask_loss_is_the_fused_color_and_mask_terms():
+    """training.color_mask_loss = the reference's ColorLoss + MirrorMaskLoss (losses.py:7-51, 175-198; both `typ`s, nn.BCELoss's
+    log clamp at -100, weight 0.1) through the fused loss kernel: value and gradients against the same two terms in torch ops."""
+    import torch
+    from mirror_nerf_amd import training
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    n = 777
+    res = {k: torch.rand(n, 3, generator=g).to(dev).requires_grad_(True) for k in ("rgb_coarse", "rgb_fine")}
+    res.update({k: torch.rand(n, generator=g).to(dev).requires_grad_(True) for k in ("mirror_mask_coarse", "mirror_mask_fine")})
+    with torch.no_grad():
+        res["mirror_mask_fine"][:5] = torch.tensor([0.0, 1.0, 1e-9, 1 - 1e-9, 0.5])       # the clamp's territory
+    target = torch.rand(n, 3, generator=g).to(dev)
+    gt = (torch.rand(n, generator=g) < 0.3).float().to(dev)
+    loss = training.color_mask_loss(res, target, gt)
+    loss.backward()
+    got = {k: v.grad.clone() for k, v in res.items()}
+    for v in res.values():
+        v.grad = None
+    ref = sum(((res[k] - target) ** 2).mean() for k in ("rgb_coarse", "rgb_fine"))
+    for k in ("mirror_mask_coarse", "mirror_mask_fine"):
+        ref = ref + 0.1 * torch.nn.functional.binary_cross_entropy(torch.clamp(res[k], 1e-7, 1 - 1e-7), gt)      # losses.py:187-190
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    for k, v in res.items():
+        finite = torch.isfinite(v.grad)
+        assert bool(finite.float().mean() > 0.99)
+        assert float((got[k] - v.grad)[finite].abs().max()) <= 1e-5 * float(v.grad[finite].abs().max()), k
