@@ -275,6 +275,7 @@ def hash_grid_leg(dev, rays):
     dt_t_own = (time.perf_counter() - t0) / 10
     dt_t = D.max_over_ranks(dt_t_own, dev)
     entries = int(models["fine"].encoder.embeddings.shape[0])
+    D.detach_overlap(list(models.values()))
     allreduce = None
     if collective:
         t_all = torch.tensor([dt_own, dt_t_own], dtype=torch.float64, device=dev)

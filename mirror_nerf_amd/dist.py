@@ -329,6 +329,18 @@ def reset_overlap():
         ov.reset()
 
 
+def detach_overlap(modules=None):
+    """Remove the overlapped all-reduce hooks of `modules` (None: of every module): buckets leave in the fixed order of _SEQ, so
+    modules that no longer take part in the step (a finished benchmark leg, a discarded model) must not stay in it -- a bucket
+    that never becomes ready holds back the ones behind it until allreduce_gradients()."""
+    mods = None if modules is None else {id(m) for m in modules}
+    for ov in list(_SEQ):
+        if mods is None or id(ov.module) in mods:
+            ov.reset()
+            ov.remove()
+            ov.module.__dict__.pop("_mnrf_overlap", None)
+
+
 class no_overlap:
     """Context manager for gradient accumulation: backward passes inside it do not send buckets from their hooks (and may
     run more than once); allreduce_gradients() after the LAST pass sends the accumulated buffers."""

@@ -211,11 +211,13 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
                         "optimizer and all-reduce included); dense f16 MFMA peak"}
     models = list(system.models.values())
     allreduce = None
+    n_overlapped = sum(m.__dict__.get("_mnrf_overlap") is not None for m in models)
     if world > 1 or D.forced():
         allreduce = {"buckets_in_place": sum(D._flat_bucket(m) is not None for m in models), "models": len(models),
-                     "overlapped_with_backward": sum(m.__dict__.get("_mnrf_overlap") is not None for m in models),
+                     "overlapped_with_backward": n_overlapped,
                      "note": "one flat gradient buffer per model, all-reduced in place (no cat / copy); issued from inside the "
                              "backward pass when a model's last gradient arrives"}
+    D.detach_overlap(models)          # (this system is done: its buckets leave the fixed send order)
     return {"value": (batch * steps + refl) * world / dt, "unit": "rays/s (primary+reflected, fwd+bwd+all-reduce+Adam)", "allreduce": allreduce,
             "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,

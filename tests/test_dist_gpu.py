@@ -58,8 +58,7 @@ WORKER = textwrap.dedent('''
     # pass, the MLP gradients as one blob; every rank ends the step with the same averaged gradients
     torch.manual_seed(0)
     tm = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev) for k in ("coarse", "fine")}
-    for old_ in list(D._SEQ):        # the buckets of the system above are not part of this step: buckets go out in a fixed order
-        old_.remove()
+    assert not D._SEQ                # synthetic_train_bench detached its system's buckets (buckets go out in a fixed order)
     ov = D.attach_overlap(tm.values())
     assert len(ov) == 2
     emb0 = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
