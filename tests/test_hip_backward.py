@@ -576,3 +576,41 @@ def test_folded_gradient_accumulation_with_other_consumers_of_the_parameters():
     loss_fn().backward()
     for q, b in zip(params_of(model), want):
         assert _rel(q.grad, 2 * b) <= 2e-6
+
+
+def test_flat_adam_takes_the_same_steps_as_torch_adam():
+    """training.FlatAdam (one flat parameter tensor per model, its .grad = the backward pass's flat gradient buffer) against
+    torch.optim.Adam(fused=True) over the 64 tensors: three training steps from the same initial weights on the same batches give
+    the same parameters (same arithmetic; the weight-gradient sums are order-dependent in the last bits)."""
+    from mirror_nerf_amd import training
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import synthetic as SY
+    rays_all = SY.device_rays(32, 32, DEV)
+
+    def run(flat):
+        torch.manual_seed(0)
+        system = M.NeRFSystem(training.default_hparams(perturb=0.0, noise_std=0.0)).to(DEV)
+        with torch.no_grad():
+            for m in system.models.values():
+                m.sigma.weight.mul_(20.0)
+                m.sigma.bias.fill_(1.0)
+        opt = training.FlatAdam(list(system.models.values()), lr=5e-4) if flat else torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(7)
+        losses = []
+        for _ in range(3):
+            idx = torch.randint(0, rays_all.shape[0], (256,), device=DEV, generator=g)
+            target = torch.rand(256, 3, device=DEV, generator=g)
+            gt = (torch.rand(256, device=DEV, generator=g) < 0.25).float()
+            losses.append(float(training.train_step(system, opt, rays_all[idx].contiguous(), target, gt)))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in system.named_parameters()}, system
+    la, pa, sa = run(True)
+    lb, pb, _ = run(False)
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(la, lb)), (la, lb)
+    assert la[2] != la[0]                                           # the weights moved (the packed images were refreshed)
+    for k in pb:
+        assert float((pa[k] - pb[k]).abs().max()) <= 2e-5 * float(pb[k].abs().max()) + 1e-7, k
+    # the parameters still are what state_dict / checkpoints see, and are views of the flat tensors
+    sd = sa.nerf_fine.state_dict()
+    assert torch.equal(sd["sigma.weight"], sa.nerf_fine.sigma.weight.detach())
