@@ -103,8 +103,9 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     if token is not None:       # the previous step's flags (their copy finished long ago: no queue drain)
         tripped_here = guard_async_end(token[0])
         tripped_any = tripped_here if token[1] is None else bool(token[1].item())
-        if tripped_any and not tripped_here:
-            pin_fp32(system)    # another rank left the range: every rank continues on the same (fp32) kernels
+        if tripped_any and token[1] is not None:
+            pin_fp32(system)    # more than one rank: EVERY rank pins EVERY model, whoever tripped -- the ranks must keep issuing the
+                                # same collectives (a rank without a split model left would skip the guard's all-reduce)
         if tripped_any or tripped_here:
             import warnings
             warnings.warn("mirror_nerf_amd: the previous training step left the range of the split-f16 arithmetic; "
@@ -124,8 +125,8 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
         if collective:                         # the decision must be the same on every rank: they all recompute, or none
             flag = torch.tensor([1.0 if tripped else 0.0], device=rays.device)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            if bool(flag.item()) and not tripped:
-                pin_fp32(system)
+            if bool(flag.item()):
+                pin_fp32(system)               # every rank, every model: the ranks stay on the same kernels
                 tripped = True
         if tripped:
             D.reset_overlap()                  # the first pass's bucket all-reduces (issued from inside backward) are discarded
