@@ -1,0 +1,24 @@
+"""Experiment (CPU, oracle): would a 2-product split (weights rounded to f16) in the HEAD layers only hold the 1e-4 bar?
+No: rgb moves by 6.6e-4 on the trained G11 pair, 1.1e-3 on the rough set, surface_normal by 1.7e-4 on random-init weights."""
+import sys, numpy as np
+sys.path.insert(0,'.')
+from oracle import mirror_nerf_oracle as O
+from tests.golden import fixtures as FX
+HEADS=("xyz_encoding_final.weight","dir_encoding.0.weight","rgb.0.weight","normal_net.0.weight","normal_net.1.weight","is_mirror_net.0.weight","is_mirror_net.2.weight")
+def rnd(sd, names):
+    out={k:v.copy() for k,v in sd.items()}
+    for n in names: out[n]=out[n].astype(np.float16).astype(np.float32)
+    return out
+for name in ("g11_trained_render_test","g11_rough_render_test","g4_fine_test"):
+    fx=FX.Fixture(name); m=fx.meta
+    sds=fx.state_dicts()
+    rays=fx.inputs["rays"]
+    kw=dict(m.get("kwargs",{}))
+    def run(s):
+        return O.render_rays({"coarse":s[0],"fine":s[1]},{"xyz":10,"dir":4},rays,m.get("N_samples",64),False,0,0,m.get("N_importance",128),32768,False,True,**{k:v for k,v in kw.items() if k not in("test_time",)})
+    a=run(sds)
+    b=run([rnd(s,HEADS) for s in sds])
+    c=run([rnd(s,[k for k in s if k.endswith("weight")]) for s in sds])
+    for k in ("rgb_fine","depth_fine","mirror_mask_fine","surface_normal_fine","opacity_fine"):
+        if k in a:
+            print(f"{name:28s} {k:22s} heads-f16 {np.abs(a[k]-b[k]).max():.2e}   all-f16 {np.abs(a[k]-c[k]).max():.2e}")
