@@ -1,6 +1,9 @@
-"""Hash-grid field (BASELINE config 5): the HIP kernel against the oracle restatement.
-Parity against tinycudann itself is UNPINNED (not installable here); these tests pin the kernel to this
-repository's own CPU restatement of gridencoder.cu / shencoder.cu / mirror_nerf_tcnn.py."""
+"""Hash-grid field (BASELINE config 5).
+Second half of this file (fixtures G17): the HIP path against the REFERENCE's own models/mirror_nerf_tcnn.py, models/rendering.py and
+train.NeRFSystem(model_type="nerf_tcnn") run unchanged over stand-in encoders (tests/golden/make_golden_tcnn.py) -- everything
+downstream of the encoder's interpolation is pinned.  The interpolation itself (tinycudann, not installable here) is UNPINNED: the
+first half holds the kernels to this repository's restatement of gridencoder.cu / shencoder.cu (oracle, tests/torch_ref.py -- which
+tests/test_oracle_golden.py in turn holds to the reference's G17 outputs and gradients)."""
 import warnings
 
 import numpy as np
