@@ -37,12 +37,20 @@ def main():
     ap.add_argument("--precision", default="split")
     ap.add_argument("--loss", choices=("total", "color_mask"), default="total")
     ap.add_argument("--epoch", type=int, default=5, help="the epoch number handed to TotalLoss (it gates the loss terms)")
+    ap.add_argument("--model", choices=("nerf", "nerf_tcnn"), default="nerf", help="nerf_tcnn: the hash-grid model (BASELINE config 5)")
+    ap.add_argument("--bound", type=float, default=4.0, help="nerf_tcnn: half edge of the hash grid's box")
+    ap.add_argument("--table-grad", choices=("fixed", "fp32", "f16"), default="fixed", help="nerf_tcnn: how the table gradient is accumulated")
+    ap.add_argument("--mlp-f16", action="store_true", help="nerf_tcnn: single-pass f16 MLPs in the forward kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     M.set_precision(a.precision)
     torch.manual_seed(0)
-    hp = training.default_hparams(N_importance=64, train_geometry_stage_end_epoch=4)
+    hp = training.default_hparams(N_importance=64, train_geometry_stage_end_epoch=4, model_type=a.model, bound=a.bound,
+                                  N_emb_xyz=0 if a.model == "nerf_tcnn" else 10, N_emb_dir=0 if a.model == "nerf_tcnn" else 4)
     system = M.NeRFSystem(hp).to(dev)
+    if a.model == "nerf_tcnn":
+        for m_ in system.models.values():
+            m_.table_grad_fixed, m_.table_grad_f16, m_.mlp_f16 = a.table_grad == "fixed", a.table_grad == "f16", a.mlp_f16
     if a.init:
         z = np.load(a.init)
         for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
@@ -53,7 +61,7 @@ def main():
     vr_t, vc_t = torch.from_numpy(vr).to(dev), torch.from_numpy(vc).to(dev)
     opt = torch.optim.Adam(list(system.parameters()), lr=a.lr, fused=True)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.1 ** (1.0 / max(1, a.steps)))
-    loss_fn = training.total_loss_fn(SimpleNamespace(), epoch=a.epoch) if a.loss == "total" else training.color_mask_loss
+    loss_fn = training.total_loss_fn(SimpleNamespace(model_type=a.model), epoch=a.epoch) if a.loss == "total" else training.color_mask_loss
     g = torch.Generator(device=dev).manual_seed(1)
     emb = system.embeddings
     args = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
@@ -78,12 +86,13 @@ def main():
     arrs = {}
     for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
         for k, v in mod.state_dict().items():
-            arrs[f"{mname}__{k}"] = v.detach().cpu().numpy().copy()
+            if v.numel() <= 4_000_000:        # (the hash-grid tables stay on the box)
+                arrs[f"{mname}__{k}"] = v.detach().cpu().numpy().copy()
     p, macc = val()
     arrs["meta"] = np.array(json.dumps(dict(steps=a.steps, batch=a.batch, lr=a.lr, views=a.views, res=a.res, init=a.init,
                                             trained_with="mirror_nerf_amd (scripts/train_scene.py) on MI355X, precision " + a.precision,
                                             held_out_psnr=p, mirror_mask_accuracy=macc,
-                                            sigma_max=float(max(m.sigma.weight.abs().max() for m in system.models.values())))))
+                                            sigma_max=float(max((m.sigma.weight if hasattr(m, "sigma") else m.sigma_net[1].weight[0]).abs().max() for m in system.models.values())))))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     np.savez_compressed(a.out, **arrs)
     print("wrote", a.out, f"{os.path.getsize(a.out)/1e6:.1f} MB; held-out PSNR {p:.2f} dB; ms/step {(time.time()-t0)/a.steps*1e3:.2f}")
