@@ -16,6 +16,7 @@ of the encoder's interpolation; the interpolation itself stays unpinned (tinycud
                                (a cotangent on the autograd normal)
     g17_tcnn_render_{train,test}   render_rays 64 + 64 with a coarse and a fine hash-grid model
     g17_tcnn_train_grads[_full]    NeRFSystem.forward (GT mask, compacted reflected rays, blend) + loss + every gradient
+    g17_tcnn_eval_l{1,2}           eval.batched_inference (predicted mask, level 0 traces the chunk, deeper levels compact)
 
 The 49 MB table is not stored: it is numpy's RandomState(seed).uniform (mirror_nerf_amd.synthetic.make_tcnn_table); the small
 MLPs are stored.  Table gradients are stored as per-level norms plus 4096 (index, value) samples of the touched entries.
@@ -369,7 +370,88 @@ def _train_case(name, loss_fn, n_rays, seed):
     return gfloor
 
 
+# ------------------------------------------------------------------------------------------------ eval recursion
+def eval_case(name, max_level, n_rays=72, seed=61):
+    """eval.batched_inference (eval.py:114-172, 293-360, 513-548, 676-740) with hash-grid models: predicted mirror mask thresholded
+    in place, level 0 traces every ray of a chunk that holds a mirror ray, deeper levels compact.  The mask head's last layer is
+    scaled and its bias searched so that the chunk holds mirror AND non-mirror rays, none closer than 1e-3 to the 0.5 threshold at
+    any level (SURVEY 8a hazard 7)."""
+    import eval as ref_eval
+    ref_eval.dataset = types.SimpleNamespace(white_back=False)
+    hp = R.get_hparams()
+    args = types.SimpleNamespace(**vars(hp))
+    args.predict_normal, args.predict_mirror_mask, args.only_one_field = True, True, False
+    args.max_recursive_level = max_level
+    args.app_control_mirror_roughness = args.app_reflection_substitution = False
+    args.app_place_new_mirror = args.app_reflect_newly_placed_objects = False
+    mods, ws, cfg = pair(seed, TRAIN)
+    rays = MG.pick_rays(n_rays, seed)
+    emb = {"xyz": Embedding(0), "dir": Embedding(0)}
+    gain = 8.0
+
+    def call():
+        return MG.to_np(ref_eval.batched_inference({"coarse": mods[0], "fine": mods[1]}, emb, torch.from_numpy(rays), 64, 64, False, 32768,
+                                                   args=args, trace_secondary_rays=True))
+    with torch.no_grad():
+        for m in mods:
+            m.is_mirror_net[2].weight.mul_(gain)
+    # soft masks of every level at a given bias: spy on the reference's render_rays
+    import models.rendering as RR
+    best = None
+    for db in np.linspace(-4.0, 4.0, 33):
+        with torch.no_grad():
+            for m in mods:
+                m.is_mirror_net[2].bias.fill_(float(db))
+        soft = []
+        orig = ref_eval.render_rays
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            soft.append(r["mirror_mask_fine"].detach().clone().numpy())
+            return r
+        ref_eval.render_rays = spy
+        try:
+            call()
+        finally:
+            ref_eval.render_rays = orig
+        frac0 = float((soft[0] > 0.5).mean())
+        margin = min(float(np.abs(s_ - 0.5).min()) for s_ in soft)
+        if os.environ.get("DEBUG_EVAL"):
+            print(f"      bias {db:+.2f}: level-0 soft mask min {soft[0].min():.3f} median {np.median(soft[0]):.3f} max {soft[0].max():.3f}; "
+                  f"mirror {frac0:.0%}; margin {margin:.1e}; renders {len(soft)}")
+        # (the composited mask cannot exceed the opacity: only the opaque rays of the chunk can be mirrors)
+        if 0.1 <= frac0 <= 0.75 and margin > 1e-3 and len(soft) == max_level + 1 and (best is None or margin > best[1]):
+            best = (float(db), margin, frac0, len(soft))
+    assert best is not None, "no bias puts the chunk astride the threshold with a margin"
+    with torch.no_grad():
+        for m in mods:
+            m.is_mirror_net[2].bias.fill_(best[0])
+    print(f"    mask head: gain {gain}, bias {best[0]:+.2f}: {best[2]:.0%} mirror rays at level 0, margin {best[1]:.1e}, {best[3]} renders")
+    for w_, m in zip(ws, mods):
+        w_["is_mirror_net.2.weight"] = m.is_mirror_net[2].weight.detach().numpy().copy()
+        w_["is_mirror_net.2.bias"] = m.is_mirror_net[2].bias.detach().numpy().copy()
+    ref = call()
+    args_o = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=max_level,
+                  app_control_mirror_roughness=False, trace_ray_times=2, normal_noise_std=0.0)
+    orc = O.render_eval({"coarse": ws[0], "fine": ws[1]}, {"xyz": 0, "dir": 0}, rays, 64, 64, False, 32768, args_o)
+    MG.report(name, ref, orc, skip=("z_vals_fine", "weights_fine", "pred_normal_fine"))
+    for m in mods:
+        m.double()
+    r64 = MG.to_np(ref_eval.batched_inference({"coarse": mods[0], "fine": mods[1]}, emb, torch.from_numpy(rays).double(), 64, 64, False,
+                                              32768, args=args, trace_secondary_rays=True))
+    floor = {k: float(np.max(np.abs(r64[k] - ref[k]))) if ref[k].size else 0.0 for k in ref if r64[k].shape == ref[k].shape}
+    print("    reference fp32 vs fp64 > 2e-5:", {k: f"{v:.1e}" for k, v in floor.items() if v > 2e-5})
+    meta = dict(table=dict(TRAIN, seeds=[seed, seed + 1], table_seeds=[200 + seed, 201 + seed]), args=args_o, floor=floor,
+                N_samples=64, N_importance=64, chunk=32768)
+    ins = dict(rays=rays, **mlp_arrays(ws[0], "coarse__"), **mlp_arrays(ws[1], "fine__"))
+    MG.save(name, meta, ins, ref, keep_per_sample=False)
+
+
 if __name__ == "__main__":
+    if os.environ.get("ONLY_EVAL") == "1":
+        eval_case("g17_tcnn_eval_l1", 1)
+        eval_case("g17_tcnn_eval_l2", 2)
+        sys.exit(0)
     if os.environ.get("ONLY_TRAIN") != "1":
         grid_offsets()
         field_case("g17_tcnn_field_b1", 1.0, 400, 3)
@@ -379,3 +461,5 @@ if __name__ == "__main__":
         render_case("g17_tcnn_render_test", True)
     _, ray_seed = train_case("g17_tcnn_train_grads", first_order_loss)
     train_case("g17_tcnn_train_grads_full", full_loss, seed=ray_seed)
+    eval_case("g17_tcnn_eval_l1", 1)
+    eval_case("g17_tcnn_eval_l2", 2)

@@ -798,3 +798,27 @@ def test_tcnn_fixed_point_table_gradient():
             n_fixed += 1
             assert int(((sa != 0) != (sb != 0)).sum()) <= 1e-2 * int((sb != 0).sum()) + 1      # (contributions below the fixed-point step)
     assert n_fixed >= 8
+
+
+@pytest.mark.parametrize("name", ["g17_tcnn_eval_l1", "g17_tcnn_eval_l2"])
+def test_g17_eval_recursion(name):
+    """eval.batched_inference (eval.py:114-172, 293-360, 513-548, 676-740) with the hash-grid pair: predicted mirror mask thresholded
+    in place, level 0 traces every ray of the chunk, deeper levels compact -- as captured from the reference."""
+    import mirror_nerf_amd as M
+    from tests.golden import fixtures as FX
+    fx = FX.Fixture(name)
+    m = fx.meta
+    mc, _ = _g17_model(fx, "coarse__", 0)
+    mf, _ = _g17_model(fx, "fine__", 1)
+    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    got = M.batched_inference({"coarse": mc, "fine": mf}, emb, torch.from_numpy(fx.inputs["rays"]).to(DEV), m["N_samples"], m["N_importance"],
+                              False, m["chunk"], args=m["args"], trace_secondary_rays=True, to_cpu=False)
+    n = 0
+    for k, want in fx.outputs.items():
+        if k in FX.PER_SAMPLE_FINE:
+            continue
+        assert k in got, k
+        err = float(np.max(np.abs(got[k].cpu().numpy().astype(np.float64) - want))) if want.size else 0.0
+        assert err <= FX.tolerance(k, m), (k, err, FX.tolerance(k, m))
+        n += 1
+    assert n >= 12

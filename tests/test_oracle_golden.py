@@ -232,6 +232,23 @@ def test_g17_tcnn_train_forward(name):
     assert n >= 20
 
 
+@pytest.mark.parametrize("name", ["g17_tcnn_eval_l1", "g17_tcnn_eval_l2"])
+def test_g17_tcnn_eval_recursion(name):
+    """eval.batched_inference with hash-grid models (predicted mask; level 0 traces the chunk, deeper levels compact)."""
+    fx = FX.Fixture(name)
+    m = fx.meta
+    ws = {"coarse": FX.tcnn_weights(fx, "coarse__", 0), "fine": FX.tcnn_weights(fx, "fine__", 1)}
+    got = O.render_eval(ws, {"xyz": 0, "dir": 0}, fx.inputs["rays"], m["N_samples"], m["N_importance"], False, m["chunk"], m["args"])
+    n = 0
+    for k, want in fx.outputs.items():
+        if k in FX.PER_SAMPLE_FINE:
+            continue
+        err = float(np.max(np.abs(got[k].astype(np.float64) - want))) if want.size else 0.0
+        assert err <= FX.tolerance(k, m), (k, err)
+        n += 1
+    assert n >= 12 and int((fx.outputs["mirror_mask_fine"] > 0.5).sum()) > 10
+
+
 @pytest.mark.parametrize("variant", ["plain", "detach_normal", "detach_mask", "detach_outside", "second_order"])
 def test_g17_torch_restatement_gradients(variant):
     """tests/torch_ref.tcnn_field -- the autograd yardstick of the GPU gradient tests -- against the reference's own
