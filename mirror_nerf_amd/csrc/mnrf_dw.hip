@@ -643,11 +643,13 @@ long long dw_workspace_floats(long long B) {
     return (long long)dw_splits(B) * DW_PER_SPLIT + (long long)dw_small_splits(B) * DW_PER_SMALL_SPLIT;
 }
 
-// MNRF_DW_PIPE: 0 (default) = the phased kernels everywhere, 1 = pipelined kernel for the 128-wide tiles (equal step time,
-// half the HBM traffic: see the kernel's header);
+// MNRF_DW_PIPE: 1 (default since round 4) = pipelined kernel for the 128-wide tiles, 0 = the phased kernels everywhere.  Round 2
+// measured the two equal on the first-order GEMMs; those run from operand planes now (mnrf_dwp.hip), what is left on this route
+// is the second-order pass of TotalLoss, and there the pipelined kernel measured 8.26-8.40 against 8.35-8.87 ms per step in
+// alternating runs (half the HBM traffic: see the kernel's header);
 // MNRF_DW_HINT=0 drops the scheduling-group hints of the pipelined kernel
 static int dw_pipe() {
-    static const int v = [] { const char* e = getenv("MNRF_DW_PIPE"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("MNRF_DW_PIPE"); return e ? atoi(e) : 1; }();
     return v;
 }
 static bool dw_hint() {
