@@ -315,6 +315,24 @@ int64_t mnrf_dw_planes_workspace_floats(int n_eval, const int64_t* B);
 int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
                    const uint32_t* const* seedmax, float* workspace, float* const* d_params, int accumulate, void* stream);
 
+/* Round 4: the second-order term (mnrf_field_backward2) on the planes route.  mnrf_field_backward2_planes runs the tangent pass
+ * only and leaves the tangents a' (x2_planes, mnrf_train_planes2_bytes(B)) and the density-gradient signals b (y2_planes,
+ * mnrf_train_dy_planes2_bytes(B)) as operand planes under one power-of-two scale for the call, derived from the largest |J^|
+ * whose float bits are left in *jmax (a device word, overwritten); ADDS to d_xyz when non-null.  mnrf_dw_planes2 is
+ * mnrf_dw_planes with a KIND per evaluation (HOST array, null = all 0): 0 = (x_planes, dy_planes, seedmax) of the first-order
+ * calls above, 1 = (x2_planes, y2_planes, jmax) of this one -- the weight gradients of a module over all evaluations and both
+ * orders in ONE launch (the reference: one loss.backward() through utils/func.py:10-25 with create_graph=True). */
+int64_t mnrf_train_planes2_bytes(int64_t B);
+int64_t mnrf_train_dy_planes2_bytes(int64_t B);
+int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream);
+int64_t mnrf_dw_planes2_workspace_floats(int n_eval, const int64_t* B, const int* kinds);
+int mnrf_dw_planes2(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                    const uint32_t* const* seedmax, const int* kinds, float* workspace, float* const* d_params, int accumulate,
+                    void* stream);
+
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);
  * log2_per_level_scale, base_resolution, bound: the encoding configuration (mirror_nerf_tcnn.py:36-49);

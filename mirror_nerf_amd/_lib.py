@@ -73,6 +73,14 @@ SIGNATURES = {
     "mnrf_dw_planes_workspace_floats": (_i64, [_int, ctypes.POINTER(ctypes.c_int64)]),
     "mnrf_dw_planes": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                               ctypes.POINTER(ctypes.c_void_p), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
+    "mnrf_train_planes2_bytes": (_i64, [_i64]),
+    "mnrf_train_dy_planes2_bytes": (_i64, [_i64]),
+    "mnrf_field_backward2_planes": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _c_f, _c_f, _c_f,
+                                           ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, _str]),
+    "mnrf_dw_planes2_workspace_floats": (_i64, [_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
+    "mnrf_dw_planes2": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p),
+                               _int, _str]),
     "mnrf_bench_stream": (_int, [ctypes.c_void_p, _i64, _int, _int, _str]),
     "mnrf_bench_gather": (_int, [ctypes.c_void_p, _i64, _int, _i64, _int, _c_f, _str]),
     "mnrf_tcnn_encode": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,

@@ -13,6 +13,7 @@ FOLD_GRADS = os.environ.get("MNRF_FOLD_GRADS", "1") != "0"
 # set of bf16 x 6 GEMM launches per evaluation) instead of operand planes + ONE GEMM launch per module and pass (mnrf_dwp.h)
 RAY_GRADS_KERNEL = os.environ.get("MNRF_RAY_GRADS", "1") != "0"      # 0: the torch ops it replaced (A/B measurements)
 DW_PLANES = os.environ.get("MNRF_DW_PLANES", "1") != "0"
+DW2_PLANES = os.environ.get("MNRF_DW2_PLANES", "1") != "0"    # 0: the second-order term on fp32 rows (mnrf_field_backward2)
 
 
 def _c(t):
@@ -209,7 +210,7 @@ class FieldFn(torch.autograd.Function):
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut,
                 _lib.stream()), "mnrf_field_backward_planes")
-            st.tape.append((save_x, dy, B, seed))
+            st.tape.append((save_x, dy, B, seed, 0))
         elif B:
             ws = f(max(1, L.mnrf_train_workspace_floats(B)))
             _lib.check(L.mnrf_field_backward(
@@ -218,7 +219,17 @@ class FieldFn(torch.autograd.Function):
                 (_lib.MNRF_SPLIT_F16 if ctx.split else 0) | ctx.cut | (_lib.MNRF_DW_ACCUMULATE if st.dirty else 0), _lib.stream()),
                 "mnrf_field_backward")
             st.dirty = True
-        if B and g_normal is not None and normal is not None:   # second-order term through the density-gradient normal
+        if B and g_normal is not None and normal is not None and ctx.planes and DW2_PLANES:
+            # second-order term through the density-gradient normal, planes route (round 4): the tangent pass leaves its
+            # operands on the tape as one more entry (kind 1); the module's ONE weight-gradient GEMM contracts them too
+            x2 = torch.empty(max(16, L.mnrf_train_planes2_bytes(B)), dtype=torch.uint8, device=dev)
+            y2 = torch.empty(max(16, L.mnrf_train_dy_planes2_bytes(B)), dtype=torch.uint8, device=dev)
+            jmax = torch.empty(1, dtype=torch.int32, device=dev)
+            _lib.check(L.mnrf_field_backward2_planes(
+                p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
+                p(save_invj), p(save_mask), p(x2), p(y2), p(jmax), p(d_xyz), _lib.stream()), "mnrf_field_backward2_planes")
+            st.tape.append((x2, y2, B, jmax, 1))
+        elif B and g_normal is not None and normal is not None:   # rows route (fp32 arithmetic, MNRF_DW2_PLANES=0)
             if not st.dirty:         # it ADDS to the gradients (trunk weights, sigma.weight): they start from zero then
                 st.flat.zero_()
                 st.dirty = True
@@ -291,7 +302,7 @@ class _Pending:
         for n, k in zip(PARAM_NAMES, sizes):
             self._views[n] = self.flat[off:off + k].view(PARAM_SHAPES[n])
             off += k
-        self.tape = []          # (x_planes, dy_planes, B, seedmax) per evaluation
+        self.tape = []          # (x_planes, dy_planes, B, seedmax, kind) per evaluation and order
         self.dirty = False      # the tensors hold a partial sum already (rows route, second-order pass)
 
     def all32(self):
@@ -313,8 +324,9 @@ class _Pending:
                 ys = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in grp])
                 bs = (ctypes.c_int64 * n)(*[t[2] for t in grp])
                 sm = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in grp])
-                ws = torch.empty(max(1, L.mnrf_dw_planes_workspace_floats(n, bs)), dtype=torch.float32, device=self.flat.device)
-                _lib.check(L.mnrf_dw_planes(n, xs, ys, bs, sm, p(ws), arr, 1 if self.dirty else 0, _lib.stream()), "mnrf_dw_planes")
+                kd = (ctypes.c_int * n)(*[t[4] for t in grp])      # 0: first-order planes, 1: second-order planes
+                ws = torch.empty(max(1, L.mnrf_dw_planes2_workspace_floats(n, bs, kd)), dtype=torch.float32, device=self.flat.device)
+                _lib.check(L.mnrf_dw_planes2(n, xs, ys, bs, sm, kd, p(ws), arr, 1 if self.dirty else 0, _lib.stream()), "mnrf_dw_planes2")
                 self.dirty = True
         elif not self.dirty:
             self.flat.zero_()      # no samples at all in this pass

@@ -14,9 +14,12 @@ long long dw2_workspace_floats(long long B);
 // second-order pass: so = tangents and density-gradient signals of field_bwd2_kernel; ADDS to d_params
 int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, hipStream_t s);
 // ---- round 3: weight gradients from operand planes (mnrf_dwp.hip / mnrf_dwp.h)
-long long dwp_workspace_floats(int n_eval, const int64_t* B);
+// kinds (null = all 0): per evaluation 0 = first-order planes, 1 = second-order planes (mnrf_dwp.h)
+long long dwp_workspace_floats(int n_eval, const int64_t* B, const int* kinds);
 int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
-               const unsigned* const* seedmax, float* ws, float* const* d_params, int accumulate, hipStream_t s);
+               const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate, hipStream_t s);
+// largest |J^| of a second-order pass (float bits) -> *out, as field_split_bwd2_kernel's prologue forms it
+void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s);
 // largest seed magnitude of an evaluation (float bits) -> *out; the seeds are those of field_split_bwd_kernel's prologue
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s);

@@ -71,6 +71,23 @@ constexpr int PLY_SIG = DY_FLOATS / 16;              // 171
 constexpr int PLY_FB = PLY_SIG + 1;                  // 172
 constexpr long long PLY_SB_BYTES = (long long)PLY_FB * PL_FB_BYTES;
 
+// ---- second-order pass (round 4): the gradient through the density-gradient normal adds  dW_i += sum_s b_i[s] (x) a'_(i-1)[s]
+// to the 8 trunk layers and  dw_sigma += sum_s a'_8[s]  (mnrf_field_split_bwd.inc, field_split_bwd2_kernel).  Its operands are
+// the B operands that kernel already holds for its own GEMMs: the tangents a' (X2 planes: [xyz-encoding tangent | a'_1..a'_8],
+// the first 132 feature blocks of the X layout) and the density-gradient signals b (Y2 planes: [b_1..b_8 | one block whose
+// row 0 is 2^boost], the first 128 feature blocks of the dY layout + 1).  In the kernel the tangents of sample s carry 2^k_s (its
+// J^ normalised to [1, 2)); their planes carry 2^(K2 - k_s) <= 1 of that with K2 from the largest |J^| of the launch (a pre-pass,
+// like the seeds' maximum), the b planes 2^boost, and the finish kernel multiplies by 2^-(K2 + boost).  For the GEMM
+// such an evaluation is one more entry of the tape with KIND 1: same job numbers, the jobs of the heads have no stages.
+static_assert(TA_ENC == SEC_ENC && TA_H == SEC_H && BS_L == TA_H + 8 * 256, "second-order sections sit where the first-order ones do");
+constexpr int PL2X_FB = (TA_H + 8 * 256) / 16;       // 132
+constexpr long long PL2X_SB_BYTES = (long long)PL2X_FB * PL_FB_BYTES;
+constexpr int PL2Y_SIG = 8 * 256 / 16;               // 128: row 0 = 2^boost (the A operand of dw_sigma += sum a'_8)
+constexpr int PL2Y_FB = PL2Y_SIG + 1;                // 129
+constexpr long long PL2Y_SB_BYTES = (long long)PL2Y_FB * PL_FB_BYTES;
+__host__ __device__ inline long long dwp_x_stride(int kind) { return kind ? PL2X_SB_BYTES : PLX_SB_BYTES; }
+__host__ __device__ inline long long dwp_y_stride(int kind) { return kind ? PL2Y_SB_BYTES : PLY_SB_BYTES; }
+
 // ---- the GEMMs of one evaluation of the field (first-order pass): rows = dY feature blocks, columns = X feature blocks
 struct DwpJob {
     short ya, na;      // first feature block and block count of the dY section (<= 16)
@@ -104,6 +121,16 @@ __host__ __device__ inline DwpJob dwp_job(int j) {
     }
 }
 static_assert(DY_NRM1 + 128 == DY_MIR1, "normal_net.0 and is_mirror_net.0 gradients are adjacent: one 256-row job");
+// jobs of an evaluation of kind 1 (second-order planes): the trunk (0..8) and sigma (13), no bias sums
+__host__ __device__ inline bool dwp_has(int kind, int j) { return kind == 0 || j <= 8 || j == 13; }
+__host__ __device__ inline DwpJob dwp_job_of(int kind, int j) {
+    DwpJob jb = dwp_job(j);
+    if (kind) {
+        jb.bias = 0;
+        if (j == 13) jb.ya = PL2Y_SIG;
+    }
+    return jb;
+}
 
 // cost of one stage (32 samples) of job j in KiB of operand tiles: the GEMM is HBM-bound, work is dealt by bytes
 __host__ __device__ inline int dwp_weight(int j) {
@@ -119,16 +146,19 @@ __host__ __device__ inline int dwp_weight(int j) {
 struct DwpPlan {
     int n_eval;
     int n_sb[DWP_MAX_EVAL];
+    int kind[DWP_MAX_EVAL];      // 0: first-order planes, 1: second-order planes
     int G;
     long long T;
 };
 
+// stages of virtual job (j, e): the evaluation's sample blocks, or none where its kind has no such job
+__host__ __device__ inline int dwp_stages(const DwpPlan& p, int j, int e) { return dwp_has(p.kind[e], j) ? p.n_sb[e] : 0; }
+
 __host__ __device__ inline long long dwp_total(const DwpPlan& p) {
-    long long sb = 0;
-    for (int e = 0; e < p.n_eval; ++e) sb += p.n_sb[e];
-    long long w = 0;
-    for (int j = 0; j < DWP_JOBS; ++j) w += dwp_weight(j);
-    return sb * w;
+    long long t = 0;
+    for (int j = 0; j < DWP_JOBS; ++j)
+        for (int e = 0; e < p.n_eval; ++e) t += (long long)dwp_stages(p, j, e) * dwp_weight(j);
+    return t;
 }
 
 __host__ __device__ inline int dwp_pick_G(long long T, int cus) {

@@ -68,8 +68,8 @@ __device__ __forceinline__ void dma_tile(const char* src, char* dst, int lane16)
 
 // MB: dY blocks per wave row (wn), KB: X blocks per wave column (wk); NA / NX: blocks of the job's operands
 template <int MB, int KB, int NA, int NX>
-__device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, const char* __restrict__ Xb, int s_lo, int s_hi,
-                                                bool bias, float* __restrict__ slot) {
+__device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, const char* __restrict__ Xb, long long ysb, long long xsb,
+                                                int s_lo, int s_hi, bool bias, float* __restrict__ slot) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wk = wave >> 2;
@@ -89,8 +89,8 @@ __device__ __forceinline__ void dwp_segment_run(const char* __restrict__ Yb, con
 
     // the wave's share of a stage's tiles: t = wave, wave + 8, ...  (A tiles first, then X tiles at DWP_XOFF)
     auto issue = [&](int s, int buf) {
-        const char* ya = Yb + (long long)s * PLY_SB_BYTES;
-        const char* xa = Xb + (long long)s * PLX_SB_BYTES;
+        const char* ya = Yb + (long long)s * ysb;
+        const char* xa = Xb + (long long)s * xsb;
         char* base = lds + buf * DWP_BUF;
 #pragma unroll
         for (int q = 0; q < (NT + 7) / 8; ++q) {
@@ -194,8 +194,8 @@ __device__ __forceinline__ u32x4 read_operand2(const char* half0, const char* ha
 }
 
 template <int MB, int KB, int NA, int NX>
-__device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, const char* __restrict__ Xb, int s_lo, int s_hi,
-                                                  bool bias, float* __restrict__ slot) {
+__device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, const char* __restrict__ Xb, long long ysb, long long xsb,
+                                                  int s_lo, int s_hi, bool bias, float* __restrict__ slot) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wk = wave >> 2;
@@ -221,8 +221,8 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
     const int n_hs = 2 * (s_hi - s_lo);
     auto issue = [&](int hs, int ring_slot) {      // half-stage hs = rows 16 (hs & 1) .. of sample block s_lo + hs / 2
         const int s = s_lo + (hs >> 1);
-        const char* ya = Yb + (long long)s * PLY_SB_BYTES + (hs & 1) * 512 + lsrc;
-        const char* xa = Xb + (long long)s * PLX_SB_BYTES + (hs & 1) * 512 + lsrc;
+        const char* ya = Yb + (long long)s * ysb + (hs & 1) * 512 + lsrc;
+        const char* xa = Xb + (long long)s * xsb + (hs & 1) * 512 + lsrc;
         char* base = lds + ring_slot * SLOT;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -308,34 +308,36 @@ __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) 
     long long P = 0, c0, c1;
     dwp_interval(p, g, c0, c1);
     for (int j = 0; j < DWP_JOBS; ++j) {
-        const DwpJob jb = dwp_job(j);
         const int w = dwp_weight(j);
         for (int e = 0; e < p.n_eval; ++e) {
-            const int n = p.n_sb[e];
+            const int n = dwp_stages(p, j, e);
             int s_lo, s_hi;
             dwp_segment(c0, c1, P, w, n, s_lo, s_hi);
             P += (long long)n * w;
             if (s_hi <= s_lo) continue;
+            const int kind = p.kind[e];
+            const DwpJob jb = dwp_job_of(kind, j);
+            const long long ysb = dwp_y_stride(kind), xsb = dwp_x_stride(kind);
             const char* Yb = A.ev[e].Y + (long long)jb.ya * PL_FB_BYTES;
             const char* Xb = A.ev[e].X + (long long)jb.xa * PL_FB_BYTES;
             float* slot = A.part + (long long)(g + j * p.n_eval + e) * DWP_SLOT_FLOATS;
             if constexpr (HALF) {
                 switch (jb.shape) {
-                case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 1: dwp_segment_run_h<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 2: dwp_segment_run_h<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 3: dwp_segment_run_h<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 4: dwp_segment_run_h<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                default: dwp_segment_run_h<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 1: dwp_segment_run_h<4, 2, 16, 4>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 2: dwp_segment_run_h<2, 8, 8, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 3: dwp_segment_run_h<2, 1, 8, 2>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 4: dwp_segment_run_h<1, 8, 1, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                default: dwp_segment_run_h<1, 4, 1, 8>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
                 }
             } else {
                 switch (jb.shape) {
-                case 0: dwp_segment_run<4, 8, 16, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 1: dwp_segment_run<4, 2, 16, 4>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 2: dwp_segment_run<2, 8, 8, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 3: dwp_segment_run<2, 1, 8, 2>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                case 4: dwp_segment_run<1, 8, 1, 16>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
-                default: dwp_segment_run<1, 4, 1, 8>(Yb, Xb, s_lo, s_hi, jb.bias, slot); break;
+                case 0: dwp_segment_run<4, 8, 16, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 1: dwp_segment_run<4, 2, 16, 4>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 2: dwp_segment_run<2, 8, 8, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 3: dwp_segment_run<2, 1, 8, 2>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 4: dwp_segment_run<1, 8, 1, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                default: dwp_segment_run<1, 4, 1, 8>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
                 }
             }
         }
@@ -363,6 +365,7 @@ struct DwpFinishArgs {
     DwpLayer layer[16];
     const float* part;
     const unsigned* seedmax[DWP_MAX_EVAL];
+    int kind[DWP_MAX_EVAL];
     short g_lo[DWP_JOBS * DWP_MAX_EVAL], g_hi[DWP_JOBS * DWP_MAX_EVAL];     // owners of virtual job v (g_lo > g_hi: none)
     int n_eval;
     int accumulate;
@@ -371,9 +374,10 @@ struct DwpFinishArgs {
 
 // scale exponent of an evaluation's dY planes: K puts the largest seed magnitude into [2^6, 2^7) (the backward kernel uses
 // the same K) plus the boost of mnrf_dwp.h
-__device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax) {
+__device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax, int kind) {
     const int e = (int)((*seedmax >> 23) & 0xffu);
-    const int K = (e == 0 || e == 255) ? 0 : 6 - (e - 127);
+    // kind 1: *seedmax holds the largest |J^| of the launch and K2 puts it into [1, 2) (field_split_bwd2_kernel uses the same K2)
+    const int K = (e == 0 || e == 255) ? 0 : (kind ? 0 : 6) - (e - 127);
     return K + PL_BOOST_LOG2;
 }
 
@@ -407,9 +411,10 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
     float total = 0.f;
     for (int e = 0; e < F.n_eval; ++e) {
         const int v = job * F.n_eval + e;
+        if (is_bias && F.kind[e]) continue;      // the second-order term has no bias gradient (its jobs write no bias sums)
         float sum = 0.f;
         for (int g = F.g_lo[v]; g <= F.g_hi[v]; ++g) sum += F.part[(long long)(g + v) * DWP_SLOT_FLOATS + idx];
-        if (F.g_lo[v] <= F.g_hi[v]) total += ldexpf(sum, -dwp_scale_log2(F.seedmax[e]));      // (ldexp: K can exceed 126)
+        if (F.g_lo[v] <= F.g_hi[v]) total += ldexpf(sum, -dwp_scale_log2(F.seedmax[e], F.kind[e]));      // (ldexp: K can exceed 126)
     }
     float* dst = is_bias ? ly.d_b + (el - nw) : ly.d_w + el;
     *dst = F.accumulate ? *dst + total : total;
@@ -465,6 +470,35 @@ void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn
                        save_inv, B, out);
 }
 
+// largest |J^| (the seed of the second-order pass) exactly as field_split_bwd2_kernel's prologue forms it
+__global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float* __restrict__ normal, const float* __restrict__ save_invj,
+                                long long B, unsigned* __restrict__ out) {
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+        const float inv = save_invj[i];
+        const float g0 = g_normal[i * 3], g1 = g_normal[i * 3 + 1], g2 = g_normal[i * 3 + 2];
+        float j0, j1, j2;
+        if (inv > 0.f) {
+            const float n0 = normal[i * 3], n1 = normal[i * 3 + 1], n2 = normal[i * 3 + 2];
+            const float dt = n0 * g0 + n1 * g1 + n2 * g2;
+            j0 = -(g0 - n0 * dt) * inv; j1 = -(g1 - n1 * dt) * inv; j2 = -(g2 - n2 * dt) * inv;
+        } else {
+            j0 = g0 * inv; j1 = g1 * inv; j2 = g2 * inv;
+        }
+        mx = fmaxf(mx, fmaxf(fabsf(j0), fmaxf(fabsf(j1), fabsf(j2))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+}
+
+void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s) {
+    zero_fill(s, out, sizeof(unsigned));
+    long long blocks = (B + 1023) / 1024;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------- driver
 static int dwp_cus() {
     static const int v = [] {
@@ -477,26 +511,26 @@ static int dwp_cus() {
     return v;
 }
 
-static DwpPlan dwp_make_plan(int n_eval, const int64_t* B) {
+static DwpPlan dwp_make_plan(int n_eval, const int64_t* B, const int* kinds) {
     DwpPlan p;
     p.n_eval = n_eval;
-    for (int e = 0; e < DWP_MAX_EVAL; ++e) p.n_sb[e] = 0;
-    for (int e = 0; e < n_eval; ++e) p.n_sb[e] = (int)(dwp_tiles128(B[e]) * 4);
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) { p.n_sb[e] = 0; p.kind[e] = 0; }
+    for (int e = 0; e < n_eval; ++e) { p.n_sb[e] = (int)(dwp_tiles128(B[e]) * 4); p.kind[e] = kinds && kinds[e] ? 1 : 0; }
     p.T = dwp_total(p);
     p.G = dwp_pick_G(p.T, dwp_cus());
     return p;
 }
 
-long long dwp_workspace_floats(int n_eval, const int64_t* B) {
-    const DwpPlan p = dwp_make_plan(n_eval, B);
+long long dwp_workspace_floats(int n_eval, const int64_t* B, const int* kinds) {
+    const DwpPlan p = dwp_make_plan(n_eval, B, kinds);
     return (long long)(p.G + DWP_JOBS * n_eval) * DWP_SLOT_FLOATS;
 }
 
 int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
-               const unsigned* const* seedmax, float* ws, float* const* d_params, int accumulate, hipStream_t s) {
+               const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate, hipStream_t s) {
     if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return -1;
     DwpArgs A;
-    A.plan = dwp_make_plan(n_eval, B);
+    A.plan = dwp_make_plan(n_eval, B, kinds);
     if (A.plan.T == 0) return accumulate ? 0 : -2;      // nothing to add; an overwrite of nothing is the caller's business
     for (int e = 0; e < n_eval; ++e) A.ev[e] = DwpEval{(const char*)x_planes[e], (const char*)dy_planes[e], seedmax[e]};
     for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr};
@@ -516,14 +550,14 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     F.part = ws;
     F.n_eval = n_eval;
     F.accumulate = accumulate;
-    for (int e = 0; e < DWP_MAX_EVAL; ++e) F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr;
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) { F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr; F.kind[e] = A.plan.kind[e]; }
     // owners of every virtual job, from the same arithmetic the kernel uses
     {
         long long P = 0;
         for (int j = 0; j < DWP_JOBS; ++j) {
             const int w = dwp_weight(j);
             for (int e = 0; e < n_eval; ++e) {
-                const int v = j * n_eval + e, n = A.plan.n_sb[e];
+                const int v = j * n_eval + e, n = dwp_stages(A.plan, j, e);
                 int lo = 1, hi = 0;
                 bool any = false;
                 for (int g = 0; g < A.plan.G; ++g) {

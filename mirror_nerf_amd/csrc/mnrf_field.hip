@@ -300,12 +300,22 @@ extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const 
 
 extern "C" int64_t mnrf_dw_planes_workspace_floats(int n_eval, const int64_t* B) {
     if (n_eval < 1 || n_eval > DWP_MAX_EVAL || !B) return 0;
-    return dwp_workspace_floats(n_eval, B);
+    return dwp_workspace_floats(n_eval, B, nullptr);
+}
+extern "C" int64_t mnrf_dw_planes2_workspace_floats(int n_eval, const int64_t* B, const int* kinds) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL || !B) return 0;
+    return dwp_workspace_floats(n_eval, B, kinds);
 }
 
 extern "C" int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
                               const uint32_t* const* seedmax, float* workspace, float* const* d_params, int accumulate,
                               void* stream) {
+    return mnrf_dw_planes2(n_eval, x_planes, dy_planes, B, seedmax, nullptr, workspace, d_params, accumulate, stream);
+}
+
+extern "C" int mnrf_dw_planes2(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                               const uint32_t* const* seedmax, const int* kinds, float* workspace, float* const* d_params,
+                               int accumulate, void* stream) {
     if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: 1..8 evaluations per call");
     if (!x_planes || !dy_planes || !B || !seedmax || !workspace || !d_params) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: null pointer");
     long long total = 0;
@@ -317,10 +327,30 @@ extern "C" int mnrf_dw_planes(int n_eval, const void* const* x_planes, const voi
     if (total * 812 >= (1LL << 31)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: too many samples for one call (split the evaluations)");
     for (int i = 0; i < MNRF_N_PARAMS; ++i)
         if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: null gradient pointer");
-    if (launch_dwp(n_eval, x_planes, dy_planes, B, (const unsigned* const*)seedmax, workspace, d_params, accumulate ? 1 : 0,
+    if (launch_dwp(n_eval, x_planes, dy_planes, B, (const unsigned* const*)seedmax, kinds, workspace, d_params, accumulate ? 1 : 0,
                    (hipStream_t)stream) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: bad plan");
     return mnrf_check_launch("mnrf_dw_planes");
+}
+
+extern "C" int64_t mnrf_train_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2X_SB_BYTES; }
+extern "C" int64_t mnrf_train_dy_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2Y_SB_BYTES; }
+
+extern "C" int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                           const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                           const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                           void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream) {
+    if (!packed || !g_normal || !normal || !save_invj || !save_mask || !x2_planes || !y2_planes || !jmax)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: negative sample count");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: need xyz or rays+z_vals");
+    hipStream_t s = (hipStream_t)stream;
+    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s);
+    FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
+                    (const unsigned long long*)save_mask, nullptr, d_xyz, (char*)x2_planes, (char*)y2_planes, jmax};
+    if (launch_split_bwd2(A, s) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: too many samples for one launch");
+    return mnrf_check_launch("mnrf_field_backward2_planes");
 }
 
 extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_FLOATS * B + dw2_workspace_floats(B); }

@@ -82,8 +82,13 @@ struct FieldBwd2Args {
     const float* normal;       // forward output (B,3)
     const float* save_invj;    // 1/|J| (negative: eps clamp)
     const unsigned long long* save_mask;
-    float* so;                 // [SO_FLOATS sections][B][width]
+    float* so;                 // [SO_FLOATS sections][B][width]   (null with the planes below)
     float* d_xyz;              // accumulated into (may be null)
+    // round 4: tangents / signals as operand planes (mnrf_dwp.h "second-order pass") under one power-of-two scale per launch,
+    // derived from the largest |J^| of the evaluation (*jmax, float bits, filled by jhat_max_kernel)
+    char* x2_planes;           // [sample blocks][PL2X_FB][hi | lo][1 KiB]
+    char* y2_planes;           // [sample blocks][PL2Y_FB][hi | lo][1 KiB]
+    const unsigned* jmax;
 };
 
 // split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.

@@ -16,7 +16,7 @@ static int check(const DwpPlan& p) {
     for (int j = 0; j < DWP_JOBS; ++j) {
         const int w = dwp_weight(j);
         for (int e = 0; e < p.n_eval; ++e) {
-            const int v = j * p.n_eval + e, n = p.n_sb[e];
+            const int v = j * p.n_eval + e, n = dwp_stages(p, j, e);
             std::vector<int> owner(n, -1);
             int g_lo = -1, g_hi = -1;
             for (int g = 0; g < p.G; ++g) {
@@ -58,13 +58,19 @@ int main() {
         wsum += dwp_weight(j);
     }
     if (wsum != 812) { std::printf("weights sum %d\n", wsum); return 1; }
+    for (int j = 0; j < DWP_JOBS; ++j) {      // second-order planes: their own (shorter) layouts
+        if (!dwp_has(1, j)) continue;
+        const DwpJob jb = dwp_job_of(1, j);
+        if (jb.bias || jb.ya + jb.na > PL2Y_FB || jb.xa + jb.nx > PL2X_FB) { std::printf("second-order job %d out of the layout\n", j); return 1; }
+    }
     std::srand(7);
     int cases = 0;
     for (int it = 0; it < 1000; ++it) {
         DwpPlan p;
         p.n_eval = 1 + std::rand() % DWP_MAX_EVAL;
-        for (int e = 0; e < DWP_MAX_EVAL; ++e) p.n_sb[e] = 0;
+        for (int e = 0; e < DWP_MAX_EVAL; ++e) { p.n_sb[e] = 0; p.kind[e] = 0; }
         for (int e = 0; e < p.n_eval; ++e) {
+            p.kind[e] = (std::rand() % 3) == 0;      // a third of the evaluations are second-order planes (trunk + sigma jobs only)
             const int kind = std::rand() % 4;
             p.n_sb[e] = kind == 0 ? 0 : (kind == 1 ? 4 * (1 + std::rand() % 3) : (kind == 2 ? 4 * (std::rand() % 600) : 4 * (std::rand() % 60000)));
         }
@@ -78,7 +84,7 @@ int main() {
     // the training bench's shape: 1024 + 257 rays x 64 (coarse) samples
     DwpPlan p;
     p.n_eval = 2;
-    for (int e = 0; e < DWP_MAX_EVAL; ++e) p.n_sb[e] = 0;
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) { p.n_sb[e] = 0; p.kind[e] = 0; }
     p.n_sb[0] = 2048; p.n_sb[1] = 516;
     p.T = dwp_total(p);
     p.G = dwp_pick_G(p.T, 256);

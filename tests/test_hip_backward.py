@@ -500,6 +500,103 @@ def test_planes_route_agrees_with_rows_route(B, n_eval, precision):
         assert _rel(a, n_eval * b) <= 1e-5, n
 
 
+@pytest.mark.parametrize("B,ray_mode", [(200, False), (4096 + 77, False), (96 * 64, True)])
+def test_second_order_planes_route_agrees_with_rows_route(B, ray_mode):
+    """The second-order term through the C ABI on the same samples: mnrf_field_backward2_planes + mnrf_dw_planes2 (kind 1)
+    against mnrf_field_backward2 (fp32 rows, bf16 x 3 GEMMs).  dL/dxyz bit-identical (the tangent pass is the same code); the
+    nine weight gradients the term reaches to 6e-5 of each tensor's largest entry; every other gradient untouched.  g_normal
+    spans eight orders of magnitude, so the per-sample scale 2^k_s and the launch scale 2^K2 both matter.  Then mixed: a
+    first-order and a second-order evaluation in ONE mnrf_dw_planes2 launch = the sum of the two routes.
+    (Why 6e-5 and not the 1e-5 of the first-order planes: at torch's default initialisation the signals b_1..b_3 are ~1e-4, and
+    16 b then has a subnormal low f16 half.  Against float64 both routes sit at 2e-5..5e-5 there, scripts/check_so_routes.py;
+    on trained weights the median |b| is 0.05..0.6, scripts/probe_b_magnitudes.py, and the halves are normal.)"""
+    import ctypes
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import _lib
+    from mirror_nerf_amd.weights import PARAM_NAMES, PARAM_SHAPES, packed_of
+    L, p = _lib.lib(), _lib.ptr
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=DEV)  # noqa: E731
+    torch.manual_seed(B + 5)
+    model = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True).to(DEV)
+    with torch.no_grad():
+        model.sigma.weight.mul_(20.0)
+    packed = packed_of(model)
+    if ray_mode:
+        spr, n_rays = 64, B // 64
+        rays = torch.cat([torch.rand(n_rays, 3, device=DEV) - 0.5, torch.nn.functional.normalize(torch.randn(n_rays, 3, device=DEV), dim=1),
+                          torch.full((n_rays, 1), 0.5, device=DEV), torch.full((n_rays, 1), 4.0, device=DEV)], 1).contiguous()
+        z = (torch.rand(n_rays, spr, device=DEV).sort(1).values * 3.5 + 0.5).contiguous()
+        xyz, xs = None, 3
+        de = M.Embedding(4)(rays[:, 3:6]).contiguous()
+    else:
+        spr, rays, z, xs = 1, None, None, 3
+        xyz = (torch.rand(B, 3, device=DEV) * 6 - 3).contiguous()
+        de = M.Embedding(4)(torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=1))
+    o = (f(B), f(B, 3), f(B, 3), f(B), f(B, 3))
+    sx = torch.zeros(L.mnrf_train_planes_bytes(B), dtype=torch.uint8, device=DEV)
+    sm = torch.zeros(L.mnrf_train_mask_words(B), dtype=torch.int64, device=DEV)
+    si, sj = f(B), f(B)
+    _lib.check(L.mnrf_field_forward_train(p(packed), B, p(xyz), xs, p(rays), p(z), spr, p(de), 27, *[p(t) for t in o], p(sx), p(sm),
+                                          p(si), p(sj), _lib.MNRF_SPLIT_F16 | _lib.MNRF_TRAIN_PLANES, _lib.stream()), "forward")
+    normal = o[4]
+    scale = 10.0 ** (torch.rand(B, device=DEV) * 8 - 8)
+    g_n = (torch.randn(B, 3, device=DEV) * scale[:, None]).contiguous()
+    g_n[::17] = 0.0                                   # samples without a gradient (zero J^: k_s = 0, zero tangents)
+    arr = lambda ts: (ctypes.c_void_p * 32)(*[t.data_ptr() for t in ts])  # noqa: E731
+    # rows
+    d_r = [torch.zeros(*PARAM_SHAPES[n], device=DEV) for n in PARAM_NAMES]
+    dx_r = torch.zeros(B, 3, device=DEV)
+    ws2 = f(L.mnrf_train_workspace2_floats(B))
+    _lib.check(L.mnrf_field_backward2(p(packed), B, p(xyz), xs, p(rays), p(z), spr, p(g_n), p(normal), p(sj), p(sm), p(ws2),
+                                      arr(d_r), p(dx_r), _lib.MNRF_SPLIT_F16, _lib.stream()), "backward2 rows")
+    # planes
+    x2 = torch.zeros(L.mnrf_train_planes2_bytes(B), dtype=torch.uint8, device=DEV)
+    y2 = torch.zeros(L.mnrf_train_dy_planes2_bytes(B), dtype=torch.uint8, device=DEV)
+    jmax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dx_p = torch.zeros(B, 3, device=DEV)
+    _lib.check(L.mnrf_field_backward2_planes(p(packed), B, p(xyz), xs, p(rays), p(z), spr, p(g_n), p(normal), p(sj), p(sm),
+                                             p(x2), p(y2), p(jmax), p(dx_p), _lib.stream()), "backward2 planes")
+    assert torch.equal(dx_r, dx_p)
+    d_p = [torch.full(PARAM_SHAPES[n], 7.0, device=DEV) for n in PARAM_NAMES]      # overwritten (accumulate = 0)
+    bs = (ctypes.c_int64 * 1)(B)
+    kd = (ctypes.c_int * 1)(1)
+    wsp = f(L.mnrf_dw_planes2_workspace_floats(1, bs, kd))
+    _lib.check(L.mnrf_dw_planes2(1, (ctypes.c_void_p * 1)(x2.data_ptr()), (ctypes.c_void_p * 1)(y2.data_ptr()), bs,
+                                 (ctypes.c_void_p * 1)(jmax.data_ptr()), kd, p(wsp), arr(d_p), 0, _lib.stream()), "dw planes2")
+    torch.cuda.synchronize()
+    reached = 0
+    for n, a, b in zip(PARAM_NAMES, d_p, d_r):
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, n      # heads, biases: the term does not reach them
+        else:
+            reached += 1
+            assert _rel(a, b) <= 6e-5, (n, _rel(a, b))
+    assert reached == 9
+    # mixed launch: first-order planes of the same samples + the second-order planes
+    g_sigma = torch.randn(B, device=DEV)
+    g_rgb, g_pn, g_m = torch.randn(B, 3, device=DEV), torch.randn(B, 3, device=DEV), torch.randn(B, device=DEV)
+    dy = torch.zeros(L.mnrf_train_dy_planes_bytes(B), dtype=torch.uint8, device=DEV)
+    seedmax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.mnrf_field_backward_planes(p(packed), B, p(xyz), xs, p(rays), p(z), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m),
+                                            p(o[1]), p(o[2]), p(o[3]), p(sm), p(si), p(dy), p(seedmax), None, None, None, 0,
+                                            _lib.stream()), "backward planes")
+    d_1 = [f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+    bs1 = (ctypes.c_int64 * 1)(B)
+    ws1 = f(L.mnrf_dw_planes_workspace_floats(1, bs1))
+    _lib.check(L.mnrf_dw_planes(1, (ctypes.c_void_p * 1)(sx.data_ptr()), (ctypes.c_void_p * 1)(dy.data_ptr()), bs1,
+                                (ctypes.c_void_p * 1)(seedmax.data_ptr()), p(ws1), arr(d_1), 0, _lib.stream()), "dw planes")
+    d_m = [f(*PARAM_SHAPES[n]) for n in PARAM_NAMES]
+    bs2 = (ctypes.c_int64 * 2)(B, B)
+    kd2 = (ctypes.c_int * 2)(0, 1)
+    wsm = f(L.mnrf_dw_planes2_workspace_floats(2, bs2, kd2))
+    _lib.check(L.mnrf_dw_planes2(2, (ctypes.c_void_p * 2)(sx.data_ptr(), x2.data_ptr()), (ctypes.c_void_p * 2)(dy.data_ptr(), y2.data_ptr()),
+                                 bs2, (ctypes.c_void_p * 2)(seedmax.data_ptr(), jmax.data_ptr()), kd2, p(wsm), arr(d_m), 0,
+                                 _lib.stream()), "dw planes2 mixed")
+    torch.cuda.synchronize()
+    for n, a, b, c in zip(PARAM_NAMES, d_m, d_1, d_p):
+        assert _rel(a, b + c) <= 1e-5, (n, _rel(a, b + c))      # (another plan deals the stages differently: another summation order)
+
+
 def test_half_stage_ring_of_the_weight_gradient_gemm():
     """MNRF_DWP_HALF=1 (read once by the library): the deeper-prefetch experiment of mnrf_dwp.hip -- half-stages through a ring
     of four buffers, K = 16 MFMAs -- computes the same gradients; the plane-route test runs on it in a child process."""
