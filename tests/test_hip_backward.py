@@ -597,13 +597,13 @@ def test_second_order_planes_route_agrees_with_rows_route(B, ray_mode):
         assert _rel(a, b + c) <= 1e-5, (n, _rel(a, b + c))      # (another plan deals the stages differently: another summation order)
 
 
-def test_half_stage_ring_of_the_weight_gradient_gemm():
-    """MNRF_DWP_HALF=1 (read once by the library): the deeper-prefetch experiment of mnrf_dwp.hip -- half-stages through a ring
-    of four buffers, K = 16 MFMAs -- computes the same gradients; the plane-route test runs on it in a child process."""
+def test_two_buffer_loop_of_the_weight_gradient_gemm():
+    """MNRF_DWP_RING=0 (read once by the library) selects the round-3 loop of mnrf_dwp.hip -- two whole-stage buffers instead of
+    the ring of half-stages -- which computes the same gradients; the plane-route tests run on it in a child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MNRF_DWP_HALF="1")
+    env = dict(os.environ, MNRF_DWP_RING="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                         "planes_route_agrees or field_backward_matches_autograd"],
