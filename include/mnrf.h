@@ -264,6 +264,12 @@ int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double l
  * `bytes` of `buf` with the instruction that GEMM streams its operand planes with (global_load_lds_dwordx4, 1 KiB per
  * wave-instruction, `depth` = 8 or 16 in flight per wave, aux = 0 default policy / 2 non-temporal), computing nothing. */
 int mnrf_bench_stream(const void* buf, int64_t bytes, int aux, int depth, void* stream);
+/* ... and with the GEMM's address pattern: `windows` jobs, job-major; job w reads, per 32-sample stage s, chunk_a bytes at
+ * a + s * stride_a + w * chunk_a and chunk_x bytes at x + s * stride_x + w * chunk_x (whole KiB; windows * n_stages >= 256 units
+ * dealt to one workgroup per CU), 16 KiB in flight per wave, nt policy, barrier != 0: a raw workgroup barrier per stage like the
+ * GEMM's (scripts/bw_probe.py). */
+int mnrf_bench_stream2(const void* a, const void* x, int n_stages, int64_t stride_a, int64_t stride_x, int chunk_a, int chunk_x,
+                       int windows, int barrier, void* stream);
 
 /* Measurement aid for the hash-grid field: the rate of independent random gathers of 8 B (a float2 table entry) or 4 B (what
  * an fp16 table would fetch) from a table of `table_bytes` -- the ceiling that bounds that field's kernels once the table is

@@ -82,6 +82,7 @@ SIGNATURES = {
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p),
                                _int, _str]),
     "mnrf_bench_stream": (_int, [ctypes.c_void_p, _i64, _int, _int, _str]),
+    "mnrf_bench_stream2": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, _i64, _i64, _int, _int, _int, _int, _str]),
     "mnrf_bench_gather": (_int, [ctypes.c_void_p, _i64, _int, _i64, _int, _c_f, _str]),
     "mnrf_tcnn_encode": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,
                                 _c_f, _str]),

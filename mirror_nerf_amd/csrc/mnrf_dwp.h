@@ -132,10 +132,17 @@ __host__ __device__ inline DwpJob dwp_job_of(int kind, int j) {
     return jb;
 }
 
-// cost of one stage (32 samples) of job j in KiB of operand tiles: the GEMM is HBM-bound, work is dealt by bytes
+// cost of one stage (32 samples) of job j: KiB of operand tiles (the GEMM is HBM-bound, work is dealt by bytes) plus what a
+// stage costs whatever its size -- barrier, counted wait, request -- expressed in KiB: without it the workgroups that own the
+// small jobs (18-40 KiB per stage) finish last
+#ifndef MNRF_EXP_DWP_STAGE_KIB
+#define MNRF_EXP_DWP_STAGE_KIB 0
+#endif
+constexpr int DWP_STAGE_KIB = MNRF_EXP_DWP_STAGE_KIB;
+constexpr int DWP_MAX_WEIGHT = 64 + DWP_STAGE_KIB;
 __host__ __device__ inline int dwp_weight(int j) {
     const DwpJob jb = dwp_job(j);
-    return 2 * (jb.na + jb.nx);
+    return 2 * (jb.na + jb.nx) + DWP_STAGE_KIB;
 }
 
 // ---- work plan.  Virtual job v = j * n_eval + e (job-major); its stage s (sample block s of evaluation e) starts at cost
@@ -162,7 +169,7 @@ __host__ __device__ inline long long dwp_total(const DwpPlan& p) {
 }
 
 __host__ __device__ inline int dwp_pick_G(long long T, int cus) {
-    long long g = T / 256;
+    long long g = T / (4 * DWP_MAX_WEIGHT);
     if (g < 1) g = 1;
     return (int)(g < cus ? g : cus);
 }

@@ -235,6 +235,25 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
         }
     };
 
+    auto issue_piece = [&](int hs, int ring_slot, int q) {      // instruction q of half-stage hs alone
+        const int s = s_lo + (hs >> 1);
+        int pr = wave + 8 * q;
+        if (pr >= NP) pr -= NP;
+        const char* src = pr < NA ? Yb + (long long)s * ysb + (hs & 1) * 512 + lsrc + pr * PL_FB_BYTES
+                                  : Xb + (long long)s * xsb + (hs & 1) * 512 + lsrc + (pr - NA) * PL_FB_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + ring_slot * SLOT + pr * 1024), 16, 0, PL_LOAD_AUX);
+    };
+    // PACED (default since the end of round 4): the 2 Q requests that refill a stage's slots are spread over the KB column blocks
+    // of the stage's MFMAs instead of leaving as one burst of 8 waves x 2 Q instructions right after the barrier, and the X
+    // operands are read one column block ahead (below).  Together 1.23 against 1.28-1.36 ms for the two evaluations of a training
+    // step -- the time of this loop with its LDS reads and MFMAs compiled out (MNRF_EXP_DWP_NOMATH): the math is hidden now.
+#if defined(MNRF_EXP_DWP_BURST) || defined(MNRF_EXP_DWP_NOMATH)
+    constexpr bool PACED = false;
+#else
+    constexpr bool PACED = true;
+#endif
+
     __syncthreads();                 // the previous segment's last stage has been read by every wave
     int next_hs = 0, next_slot = 0;  // next half-stage to request and the slot it goes to (hs mod D)
 #pragma unroll 1
@@ -247,8 +266,18 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
         // a RAW barrier: __syncthreads() waits for vmcnt(0) first and would drain the ring.  After it everybody's tiles of stage
         // st are there and stage st - 1 has been read (its LDS reads were consumed by its MFMAs): its two slots are free
         __builtin_amdgcn_s_barrier();
+        // ... for half-stages hs0, hs0 + 1: request idx of 2 Q = instruction idx % Q of half-stage hs0 + idx / Q
+        const int hs0 = next_hs, slot0 = next_slot, slot1 = next_slot + 1 == D ? 0 : next_slot + 1;
+        const auto request = [&](int idx) {
+            const int k = idx / Q, q = idx - k * Q;
+            if (hs0 + k < n_hs) issue_piece(hs0 + k, k == 0 ? slot0 : slot1, q);
+        };
 #pragma unroll 1
-        for (int k = 0; k < 2 && next_hs < n_hs; ++k, ++next_hs) { issue(next_hs, next_slot); next_slot = next_slot + 1 == D ? 0 : next_slot + 1; }
+        for (int k = 0; k < 2 && next_hs < n_hs; ++k, ++next_hs) next_slot = next_slot + 1 == D ? 0 : next_slot + 1;
+        if (!PACED || !has_a) {      // (a wave without a row block has no MFMAs to spread them over)
+#pragma unroll
+            for (int idx = 0; idx < 2 * Q; ++idx) request(idx);
+        }
         const int cur1 = cur + 1 == D ? 0 : cur + 1;
         const char* A0 = lds + cur * SLOT;
         const char* A1 = lds + cur1 * SLOT;
@@ -265,10 +294,21 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
                 ah[mb] = read_operand2(A0 + (wn * MB + mb) * 1024, A1 + (wn * MB + mb) * 1024, lane8);
                 al[mb] = read_operand2(A0 + (wn * MB + mb) * 1024 + 512, A1 + (wn * MB + mb) * 1024 + 512, lane8);
             }
+            // the X operands one column block ahead of the MFMAs that consume them, requested after the first row block's MFMAs
+            // of the block before: their LDS round trip runs under the other 3 (MB - 1) MFMAs.  (The compiler's own schedule read
+            // two blocks, waited for all of them, multiplied; and it waits with lgkmcnt(0) for these transposing reads, so the
+            // request must not be the last thing before the wait: hence the scheduling barriers.)
+            u32x4 bhq[2], blq[2];
+            bhq[0] = read_operand2(X0 + (wk * KB) * 1024, X1 + (wk * KB) * 1024, lane8);
+            blq[0] = read_operand2(X0 + (wk * KB) * 1024 + 512, X1 + (wk * KB) * 1024 + 512, lane8);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const u32x4 bh = read_operand2(X0 + (wk * KB + kb) * 1024, X1 + (wk * KB + kb) * 1024, lane8);
-                const u32x4 bl = read_operand2(X0 + (wk * KB + kb) * 1024 + 512, X1 + (wk * KB + kb) * 1024 + 512, lane8);
+                if constexpr (PACED) {
+#pragma unroll
+                    for (int idx = kb * 2 * Q / KB; idx < (kb + 1) * 2 * Q / KB; ++idx) request(idx);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 bh = bhq[kb & 1], bl = blq[kb & 1];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     f32x4 c = acc[mb][kb];
@@ -276,7 +316,16 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
                     c = mfma_h(ah[mb], bl, c);      // hi . lo
                     c = mfma_h(ah[mb], bh, c);      // hi . hi
                     acc[mb][kb] = c;
+                    if (mb == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kb + 1 < KB) {
+                            bhq[(kb + 1) & 1] = read_operand2(X0 + (wk * KB + kb + 1) * 1024, X1 + (wk * KB + kb + 1) * 1024, lane8);
+                            blq[(kb + 1) & 1] = read_operand2(X0 + (wk * KB + kb + 1) * 1024 + 512, X1 + (wk * KB + kb + 1) * 1024 + 512, lane8);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (bias && wk == 0) {
 #pragma unroll
@@ -632,6 +681,69 @@ __global__ __launch_bounds__(512, 1) void stream_probe_kernel(const char* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 }  // namespace mnrf
+
+namespace mnrf {
+// The same reader with the GEMM's ADDRESS PATTERN: a workgroup walks consecutive 32-sample stages and takes chunk_a bytes at
+// a + s * stride_a and chunk_x bytes at x + s * stride_x per stage (chunks of 1 KiB pieces dealt to the 8 waves), 16 pieces in
+// flight per wave, optionally with the GEMM's raw barrier per stage.  Separates "strided chunks instead of one contiguous run" and
+// "eight waves in lock step" from everything else that distinguishes dwp_gemm_kernel from the contiguous probe above.
+// HALVES: the GEMM ring's lane pattern -- a stage travels as two half-stages, an instruction takes rows 0-15 (or 16-31) of the hi
+// tile (lanes 0-31) and of the lo tile (lanes 32-63) of a feature block: two 512-byte runs instead of 1 KiB contiguous
+template <bool BARRIER, bool HALVES>
+__global__ __launch_bounds__(512, 1) void stream_probe2_kernel(const char* __restrict__ a, const char* __restrict__ x, int n_stages,
+                                                               long long stride_a, long long stride_x, int pieces_a, int pieces_x,
+                                                               int windows) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // `windows` jobs, job-major like the GEMM's cost line: job w reads the w-th chunk-sized window of every stage's stride
+    const long long units = (long long)windows * n_stages;
+    const long long u0 = blockIdx.x * units / gridDim.x, u1 = (blockIdx.x + 1) * units / gridDim.x;
+    char* dst = dwp_smem + wave * (16 * 1024);
+    const int per_wave = (pieces_a + pieces_x + 7) / 8;      // pieces per wave and stage (a wave past the end re-loads piece 0)
+    int k = 0;
+    for (long long u = u0; u < u1; ++u) {
+        const int w = (int)(u / n_stages), s = (int)(u - (long long)w * n_stages);
+        const int lsrc = HALVES ? (lane >> 5) * 1024 + (lane & 31) * 16 : lane * 16;
+        const char* pa = a + (long long)s * stride_a + (long long)w * pieces_a * 1024 + lsrc;
+        const char* px = x + (long long)s * stride_x + (long long)w * pieces_x * 1024 + lsrc;
+        for (int q = 0; q < per_wave; ++q, ++k) {
+            int pc = wave + 8 * q;
+            if (pc >= pieces_a + pieces_x) pc = 0;
+            const char* src = pc < pieces_a ? pa : px;
+            if (pc >= pieces_a) pc -= pieces_a;
+            // HALVES: piece pc = half h of feature block fb of the chunk (all blocks' half 0 first: a half-stage), else KiB pc
+            const int np = pc < pieces_a && src == pa ? pieces_a : pieces_x;
+            src += HALVES ? (pc % (np / 2)) * 2048 + (pc / (np / 2)) * 512 : pc * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (k & 15) * 1024), 16, 0, PL_LOAD_AUX);
+            if (k >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        }
+        if (BARRIER) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+}  // namespace mnrf
+
+extern "C" int mnrf_bench_stream2(const void* a, const void* x, int n_stages, int64_t stride_a, int64_t stride_x, int chunk_a, int chunk_x,
+                                  int windows, int barrier, void* stream) {
+    using namespace mnrf;
+    if (!a || !x || n_stages < 256 || chunk_a < 1024 || chunk_x < 0 || (chunk_a & 1023) || (chunk_x & 1023) || windows < 1 ||
+        (int64_t)windows * chunk_a > stride_a || (int64_t)windows * chunk_x > stride_x)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_bench_stream2: chunks in whole KiB, at least 256 stages");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipStream_t s = (hipStream_t)stream;
+    const bool halves = (barrier & 2) != 0;
+    if ((barrier & 1) && halves) hipLaunchKernelGGL((stream_probe2_kernel<true, true>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                                    (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    else if (barrier & 1) hipLaunchKernelGGL((stream_probe2_kernel<true, false>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                                    (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    else if (halves) hipLaunchKernelGGL((stream_probe2_kernel<false, true>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                            (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    else hipLaunchKernelGGL((stream_probe2_kernel<false, false>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                            (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    return mnrf_check_launch("mnrf_bench_stream2");
+}
 
 extern "C" int mnrf_bench_stream(const void* buf, int64_t bytes, int aux, int depth, void* stream) {
     using namespace mnrf;

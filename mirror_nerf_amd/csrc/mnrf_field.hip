@@ -324,7 +324,7 @@ extern "C" int mnrf_dw_planes2(int n_eval, const void* const* x_planes, const vo
             return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: every evaluation needs B > 0 and its three buffers");
         total += dwp_sample_blocks(B[e]);
     }
-    if (total * 812 >= (1LL << 31)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: too many samples for one call (split the evaluations)");
+    if (total * (812 + DWP_JOBS * DWP_STAGE_KIB) >= (1LL << 31)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: too many samples for one call (split the evaluations)");
     for (int i = 0; i < MNRF_N_PARAMS; ++i)
         if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes: null gradient pointer");
     if (launch_dwp(n_eval, x_planes, dy_planes, B, (const unsigned* const*)seedmax, kinds, workspace, d_params, accumulate ? 1 : 0,

@@ -45,6 +45,17 @@ for aux in (0, 2):
         t = timed(lambda: _lib.check(L.mnrf_bench_stream(ctypes.c_void_p(xs[0].data_ptr()), xs[0].numel(), aux, depth, _lib.stream()), "stream"))
         print(f"LDS-DMA streaming read ({'nt' if aux else 'default'} policy, {depth} x 1 KiB in flight per wave) of {xs[0].numel() / 1e9:.2f} GB: "
               f"{xs[0].numel() // 256 // 8192 * 8192 * 256 / t / 1e12:.2f} TB/s")
+# the same instruction with the GEMM's address pattern (job 1: 32 KiB of dY + 32 KiB of X per 32-sample stage, strides of the plane
+# layouts), without and with a workgroup barrier per stage; then with the chunks contiguous (stride = chunk)
+nsb = xs[0].numel() // (174 * 2048)
+for name, sa, sx, win in (("10 jobs over the plane strides (344 / 348 KiB)", 172 * 2048, 174 * 2048, 10),
+                          ("one job over contiguous chunks", 32768, 32768, 1)):
+    for barrier in (0, 1, 2, 3):      # bit 0: barrier per stage, bit 1: the ring's half-tile lane pattern
+        ns = nsb if win > 1 else min(ys[0].numel(), xs[0].numel()) // 32768
+        t = timed(lambda: _lib.check(L.mnrf_bench_stream2(ctypes.c_void_p(ys[0].data_ptr()), ctypes.c_void_p(xs[0].data_ptr()), ns, sa, sx,
+                                                          32768, 32768, win, barrier, _lib.stream()), "stream2"))
+        print(f"LDS-DMA read (nt), 2 x 32 KiB per stage, {name}, {'barrier per stage' if barrier & 1 else 'no barrier'}{', half-tile pattern' if barrier & 2 else ''}: "
+              f"{ns * win * 65536 / t / 1e12:.2f} TB/s")
 n = len(Bs)
 bs = (ctypes.c_int64 * n)(*Bs)
 seed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in Bs]

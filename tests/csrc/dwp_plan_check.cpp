@@ -57,7 +57,7 @@ int main() {
         if (jb.ya < 0 || jb.ya + jb.na > PLY_FB || jb.xa < 0 || jb.xa + jb.nx > PLX_FB || jb.na > 16 || jb.nx > 16) { std::printf("job %d out of the layout\n", j); return 1; }
         wsum += dwp_weight(j);
     }
-    if (wsum != 812) { std::printf("weights sum %d\n", wsum); return 1; }
+    if (wsum != 812 + DWP_JOBS * DWP_STAGE_KIB) { std::printf("weights sum %d\n", wsum); return 1; }
     for (int j = 0; j < DWP_JOBS; ++j) {      // second-order planes: their own (shorter) layouts
         if (!dwp_has(1, j)) continue;
         const DwpJob jb = dwp_job_of(1, j);
