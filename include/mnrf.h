@@ -266,8 +266,9 @@ int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double l
 int mnrf_bench_stream(const void* buf, int64_t bytes, int aux, int depth, void* stream);
 /* ... and with the GEMM's address pattern: `windows` jobs, job-major; job w reads, per 32-sample stage s, chunk_a bytes at
  * a + s * stride_a + w * chunk_a and chunk_x bytes at x + s * stride_x + w * chunk_x (whole KiB; windows * n_stages >= 256 units
- * dealt to one workgroup per CU), 16 KiB in flight per wave, nt policy, barrier != 0: a raw workgroup barrier per stage like the
- * GEMM's (scripts/bw_probe.py). */
+ * dealt to one workgroup per CU), 16 KiB in flight per wave, nt policy.  `barrier` is a bit set: 1 = a raw workgroup barrier per
+ * stage like the GEMM's, 2 = the GEMM ring's half-tile lane pattern, 4 / 8 = (with 1 and 2) its stage-wise wait for all but 4 / 12
+ * of a wave's requests instead of an instruction-wise wait for the oldest of 16 (scripts/bw_probe.py). */
 int mnrf_bench_stream2(const void* a, const void* x, int n_stages, int64_t stride_a, int64_t stride_x, int chunk_a, int chunk_x,
                        int windows, int barrier, void* stream);
 

@@ -227,7 +227,10 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             int pr = wave + 8 * q;
-            if (pr >= NP) pr -= NP;              // (no work left for this wave: an identical re-load keeps the counts uniform)
+            // no work left for this wave: an identical re-load keeps the counts uniform.  (Skipping it instead -- such a wave then
+            // counts Q - 1 requests per half-stage -- removes 10 % of a training step's requests and measured SLOWER: 1.30-1.38
+            // against 1.24-1.25 ms, alternating on one box.)
+            if (pr >= NP) pr -= NP;
             const char* src = pr < NA ? ya + pr * PL_FB_BYTES : xa + (pr - NA) * PL_FB_BYTES;
             char* dst = base + pr * 1024;        // [dY half-tile pairs: NA KiB][X half-tile pairs: NX KiB]
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -689,7 +692,10 @@ namespace mnrf {
 // "eight waves in lock step" from everything else that distinguishes dwp_gemm_kernel from the contiguous probe above.
 // HALVES: the GEMM ring's lane pattern -- a stage travels as two half-stages, an instruction takes rows 0-15 (or 16-31) of the hi
 // tile (lanes 0-31) and of the lo tile (lanes 32-63) of a feature block: two 512-byte runs instead of 1 KiB contiguous
-template <bool BARRIER, bool HALVES>
+// BULK (1: the GEMM ring with D = 5, 2: a deeper one): the wave does not wait instruction by instruction for its oldest request but,
+// once per stage, until all but 4 (12) of its requests have landed -- the stage is complete -- then the barrier, then the next
+// stage's 8 requests in one burst
+template <bool BARRIER, bool HALVES, int BULK = 0>
 __global__ __launch_bounds__(512, 1) void stream_probe2_kernel(const char* __restrict__ a, const char* __restrict__ x, int n_stages,
                                                                long long stride_a, long long stride_x, int pieces_a, int pieces_x,
                                                                int windows) {
@@ -716,8 +722,10 @@ __global__ __launch_bounds__(512, 1) void stream_probe2_kernel(const char* __res
             src += HALVES ? (pc % (np / 2)) * 2048 + (pc / (np / 2)) * 512 : pc * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + (k & 15) * 1024), 16, 0, PL_LOAD_AUX);
-            if (k >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            if (BULK == 0 && k >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
         }
+        if (BULK == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (BULK == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -734,7 +742,11 @@ extern "C" int mnrf_bench_stream2(const void* a, const void* x, int n_stages, in
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     hipStream_t s = (hipStream_t)stream;
     const bool halves = (barrier & 2) != 0;
-    if ((barrier & 1) && halves) hipLaunchKernelGGL((stream_probe2_kernel<true, true>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+    if (barrier & 4) hipLaunchKernelGGL((stream_probe2_kernel<true, true, 1>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                                    (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    else if (barrier & 8) hipLaunchKernelGGL((stream_probe2_kernel<true, true, 2>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
+                                    (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
+    else if ((barrier & 1) && halves) hipLaunchKernelGGL((stream_probe2_kernel<true, true>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
                                     (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);
     else if (barrier & 1) hipLaunchKernelGGL((stream_probe2_kernel<true, false>), dim3(cus), dim3(512), 128 * 1024, s, (const char*)a, (const char*)x, n_stages,
                                     (long long)stride_a, (long long)stride_x, chunk_a / 1024, chunk_x / 1024, windows);

@@ -50,11 +50,11 @@ for aux in (0, 2):
 nsb = xs[0].numel() // (174 * 2048)
 for name, sa, sx, win in (("10 jobs over the plane strides (344 / 348 KiB)", 172 * 2048, 174 * 2048, 10),
                           ("one job over contiguous chunks", 32768, 32768, 1)):
-    for barrier in (0, 1, 2, 3):      # bit 0: barrier per stage, bit 1: the ring's half-tile lane pattern
+    for barrier in (0, 1, 2, 3, 7, 11):      # bit 0: barrier per stage, bit 1: the ring's half-tile lane pattern, bits 2 / 3: bulk waits
         ns = nsb if win > 1 else min(ys[0].numel(), xs[0].numel()) // 32768
         t = timed(lambda: _lib.check(L.mnrf_bench_stream2(ctypes.c_void_p(ys[0].data_ptr()), ctypes.c_void_p(xs[0].data_ptr()), ns, sa, sx,
                                                           32768, 32768, win, barrier, _lib.stream()), "stream2"))
-        print(f"LDS-DMA read (nt), 2 x 32 KiB per stage, {name}, {'barrier per stage' if barrier & 1 else 'no barrier'}{', half-tile pattern' if barrier & 2 else ''}: "
+        print(f"LDS-DMA read (nt), 2 x 32 KiB per stage, {name}, {'barrier per stage' if barrier & 1 else 'no barrier'}{', half-tile pattern' if barrier & 2 else ''}{', stage-wise wait for all but 4 requests per wave' if barrier & 4 else ''}{', stage-wise wait for all but 12' if barrier & 8 else ''}: "
               f"{ns * win * 65536 / t / 1e12:.2f} TB/s")
 n = len(Bs)
 bs = (ctypes.c_int64 * n)(*Bs)
@@ -69,3 +69,16 @@ t = timed(lambda: _lib.check(L.mnrf_dw_planes(n, X, Y, bs, S, p(ws), arr, 0, _li
 sb = sum((B + 127) // 128 * 4 for B in Bs)
 print(f"mnrf_dw_planes: {t * 1e3:.3f} ms; unique plane bytes {total / 1e9:.2f} GB = {total / t / 1e12:.2f} TB/s; "
       f"bytes the jobs read {sb * 812 * 1024 / 1e9:.2f} GB = {sb * 812 * 1024 / t / 1e12:.2f} TB/s")
+
+# the same launch over second-order planes only (kind 1: the trunk jobs and sigma, 562 KiB per sample block, 91 % of it in the
+# 64-KiB-per-stage jobs): how much of the distance to the probe belongs to the small jobs of the first-order table
+x2 = torch.randint(0, 255, (L.mnrf_train_planes2_bytes(Bs[0]),), dtype=torch.uint8, device=dev)
+y2 = torch.randint(0, 255, (L.mnrf_train_dy_planes2_bytes(Bs[0]),), dtype=torch.uint8, device=dev)
+bs1 = (ctypes.c_int64 * 1)(Bs[0])
+kd1 = (ctypes.c_int * 1)(1)
+ws1 = torch.empty(L.mnrf_dw_planes2_workspace_floats(1, bs1, kd1), dtype=torch.float32, device=dev)
+t = timed(lambda: _lib.check(L.mnrf_dw_planes2(1, (ctypes.c_void_p * 1)(x2.data_ptr()), (ctypes.c_void_p * 1)(y2.data_ptr()), bs1,
+                                               (ctypes.c_void_p * 1)(seed[0].data_ptr()), kd1, p(ws1), arr, 0, _lib.stream()), "dw2"))
+sb1 = (Bs[0] + 127) // 128 * 4
+print(f"mnrf_dw_planes2, second-order planes of {Bs[0]} samples: {t * 1e3:.3f} ms; bytes the jobs read {sb1 * 562 * 1024 / 1e9:.2f} GB = "
+      f"{sb1 * 562 * 1024 / t / 1e12:.2f} TB/s")
