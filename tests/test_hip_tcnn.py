@@ -406,19 +406,23 @@ def test_tcnn_forward_sees_updated_weights():
     xt = torch.from_numpy(x6).to(DEV)
     with torch.no_grad():
         first = m(xt, compute_normal=False)["rgb"].cpu().numpy()
-        ptrs = {m._weights().data_ptr()}
-        for _ in range(4):
+        ptrs, rounds = {m._weights().data_ptr()}, 0
+        # (the caching allocator hands the blob's address out again after a few rounds -- how many depends on what the
+        # process allocated before: at least 4 rounds, then until an address has repeated)
+        while rounds < 4 or (len(ptrs) == rounds + 1 and rounds < 64):
+            rounds += 1
             for name in ("sigma_net.0.weight", "color_net.1.weight", "is_mirror_net.0.bias"):
                 p = dict(m.named_parameters())[name]
-                p.mul_(1.25).add_(0.01)
+                p.mul_(1.25 if rounds % 2 else 0.8).add_(0.01 if rounds % 2 else -0.008)      # (there and back: bounded)
                 w[name] = p.detach().cpu().numpy().copy()
             ptrs.add(m._weights().data_ptr())     # (the caching allocator alternates between two blocks: addresses repeat)
             got = {k: v.cpu().numpy() for k, v in m(xt, compute_normal=False).items()}
             want = O.tcnn_field_forward(w, x6, cfg, False, False)
             for k in ("sigma", "rgb", "is_mirror"):
                 assert float(np.max(np.abs(got[k] - want[k]))) <= 5e-5, k
-    assert float(np.max(np.abs(first - got["rgb"]))) > 1e-3      # (the edits did change the output)
-    assert len(ptrs) < 5                                          # (at least one address was reused)
+            assert float(np.max(np.abs(first - got["rgb"]))) > 1e-3      # (the edit did change the output)
+            first = got["rgb"]
+    assert len(ptrs) <= rounds                                    # (at least one address was reused)
 
 
 @pytest.mark.parametrize("sigma_only,grad", [(False, False)])
