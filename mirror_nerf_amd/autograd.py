@@ -139,12 +139,18 @@ class FieldFn(torch.autograd.Function):
                 (_lib.MNRF_SPLIT_F16 if split else 0) | (_lib.MNRF_TRAIN_PLANES if planes else 0), _lib.stream()),
                 "mnrf_field_forward_train")
         ctx.split, ctx.planes = split, planes    # the backward follows the arithmetic (and the save format) of ITS forward
+        ctx.packed = packed                      # ... and reads ITS weights: the image object (31 us of host time per look-up)
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.set_materialize_grads(False)   # an unused `normal` must arrive as None, not as zeros: it gates the second-order pass
         ctx.save_for_backward(xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj)
-        ctx.param_shapes = [tuple(t.shape) for t in params]
+        # names / shapes of `params` (same order: weights.params_of), cached on the module next to the list they derive from
         from .weights import param_refs
-        ctx.param_names = [full for _, _, full in param_refs(module)]     # same order as `params` (weights.params_of)
+        refs = param_refs(module)
+        meta = module.__dict__.get("_mnrf_param_meta")
+        if meta is None or meta[0] is not refs or len(meta[1]) != len(params):
+            meta = (refs, [full for _, _, full in refs], [tuple(t.shape) for t in params])
+            module.__dict__["_mnrf_param_meta"] = meta
+        ctx.param_names, ctx.param_shapes = meta[1], meta[2]
         # how many evaluations of this module await their backward (primary + reflected rays: see backward).  A gradient
         # buffer still pending at FORWARD time belongs to a backward pass that died (an exception skips the engine's
         # end-of-pass callbacks): drop it together with its count
@@ -159,11 +165,10 @@ class FieldFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal):
         import ctypes
-        from .weights import packed_of
         L = _lib.lib()
         xyz, rays, z_vals, rgb, pn, mir, save_x, save_mask, save_inv, normal, save_invj = ctx.saved_tensors
         B, spr = ctx.B, ctx.spr
-        packed = packed_of(ctx.module)
+        packed = ctx.packed
         dev = packed.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         z = lambda t, *s: torch.zeros(*s, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()  # noqa: E731
@@ -195,8 +200,7 @@ class FieldFn(torch.autograd.Function):
         first = st is None
         if first:
             st = _Pending(ctx.param_names, ctx.param_shapes, dev)
-        all32 = st.all32()
-        arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in all32])
+        arr = st.pointers()
         need = ctx.needs_input_grad
         want_xyz = (xyz is not None and need[2]) or (rays is not None and need[3])
         d_xyz = f(B, 3) if want_xyz else None
@@ -291,23 +295,42 @@ class FieldFn(torch.autograd.Function):
 
 class _Pending:
     """Gradient tensors of one module for one backward pass: views of ONE flat buffer in state_dict order of the 32 field
-    parameters (an absent optional head keeps its slots as scratch), plus the tape of the planes route."""
+    parameters (an absent optional head keeps its slots as scratch), plus the tape of the planes route.  The kernels only need
+    the 32 addresses (base + offset); the views are made when the gradients are handed over (creating them up front cost 70 us
+    of host time in front of the first backward launch of every module, where the device has nothing else queued)."""
+    _layout = None      # (names, sizes, byte offsets, total) of weights.PARAM_NAMES, computed once
 
     def __init__(self, names, shapes, dev):
-        from .weights import PARAM_NAMES, PARAM_SHAPES
+        if _Pending._layout is None:
+            from .weights import PARAM_NAMES, PARAM_SHAPES
+            sizes = [int(torch.Size(PARAM_SHAPES[n]).numel()) for n in PARAM_NAMES]
+            offs, off = [], 0
+            for k in sizes:
+                offs.append(off)
+                off += k
+            _Pending._layout = (list(PARAM_NAMES), sizes, offs, off)
         self.names, self.shapes = list(names), list(shapes)
-        sizes = [int(torch.Size(PARAM_SHAPES[n]).numel()) for n in PARAM_NAMES]
-        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        self._views, off = {}, 0
-        for n, k in zip(PARAM_NAMES, sizes):
-            self._views[n] = self.flat[off:off + k].view(PARAM_SHAPES[n])
-            off += k
+        self.flat = torch.empty(_Pending._layout[3], dtype=torch.float32, device=dev)
+        self._views = None
         self.tape = []          # (x_planes, dy_planes, B, seedmax, kind) per evaluation and order
         self.dirty = False      # the tensors hold a partial sum already (rows route, second-order pass)
 
+    def pointers(self):
+        """ctypes array of the 32 gradient addresses (what the C ABI's d_params takes)."""
+        import ctypes
+        base = self.flat.data_ptr()
+        return (ctypes.c_void_p * _lib.N_PARAMS)(*[base + 4 * o for o in _Pending._layout[2]])
+
+    def views(self):
+        if self._views is None:
+            from .weights import PARAM_SHAPES
+            names, sizes, offs, _ = _Pending._layout
+            self._views = {n: self.flat[o:o + k].view(PARAM_SHAPES[n]) for n, k, o in zip(names, sizes, offs)}
+        return self._views
+
     def all32(self):
-        from .weights import PARAM_NAMES
-        return [self._views[n] for n in PARAM_NAMES]
+        v = self.views()
+        return [v[n] for n in _Pending._layout[0]]
 
     def finish(self):
         """Complete the gradients (launch the weight-gradient GEMM over the tape) and return them in the module's order."""
@@ -316,7 +339,7 @@ class _Pending:
         p = _lib.ptr
         tape, self.tape = self.tape, []
         if tape:
-            arr = (ctypes.c_void_p * _lib.N_PARAMS)(*[t.data_ptr() for t in self.all32()])
+            arr = self.pointers()
             for g0 in range(0, len(tape), 8):          # mnrf_dw_planes takes up to 8 evaluations per call
                 grp = tape[g0:g0 + 8]
                 n = len(grp)
@@ -331,7 +354,8 @@ class _Pending:
         elif not self.dirty:
             self.flat.zero_()      # no samples at all in this pass
         from .weights import decanonical      # (a model with fewer encoding bands: its own column count, weights.canonical)
-        return [decanonical(n, self._views[n], s) if n in self._views else torch.zeros(s, device=self.flat.device)
+        views = self.views()
+        return [decanonical(n, views[n], s) if n in views else torch.zeros(s, device=self.flat.device)
                 for n, s in zip(self.names, self.shapes)]
 
 

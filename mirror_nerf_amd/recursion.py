@@ -255,6 +255,11 @@ class NeRFSystem(nn.Module):
         return out
 
     def _forward(self, rays, extra):
+        from .weights import validated
+        with validated(self.models.values()):      # (the packed weight images are checked once per call, not per evaluation)
+            return self._forward_chunks(rays, extra)
+
+    def _forward_chunks(self, rays, extra):
         hp = self.hparams
         results = defaultdict(list)
         for i in range(0, rays.shape[0], hp.chunk):

@@ -1,4 +1,5 @@
-"""Host-side profile of the training step (cProfile): where the Python/launch time of a step goes."""
+"""Host-side profile of the training step (cProfile): where the Python/launch time of a step goes.
+python scripts/prof_train_host.py [tottime|cumtime]   (cumtime: this package's functions only)"""
 import cProfile
 import os
 import pstats
@@ -17,6 +18,9 @@ pr = cProfile.Profile()
 pr.enable()
 r = training.synthetic_train_bench(dev, rays, 20, 3, 1024)
 pr.disable()
-print(r["ms_per_step"])
+print(r["ms_per_step"], "ms per step under the profiler; 23 steps profiled")
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+if len(sys.argv) > 1 and sys.argv[1] == "cumtime":
+    st.sort_stats("cumtime").print_stats("mirror_nerf_amd", 45)
+else:
+    st.sort_stats("tottime").print_stats(28)

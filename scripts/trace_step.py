@@ -23,8 +23,8 @@ for r in step:
     idle += gap
     busy += e - s
     prev_end = max(prev_end, e)
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    name = name.replace("at::native::", "").replace("(anonymous namespace)::", "")[:60]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("at::native::", "")
+    name = name.split("(")[0][:60]
     out.append((s - t0, e - s, gap, name))
 print(f"step: {len(step)} launches, wall {(prev_end - t0) / 1e3:.1f} us, busy {busy / 1e3:.1f} us, idle {idle / 1e3:.1f} us")
 agg = {}
