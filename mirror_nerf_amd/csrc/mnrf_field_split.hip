@@ -67,21 +67,21 @@ int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s) { return h2x::launch_
 int launch_split_bwd2(const FieldBwd2Args& A, hipStream_t s) { return h2x::launch_bwd2(A, s); }
 
 // ------------------------------------------------------------------ split-stream packer
-// One thread per f16 of the split streams.  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l
-// of the part's fp32 tile (2T + (j>>2), nb); hi = f16(w) (round to nearest), lo = f16(w - hi).
+// One thread per LANE of a pair (round 4; it was one thread per f16: the part search below ran sixteen times as often and the
+// kernel took 30 us per model and step).  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l of the part's
+// fp32 tile (2T + (j>>2), nb); hi = f16(w) (round to nearest), lo = f16(w - hi): the thread reads two float4 and writes the 8 hi
+// halves (16 B at pair * 2048 + 16 l) and the 8 lo halves (1 KiB further).
 __global__ void split_pack_kernel(float* packed, PartTable T) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr long long FWD_HALVES = (long long)SPLIT_FWD_PAIRS * (PAIR_BYTES / 2);
-    constexpr long long BWD_HALVES = (long long)SPLIT_BWD_PAIRS * (PAIR_BYTES / 2);
-    constexpr long long HBWD_HALVES = (long long)SPLIT_HBWD_PAIRS * (PAIR_BYTES / 2);
-    if (q >= FWD_HALVES + BWD_HALVES + HBWD_HALVES) return;
-    const int region = q >= FWD_HALVES + BWD_HALVES ? 2 : (q >= FWD_HALVES ? 1 : 0);     // forward, trunk^T, heads^T
+    constexpr long long FWD_LANES = (long long)SPLIT_FWD_PAIRS * 64;
+    constexpr long long BWD_LANES = (long long)SPLIT_BWD_PAIRS * 64;
+    constexpr long long HBWD_LANES = (long long)SPLIT_HBWD_PAIRS * 64;
+    if (q >= FWD_LANES + BWD_LANES + HBWD_LANES) return;
+    const int region = q >= FWD_LANES + BWD_LANES ? 2 : (q >= FWD_LANES ? 1 : 0);     // forward, trunk^T, heads^T
     const bool bwd = region != 0;
-    const long long r = q - (region == 2 ? FWD_HALVES + BWD_HALVES : (region == 1 ? FWD_HALVES : 0));
-    const int pair = (int)(r / (PAIR_BYTES / 2));
-    const int within = (int)(r % (PAIR_BYTES / 2));
-    const bool is_lo = within >= 512;
-    const int lane = (within & 511) >> 3, j = within & 7;
+    const long long r = q - (region == 2 ? FWD_LANES + BWD_LANES : (region == 1 ? FWD_LANES : 0));
+    const int pair = (int)(r >> 6);
+    const int lane = (int)(r & 63);
     // Segments of the forward stream: the nine trunk parts (L1, L2-4, L5 encoding, L5 hidden, L6-8) are stored in two
     // HALVES of 8 row blocks each (mnrf_field_split.inc: the kernel evaluates a trunk layer half by half), L5's two
     // parts interleaved by half; the head parts and the whole backward stream are stored part by part.
@@ -110,22 +110,35 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     const int lp = pair - pair0;
     const int rows = half >= 0 ? 8 : pt.nb;
     const int Tq = lp / rows, nb = (half >= 0 ? 8 * half : 0) + lp % rows;
-    float w = 0.f;
-    if (2 * Tq + (j >> 2) < pt.ntq) {      // (an odd ntq leaves the upper half of its last step zero)
-        const long long tile = pt.tile0 + (long long)(2 * Tq + (j >> 2)) * pt.nb + nb;
-        w = packed[(region == 2 ? OFF_HBWD : (region == 1 ? OFF_BWD : OFF_FWD)) + tile * TILE_FLOATS + lane * 4 + (j & 3)];
+    const float* src = packed + (region == 2 ? OFF_HBWD : (region == 1 ? OFF_BWD : OFF_FWD));
+    float w[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (2 * Tq + h < pt.ntq)       // (an odd ntq leaves the upper half of its last step zero)
+            v = *(const f32x4*)(src + (pt.tile0 + (long long)(2 * Tq + h) * pt.nb + nb) * TILE_FLOATS + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[4 * h + c] = v[c];
     }
-    const _Float16 hi = (_Float16)w;
-    const _Float16 lo = (_Float16)(w - (float)hi);
-    if (!(fabsf(w) < 65504.f)) atomicOr((unsigned*)(packed + PACKED_FLOATS - 1), MNRF_GUARD_WEIGHT);   // inf / nan / out of range
-    _Float16* dst = (_Float16*)(packed + (region == 2 ? OFF_SPLIT_HBWD : (region == 1 ? OFF_SPLIT_BWD : OFF_SPLIT_FWD)));
-    dst[r] = is_lo ? lo : hi;
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    h8v hi, lo;
+    bool bad = false;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        hi[jj] = (_Float16)w[jj];
+        lo[jj] = (_Float16)(w[jj] - (float)hi[jj]);
+        bad |= !(fabsf(w[jj]) < 65504.f);      // inf / nan / out of range
+    }
+    if (bad) atomicOr((unsigned*)(packed + PACKED_FLOATS - 1), MNRF_GUARD_WEIGHT);
+    char* dst = (char*)(packed + (region == 2 ? OFF_SPLIT_HBWD : (region == 1 ? OFF_SPLIT_BWD : OFF_SPLIT_FWD))) + (long long)pair * PAIR_BYTES + lane * 16;
+    *(h8v*)dst = hi;
+    *(h8v*)(dst + PAIR_BYTES / 2) = lo;
 }
 
 void launch_split_pack(float* packed, hipStream_t s) {
     PartTable T;
     build_parts(T);
-    const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS + SPLIT_HBWD_PAIRS) * (PAIR_BYTES / 2);
+    const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS + SPLIT_HBWD_PAIRS) * 64;
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, packed, T);
 }
 
