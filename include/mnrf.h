@@ -340,6 +340,17 @@ int mnrf_dw_planes2(int n_eval, const void* const* x_planes, const void* const* 
                     const uint32_t* const* seedmax, const int* kinds, float* workspace, float* const* d_params, int accumulate,
                     void* stream);
 
+/* ---- optimizer step (training.FlatAdam) ------------------------------------------------------------------------------------
+ * Adam over ONE flat tensor of n floats (16-byte aligned; a field model's 595 k parameters as views of one buffer, its gradient
+ * the flat buffer the backward pass produced): torch.optim.Adam's update (non-amsgrad, L2 weight decay; utils/__init__.py
+ * get_optimizer builds that optimizer, train.py:101-109) with one thread per four elements -- torch's fused multi-tensor kernel
+ * gives such a tensor ten thread blocks.  `step` = the caller's count of calls (this one included), `*skipped` (device, the
+ * caller zeroes it once) = how many of them found_inf has voided: with *found_inf != 0 nothing is updated and *skipped grows by
+ * one, as torch's fused Adam does under GradScaler; grad_scale / found_inf may be null. */
+int mnrf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int64_t step, int32_t* skipped, const float* grad_scale,
+                   const float* found_inf, void* stream);
+
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);
  * log2_per_level_scale, base_resolution, bound: the encoding configuration (mirror_nerf_tcnn.py:36-49);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mnrf_dw_planes2": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p),
                                _int, _str]),
+    "mnrf_adam_step": (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _flt, ctypes.c_double, ctypes.c_double, _flt, _flt, _i64, _c_i, _c_f, _c_f, _str]),
     "mnrf_bench_stream": (_int, [ctypes.c_void_p, _i64, _int, _int, _str]),
     "mnrf_bench_stream2": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, _i64, _i64, _int, _int, _int, _int, _str]),
     "mnrf_bench_gather": (_int, [ctypes.c_void_p, _i64, _int, _i64, _int, _c_f, _str]),

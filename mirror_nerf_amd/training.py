@@ -152,13 +152,15 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
 
 
 class FlatAdam:
-    """Opt-in optimizer for field models (MirrorNeRF with all 32 parameters at their full shapes): torch's fused Adam over ONE
-    flat parameter tensor per model instead of 32 -- the parameters become views of it, and its `.grad` IS the flat gradient
-    buffer the backward pass already produced (autograd._Pending: the `.grad`s of the parameters are views of one buffer), so a
-    step is one multi-tensor launch over 2 tensors instead of 64 (93 -> ~15 us) and nothing is gathered or copied.  Same
-    arithmetic, same `found_inf` contract (train_step's range guard).  Build it AFTER moving the models to their device."""
+    """Opt-in optimizer for field models (MirrorNeRF with all 32 parameters at their full shapes): Adam over ONE flat parameter
+    tensor per model instead of 32 -- the parameters become views of it, and its gradient IS the flat buffer the backward pass
+    already produced (autograd._Pending: the `.grad`s of the parameters are views of one buffer), so nothing is gathered or
+    copied.  The update is torch.optim.Adam's (same arithmetic, same `found_inf` contract: train_step's range guard) from
+    `mnrf_adam_step`, one thread per four elements: torch's fused multi-tensor kernel deals 65 536-element chunks to blocks, TEN
+    blocks for a model, 46 us per model and step against 6 (round 4).  `kernel=False` (or MNRF_FLAT_ADAM_KERNEL=0) keeps torch's
+    fused Adam over the flat tensors.  Build it AFTER moving the models to their device."""
 
-    def __init__(self, modules, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, modules, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, kernel=None):
         from .weights import param_refs
         self.modules, self.flats = list(modules), []
         for m in self.modules:
@@ -174,13 +176,28 @@ class FlatAdam:
                 flat[o:o + k].copy_(q.data.reshape(-1))
                 q.data = flat[o:o + k].view(q.shape)
             self.flats.append(torch.nn.Parameter(flat))
+        self.kernel = (os.environ.get("MNRF_FLAT_ADAM_KERNEL", "1") != "0") if kernel is None else bool(kernel)
         self.inner = torch.optim.Adam(self.flats, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
         self.defaults = dict(self.inner.defaults)
-        self.param_groups = self.inner.param_groups
+        self.param_groups = self.inner.param_groups      # (lr / betas / eps / weight_decay are read from here at every step)
+        if self.kernel:
+            self._m = [torch.zeros_like(fp.data) for fp in self.flats]
+            self._v = [torch.zeros_like(fp.data) for fp in self.flats]
+            self._skipped = [torch.zeros(1, dtype=torch.int32, device=fp.device) for fp in self.flats]
+            self._calls = 0
+            self._gs = self._fi = None
 
     # train_step hands the guard flag over as GradScaler does
-    grad_scale = property(lambda self: getattr(self.inner, "grad_scale", None), lambda self, v: setattr(self.inner, "grad_scale", v))
-    found_inf = property(lambda self: getattr(self.inner, "found_inf", None), lambda self, v: setattr(self.inner, "found_inf", v))
+    def _get(self, name):
+        return getattr(self, "_gs" if name == "grad_scale" else "_fi") if self.kernel else getattr(self.inner, name, None)
+
+    def _set(self, name, v):
+        if self.kernel:
+            setattr(self, "_gs" if name == "grad_scale" else "_fi", v)
+        else:
+            setattr(self.inner, name, v)
+    grad_scale = property(lambda self: self._get("grad_scale"), lambda self, v: self._set("grad_scale", v))
+    found_inf = property(lambda self: self._get("found_inf"), lambda self, v: self._set("found_inf", v))
 
     def zero_grad(self, set_to_none=True):
         from .weights import params_of
@@ -190,18 +207,45 @@ class FlatAdam:
                 q.grad = None
 
     def step(self):
+        grads = []
         for m, fp in zip(self.modules, self.flats):
             flat = D._flat_bucket(m)                 # the backward pass's buffer when every .grad still is a view of it ...
             if flat is None:
                 flat, _copied = D._module_message(m)   # ... else a flat copy in the same layout (zeros where there is no gradient)
             fp.grad = flat
-        self.inner.step()
+            grads.append(flat)
+        if not self.kernel:
+            self.inner.step()
+            return
+        from . import _lib
+        from .weights import bump_generation
+        L, p = _lib.lib(), _lib.ptr
+        self._calls += 1
+        f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1)  # noqa: E731
+        gs, fi = f32(self._gs), f32(self._fi)
+        for i, (fp, g) in enumerate(zip(self.flats, grads)):
+            grp = self.param_groups[0]
+            _lib.check(L.mnrf_adam_step(p(fp.data), p(g.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(), float(grp["lr"]),
+                                        float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
+                                        self._calls, p(self._skipped[i]), p(gs), p(fi), _lib.stream()), "mnrf_adam_step")
+        self._gs = self._fi = None                   # (GradScaler semantics: the flags belong to one step)
+        bump_generation()                            # the packed weight images are stale now (torch optimizers do this through a hook)
 
     def state_dict(self):
-        return self.inner.state_dict()
+        if not self.kernel:
+            return self.inner.state_dict()
+        return {"kernel": True, "calls": self._calls, "exp_avg": [t.clone() for t in self._m], "exp_avg_sq": [t.clone() for t in self._v],
+                "skipped": [t.clone() for t in self._skipped], "param_groups": [{k: v for k, v in g.items() if k != "params"}
+                                                                                for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self.inner.load_state_dict(sd)
+        if not self.kernel:
+            return self.inner.load_state_dict(sd)
+        self._calls = int(sd["calls"])
+        for dst, src in zip(self._m + self._v + self._skipped, sd["exp_avg"] + sd["exp_avg_sq"] + sd["skipped"]):
+            dst.copy_(src)
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
 
 
 def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0, loss_name="color_mask", **hp_over):
@@ -281,7 +325,8 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
             "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
             "samples_per_ray": spr, "N_samples": hp.N_samples, "N_importance": hp.N_importance, "steps": steps,
-            "optimizer": "training.FlatAdam (torch's fused Adam over one flat parameter tensor per model)" if flat_adam else "torch.optim.Adam(fused=True)",
+            "optimizer": ("training.FlatAdam (Adam over one flat parameter tensor per model, " +
+                          ("mnrf_adam_step" if getattr(opt, "kernel", False) else "torch's fused kernel") + ")") if flat_adam else "torch.optim.Adam(fused=True)",
             "loss": float(loss.item()),
             "loss_fn": "losses.TotalLoss (colour, mask, normal, normal_reg; fused HIP kernels; second-order pass on)" if loss_name == "total"
                        else "ColorLoss + MirrorMaskLoss of the reference (both typs; fused loss kernel since round 4; no normal_* key read: the second-order pass is skipped)"}

@@ -679,10 +679,51 @@ def test_folded_gradient_accumulation_with_other_consumers_of_the_parameters():
         assert _rel(q.grad, 2 * b) <= 2e-6
 
 
-def test_flat_adam_takes_the_same_steps_as_torch_adam():
+def test_adam_kernel_against_torch_fused_adam():
+    """mnrf_adam_step on one flat tensor against torch.optim.Adam(fused=True): gradients over 30 orders of magnitude (and exact
+    zeros), five steps, weight decay on; then a step with found_inf set changes nothing and does not count."""
+    from mirror_nerf_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    torch.manual_seed(0)
+    n = 595_333                                  # not a multiple of four: the ragged tail
+    p0 = torch.randn(n, device=DEV) * 0.1
+    a = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([a], lr=5e-4, weight_decay=1e-3, fused=True)
+    b = torch.empty(n + 4, device=DEV)[:n]       # (16-byte aligned base, as the flat parameter tensors are)
+    b.copy_(p0)
+    m, v = torch.zeros_like(b), torch.zeros_like(b)
+    skipped = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in range(1, 6):
+        g = torch.randn(n, device=DEV) * 10.0 ** (torch.rand(n, device=DEV) * 30 - 28)
+        g[::7] = 0.0
+        a.grad = g.clone()
+        opt.step()
+        _lib.check(L.mnrf_adam_step(p(b), p(g), p(m), p(v), n, 5e-4, 0.9, 0.999, 1e-8, 1e-3, step, p(skipped), None, None,
+                                    _lib.stream()), "mnrf_adam_step")
+        assert float((a.detach() - b).abs().max()) <= 2e-7, step        # (one ulp of 0.4 per step at most)
+    before = (b.clone(), m.clone(), v.clone())
+    found = torch.ones((), device=DEV)
+    _lib.check(L.mnrf_adam_step(p(b), p(g), p(m), p(v), n, 5e-4, 0.9, 0.999, 1e-8, 1e-3, 6, p(skipped), None, p(found), _lib.stream()), "skip")
+    assert torch.equal(b, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2]) and int(skipped.item()) == 1
+    # the next real call is the SIXTH step of torch's optimizer although it is the seventh call here
+    a.grad = g.clone()
+    opt.step()
+    _lib.check(L.mnrf_adam_step(p(b), p(g), p(m), p(v), n, 5e-4, 0.9, 0.999, 1e-8, 1e-3, 7, p(skipped), None,
+                                p(torch.zeros((), device=DEV)), _lib.stream()), "after skip")
+    assert float((a.detach() - b).abs().max()) <= 2e-7
+
+
+@pytest.mark.parametrize("kernel", [False, True])
+def test_flat_adam_takes_the_same_steps_as_torch_adam(kernel):
     """training.FlatAdam (one flat parameter tensor per model, its .grad = the backward pass's flat gradient buffer) against
-    torch.optim.Adam(fused=True) over the 64 tensors: three training steps from the same initial weights on the same batches give
-    the same parameters (same arithmetic; the weight-gradient sums are order-dependent in the last bits)."""
+    torch.optim.Adam(fused=True) over the 64 tensors: three training steps from the same initial weights on the same batches.
+    kernel=False (torch's fused kernel over the flat tensors): the same parameters (same arithmetic; the weight-gradient sums are
+    order-dependent in the last bits).  kernel=True (mnrf_adam_step, the default): the update agrees to one ulp per step (test
+    above) -- and these three steps amplify one ulp enormously: with torch's OWN Adam on both sides, initial weights that differ
+    by one ulp end 8e-4 apart in the worst entry and 1.7e-4 on average in the worst tensor (scripts/check_adam_sensitivity.py:
+    an ulp moves a sample across a bin of the fine pass or a ray across the mirror threshold, and Adam's normalised step passes
+    the change of a near-zero gradient on at full size, lr = 5e-4).  The kernel stays inside that: measured 5.6e-4 / 7e-5.
+    """
     from mirror_nerf_amd import training
     import mirror_nerf_amd as M
     from mirror_nerf_amd import synthetic as SY
@@ -695,7 +736,8 @@ def test_flat_adam_takes_the_same_steps_as_torch_adam():
             for m in system.models.values():
                 m.sigma.weight.mul_(20.0)
                 m.sigma.bias.fill_(1.0)
-        opt = training.FlatAdam(list(system.models.values()), lr=5e-4) if flat else torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
+        opt = training.FlatAdam(list(system.models.values()), lr=5e-4, kernel=kernel) if flat else \
+            torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
         g = torch.Generator(device=DEV)
         g.manual_seed(7)
         losses = []
@@ -711,7 +753,10 @@ def test_flat_adam_takes_the_same_steps_as_torch_adam():
     assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(la, lb)), (la, lb)
     assert la[2] != la[0]                                           # the weights moved (the packed images were refreshed)
     for k in pb:
-        assert float((pa[k] - pb[k]).abs().max()) <= 2e-5 * float(pb[k].abs().max()) + 1e-7, k
+        if kernel:
+            assert float((pa[k] - pb[k]).abs().max()) <= 3 * 5e-4 and float((pa[k] - pb[k]).abs().mean()) <= 2e-4, k
+        else:
+            assert float((pa[k] - pb[k]).abs().max()) <= 2e-5 * float(pb[k].abs().max()) + 1e-7, k
     # the parameters still are what state_dict / checkpoints see, and are views of the flat tensors
     sd = sa.nerf_fine.state_dict()
     assert torch.equal(sd["sigma.weight"], sa.nerf_fine.sigma.weight.detach())
