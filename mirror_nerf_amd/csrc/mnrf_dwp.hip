@@ -433,43 +433,65 @@ __device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax, int kind)
     return K + PL_BOOST_LOG2;
 }
 
+// One thread per FOUR rows of one column of a Linear (round 4; it was one thread per element): rows 4 q .. 4 q + 3 of a column
+// are one float4 of the partial tile's fragment order, and consecutive columns are consecutive float4 -- the reads of the
+// partial tiles (20 per element for the large jobs) are coalesced 16-byte loads instead of 4-byte loads at a 16-byte stride.
+// After the weights of a layer come its bias sums, one thread each.
 __global__ void dwp_finish_kernel(DwpFinishArgs F) {
     const DwpLayer& ly = F.layer[blockIdx.y];
-    const int nw = ly.out_f * ly.in_f;
+    const int n4 = (ly.out_f + 3) / 4;
+    const int nw4 = n4 * ly.in_f;
     const int el = blockIdx.x * blockDim.x + threadIdx.x;
-    if (el >= nw + ly.out_f) return;
-    int job, row, col;
-    bool is_bias = el >= nw;
+    if (el >= nw4 + ly.out_f) return;
+    const bool is_bias = el >= nw4;
+    int job, row, col, n0 = 0, c = 0;
     if (!is_bias) {
-        const int n = el / ly.in_f, c = el % ly.in_f;
+        n0 = 4 * (el / ly.in_f);
+        c = el % ly.in_f;
         const bool first = c < ly.split_col;
         const DwpSource s = first ? ly.src[0] : ly.src[1];
         job = s.job;
-        row = s.row0 + n;
+        row = s.row0 + n0;
         int cc = first ? c : c - ly.split_col;
         if (s.kind == 1) cc = F.encpos[cc];
         col = s.col0 + cc;
     } else {
         job = ly.bias_job;
-        row = ly.bias_row0 + (el - nw);
+        row = ly.bias_row0 + (el - nw4);
         col = 0;
     }
     if (job < 0) return;
     const DwpJob jb = dwp_job(job);
-    // position inside a partial slot (fragment order of dwp_segment_run)
+    // position inside a partial slot (fragment order of dwp_segment_run): float4 = rows 4 (row >> 2) .. + 3 of column col
     long long idx;
-    if (!is_bias) idx = ((long long)((row >> 4) * jb.nx + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4 + (row & 3);
+    if (!is_bias) idx = ((long long)((row >> 4) * jb.nx + (col >> 4)) * 64 + ((row & 15) >> 2) * 16 + (col & 15)) * 4;
     else idx = 256 * 256 + row;
-    float total = 0.f;
+    f32x4 total = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int e = 0; e < F.n_eval; ++e) {
         const int v = job * F.n_eval + e;
         if (is_bias && F.kind[e]) continue;      // the second-order term has no bias gradient (its jobs write no bias sums)
-        float sum = 0.f;
-        for (int g = F.g_lo[v]; g <= F.g_hi[v]; ++g) sum += F.part[(long long)(g + v) * DWP_SLOT_FLOATS + idx];
-        if (F.g_lo[v] <= F.g_hi[v]) total += ldexpf(sum, -dwp_scale_log2(F.seedmax[e], F.kind[e]));      // (ldexp: K can exceed 126)
+        if (F.g_lo[v] > F.g_hi[v]) continue;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = F.g_lo[v]; g <= F.g_hi[v]; ++g) {
+            const float* src = F.part + (long long)(g + v) * DWP_SLOT_FLOATS + idx;
+            if (is_bias) sum[0] += *src;
+            else sum += *(const f32x4*)src;
+        }
+        const int k = -dwp_scale_log2(F.seedmax[e], F.kind[e]);      // (ldexp: K can exceed 126)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) total[r] += ldexpf(sum[r], k);
     }
-    float* dst = is_bias ? ly.d_b + (el - nw) : ly.d_w + el;
-    *dst = F.accumulate ? *dst + total : total;
+    if (is_bias) {
+        float* dst = ly.d_b + (el - nw4);
+        *dst = F.accumulate ? *dst + total[0] : total[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < ly.out_f) {
+                float* dst = ly.d_w + (long long)(n0 + r) * ly.in_f + c;
+                *dst = F.accumulate ? *dst + total[r] : total[r];
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------- seed maximum
@@ -654,7 +676,7 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     layer(13, 3, 128, DwpSource{15, 0, 0, 0}, none, 128, 15, 0);                               // normal_net.1
     layer(14, 128, 256, DwpSource{10, 128, 0, 0}, none, 256, 10, 128);                         // is_mirror_net.0
     layer(15, 1, 128, DwpSource{16, 0, 0, 0}, none, 128, 16, 0);                               // is_mirror_net.2
-    hipLaunchKernelGGL(dwp_finish_kernel, dim3((256 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);
+    hipLaunchKernelGGL(dwp_finish_kernel, dim3((64 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);      // (out_f / 4) x in_f + out_f threads at most
     return 0;
 }
 
