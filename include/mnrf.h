@@ -362,6 +362,9 @@ int mnrf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * with per-ray raw directions `dirs` (null: the ray direction).  sigma is the RAW output h[0] (the ReLU is
  * applied at compositing, mirror_nerf_tcnn.py:235).  geo_feat: (B,15).  Parity vs tinycudann: unpinned. */
 int mnrf_tcnn_weight_floats(void);
+/* The blob from the model's 11 MLP parameter tensors (HOST array of device pointers in the order above: contiguous fp32 in
+ * nn.Linear layout, models/mirror_nerf_tcnn.py:51-149) in one launch; padded columns and the tail are written as zeros. */
+int mnrf_tcnn_pack_weights(const float* const* params, float* weights, void* stream);
 int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                       int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
                       const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mnrf_tcnn_encode": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,
                                 _c_f, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),
+    "mnrf_tcnn_pack_weights": (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
     "mnrf_tcnn_backward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _i64,

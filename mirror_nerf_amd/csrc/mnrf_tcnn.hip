@@ -1698,6 +1698,45 @@ static void level_modes(TcnnArgs& A) {
 
 extern "C" int mnrf_tcnn_weight_floats(void) { return W_TOTAL; }
 
+// ---- the weight blob from the 11 parameter tensors in ONE launch (round 4: the host side built it with ten pads, a cat and a
+// final pad -- 23 launches per model after every optimizer step, 8 % of config 5's training step)
+namespace {
+struct BlobSeg { const float* src; int rows, src_cols, dst_cols, dst_off; };
+struct BlobArgs { BlobSeg seg[11]; float* dst; };
+__global__ void tcnn_pack_kernel(BlobArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W_TOTAL) return;
+    float v = 0.f;      // padded columns and the tail stay zero
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const BlobSeg s = A.seg[k];
+        const int j = i - s.dst_off;
+        if (j >= 0 && j < s.rows * s.dst_cols) {
+            const int r = j / s.dst_cols, c = j - r * s.dst_cols;
+            if (c < s.src_cols) v = s.src[r * s.src_cols + c];
+        }
+    }
+    A.dst[i] = v;
+}
+}  // namespace
+
+extern "C" int mnrf_tcnn_pack_weights(const float* const* params, float* weights, void* stream) {
+    if (!params || !weights) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_pack_weights: null pointer");
+    // rows, source columns, blob columns, blob offset of [sigma_net.0.weight, sigma_net.1.weight, color_net.0/1/2.weight,
+    // normal_net.0/1.weight, is_mirror_net.0.weight, .0.bias, .2.weight, .2.bias] (models/mirror_nerf_tcnn.py:51-149)
+    static const int shape[11][4] = {{64, 32, 32, W_S0}, {16, 64, 64, W_S1}, {64, 31, 32, W_C0}, {64, 64, 64, W_C1}, {3, 64, 64, W_C2},
+                                     {64, 15, 16, W_N0}, {3, 64, 64, W_N1}, {32, 15, 16, W_M0}, {1, 32, 32, B_M0}, {1, 32, 32, W_M1},
+                                     {1, 1, 1, B_M1}};
+    BlobArgs A;
+    for (int k = 0; k < 11; ++k) {
+        if (!params[k]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_pack_weights: null parameter pointer");
+        A.seg[k] = BlobSeg{params[k], shape[k][0], shape[k][1], shape[k][2], shape[k][3]};
+    }
+    A.dst = weights;
+    hipLaunchKernelGGL(tcnn_pack_kernel, dim3((W_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_tcnn_pack_weights");
+}
+
 extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                                  int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
                                  const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,

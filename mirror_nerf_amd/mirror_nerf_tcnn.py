@@ -224,14 +224,13 @@ class MirrorNeRFTcnn(nn.Module):
         from .weights import _GENERATION      # fused optimizers do not bump _version (weights.py)
         key = (_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in ps)
         if key != self._blob_key:
-            def pad(w, cols):
-                w = w.detach().float()
-                return torch.nn.functional.pad(w, (0, cols - w.shape[1])).reshape(-1)
-            parts = [pad(ps[0], 32), pad(ps[1], 64), pad(ps[2], 32), pad(ps[3], 64), pad(ps[4], 64), pad(ps[5], 16),
-                     pad(ps[6], 64), pad(ps[7], 16), ps[8].detach().float(), pad(ps[9], 32), ps[10].detach().float()]
-            blob = torch.cat(parts)
-            n = _lib.lib().mnrf_tcnn_weight_floats()
-            self._blob = torch.nn.functional.pad(blob, (0, n - blob.numel())).contiguous()
+            import ctypes
+            L = _lib.lib()
+            src = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
+            blob = torch.empty(L.mnrf_tcnn_weight_floats(), dtype=torch.float32, device=ps[0].device)
+            _lib.check(L.mnrf_tcnn_pack_weights((ctypes.c_void_p * 11)(*[t.data_ptr() for t in src]), _lib.ptr(blob), _lib.stream()),
+                       "mnrf_tcnn_pack_weights")      # (one launch; it was ten pads, a cat and a pad: 23)
+            self._blob = blob
             self._blob_key = key
         return self._blob
 

@@ -24,7 +24,7 @@ for m_ in models.values():
     m_.table_grad_f16 = a.f16_grads
 emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
 allrays = torch.from_numpy(O.synthetic_rays(800, 800)).to(dev)
-opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4)
+opt = torch.optim.Adam([p for m in models.values() for p in m.parameters()], lr=5e-4, fused=os.environ.get("MNRF_ADAM_FUSED", "1") == "1")
 target = torch.rand(a.rays, 3, device=dev)
 
 
