@@ -711,13 +711,13 @@ def main():
     train = None
     if not a.no_train:
         from mirror_nerf_amd import training
-        train = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024)
-        train_total = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, loss_name="total")
+        train = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024)
+        train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total")
         train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline")
                                     if k in train_total}
         # BASELINE config 3 as worded ("same config" as config 2: 64 coarse + 128 importance samples); the default above is
         # run.sh:266's training schedule (--N_importance 64)
-        train_c3 = training.synthetic_train_bench(dev, rays, steps=10, warmup=3, batch=1024, N_importance=128)
+        train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
         train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
                                                                   "reflected_rays_per_step", "allreduce")}
 
