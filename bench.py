@@ -269,10 +269,10 @@ def hash_grid_leg(dev, rays):
     if collective:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(20):
         step()
     torch.cuda.synchronize()
-    dt_t_own = (time.perf_counter() - t0) / 10
+    dt_t_own = (time.perf_counter() - t0) / 20
     dt_t = D.max_over_ranks(dt_t_own, dev)
     entries = int(models["fine"].encoder.embeddings.shape[0])
     D.detach_overlap(list(models.values()))
