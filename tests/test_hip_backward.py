@@ -713,6 +713,40 @@ def test_adam_kernel_against_torch_fused_adam():
     assert float((a.detach() - b).abs().max()) <= 2e-7
 
 
+def test_flat_adam_state_dict_round_trip():
+    """FlatAdam (mnrf_adam_step) interrupted after two steps -- state_dict() into a NEW FlatAdam over the same modules -- takes
+    the same third step as an uninterrupted run: moments, step count and skip count travel (checkpoint / resume)."""
+    from mirror_nerf_amd import training
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import synthetic as SY
+    rays_all = SY.device_rays(32, 32, DEV)
+
+    def run(interrupt):
+        torch.manual_seed(0)
+        system = M.NeRFSystem(training.default_hparams(perturb=0.0, noise_std=0.0)).to(DEV)
+        with torch.no_grad():
+            for m in system.models.values():
+                m.sigma.weight.mul_(20.0)
+                m.sigma.bias.fill_(1.0)
+        opt = training.FlatAdam(list(system.models.values()), lr=5e-4, kernel=True)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(7)
+        for it in range(3):
+            if interrupt and it == 2:
+                sd = opt.state_dict()
+                opt = training.FlatAdam(list(system.models.values()), lr=1e-3, kernel=True)      # (another lr: the saved groups win)
+                opt.load_state_dict(sd)
+            idx = torch.randint(0, rays_all.shape[0], (256,), device=DEV, generator=g)
+            target = torch.rand(256, 3, device=DEV, generator=g)
+            gt = (torch.rand(256, device=DEV, generator=g) < 0.25).float()
+            training.train_step(system, opt, rays_all[idx].contiguous(), target, gt)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in system.named_parameters()}
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("kernel", [False, True])
 def test_flat_adam_takes_the_same_steps_as_torch_adam(kernel):
     """training.FlatAdam (one flat parameter tensor per model, its .grad = the backward pass's flat gradient buffer) against
