@@ -34,7 +34,8 @@ __global__ void adam_kernel(AdamArgs A) {
     }
     __shared__ float bc[2];
     if (threadIdx.x == 0) {
-        const double t = (double)(A.step - (long long)*A.skipped);
+        const long long eff = A.step - (long long)*A.skipped;      // >= 1 when the caller counts as documented
+        const double t = (double)(eff < 1 ? 1 : eff);
         bc[0] = (float)(1.0 - pow(A.beta1, t));
         bc[1] = (float)sqrt(1.0 - pow(A.beta2, t));
     }
