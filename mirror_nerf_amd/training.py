@@ -80,12 +80,15 @@ def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
 #   "skip"  (default) the optimizer update of the tripping step is SKIPPED ON THE DEVICE -- torch's fused Adam takes the guard
 #           flag as its `found_inf` (the GradScaler mechanism), all-reduced (MAX) over the ranks first, so every rank skips the
 #           same step -- with no host read: nothing computed from saturated operands ever reaches the weights, the queue is
-#           not drained, and one batch is lost.  The host learns it one step later and pins the models to the fp32 kernels.
+#           not drained, and one batch is lost.  The host learns it during the next step and pins the models to the fp32 kernels.
 #   "sync"  (MNRF_GUARD_SYNC=1 / MNRF_GUARD_MODE=sync; also the fall-back for optimizers without `found_inf`) the flag is
 #           read before the optimizer step (a queue drain, ~0.7 ms): a tripped step is recomputed on the fp32 kernels.
 #   "async" (MNRF_GUARD_MODE=async, the round-2/3 behaviour) the tripping step's update IS applied; a warning follows one
 #           step late.
 GUARD_MODE = os.environ.get("MNRF_GUARD_MODE") or ("sync" if os.environ.get("MNRF_GUARD_SYNC", "0") == "1" else "skip")
+
+
+_SETTLE_LATE = os.environ.get("MNRF_GUARD_SETTLE_LATE", "1") != "0"      # 0: read the previous step's flags at the start of a step (A/B)
 
 
 def _takes_found_inf(optimizer):
@@ -100,7 +103,8 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     collective = world > 1 or D.forced()
     mode = GUARD_MODE if (GUARD_MODE != "skip" or _takes_found_inf(optimizer)) else "sync"
     token = system.__dict__.pop("_mnrf_guard_token", None)
-    if token is not None:       # the previous step's flags (their copy finished long ago: no queue drain)
+
+    def settle(token):          # the previous step's flags
         tripped_here = guard_async_end(token[0])
         tripped_any = tripped_here if token[1] is None else bool(token[1].item())
         if tripped_any and token[1] is not None:
@@ -111,10 +115,22 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
             warnings.warn("mirror_nerf_amd: the previous training step left the range of the split-f16 arithmetic; "
                           + ("its optimizer update was skipped on every rank" if token[2] == "skip" else
                              "its update HAS BEEN APPLIED (MNRF_GUARD_MODE=async)")
-                          + "; the models run on the fp32 kernels from now on", RuntimeWarning, stacklevel=2)
+                          + "; the models run on the fp32 kernels from now on", RuntimeWarning, stacklevel=3)
+    # Reading them HERE would wait for the device to finish the previous step's backward pass (their event sits behind it) and
+    # the host could not queue this step's primary pass ahead of time: the device then idles ~0.1 ms at every step start while
+    # the first launches arrive.  On one rank the flags are settled after this step's forward has been queued -- the host waits
+    # there anyway (the reflected-ray count) -- unless they have arrived already; with more than one rank they are settled
+    # now (the pinning decision must reach every rank before any of them issues this step's collectives).
+    late = _SETTLE_LATE and token is not None and token[0] is not None and not collective and mode == "skip" and not token[0][2].query()
+    if token is not None and not late:
+        settle(token)
 
     def fwd_bwd():
+        nonlocal late
         res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
+        if late:                # (a trip pins the models for the NEXT forward; this step's own flags gate its own update)
+            settle(token)
+            late = False
         loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
