@@ -82,6 +82,10 @@ extern "C" {
  * mnrf_packed_floats() - 1) is a sticky device flag: mnrf_pack_weights clears it, every MNRF_SPLIT_F16 kernel ORs in */
 #define MNRF_GUARD_SATURATED 1u    /* an operand of a Linear reached the f16 maximum: hi/lo pairs no longer carry fp32 */
 #define MNRF_GUARD_WEIGHT 2u       /* a weight is non-finite or >= 65504 in magnitude (set by mnrf_pack_weights) */
+#define MNRF_GUARD_IN_FORWARD 128u       /* with SATURATED, which pass: ... an activation of a forward evaluation */
+#define MNRF_GUARD_IN_BACKWARD 256u      /* ... a scaled activation gradient of the training backward (mnrf_field_backward_planes: the
+                                            caller may lower the gradient scale instead of leaving the split arithmetic, see its flags) */
+#define MNRF_GUARD_IN_SECOND_ORDER 512u  /* ... a scaled tangent or signal of the second-order pass (mnrf_field_backward2*) */
 #define MNRF_GUARD_ENC_RANGE 4u    /* a position with |x| >= 16: sin/cos arguments beyond 2^13, outside the fast exact reduction */
 /* The fp32 kernels never touch it.  Host policy (mirror_nerf_amd.mirror_nerf.check_guard): read it once per frame /
  * training step; non-zero -> the module is switched to the exact fp32 kernels and the work is repeated. */
@@ -313,7 +317,11 @@ int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz,
                                const float* g_is_mirror, const float* rgb, const float* pred_normal,
                                const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
                                void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir, const float* keep_mirror,
-                               unsigned flags /* MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD */, void* stream);
+                               unsigned flags /* MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD | r << 16 with r = 0..15: every sample's
+                                                 largest seed is scaled to [2^(6-r), 2^(7-r)) instead of [2^6, 2^7) -- 2^r more room
+                                                 for gradients that GROW on their way down the trunk (trained weights), r bits
+                                                 less for those that shrink; the same r goes to mnrf_dw_planes2 in kinds[e] */,
+                               void* stream);
 
 /* Weight gradients of n_eval (1..8) evaluations of one module: x_planes[e] from mnrf_field_forward_train, dy_planes[e] and
  * seedmax[e] from mnrf_field_backward_planes, B[e] their sample counts (HOST arrays).  d_params: HOST array of MNRF_N_PARAMS
@@ -326,7 +334,8 @@ int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* d
  * only and leaves the tangents a' (x2_planes, mnrf_train_planes2_bytes(B)) and the density-gradient signals b (y2_planes,
  * mnrf_train_dy_planes2_bytes(B)) as operand planes under one power-of-two scale for the call, derived from the largest |J^|
  * whose float bits are left in *jmax (a device word, overwritten); ADDS to d_xyz when non-null.  mnrf_dw_planes2 is
- * mnrf_dw_planes with a KIND per evaluation (HOST array, null = all 0): 0 = (x_planes, dy_planes, seedmax) of the first-order
+ * mnrf_dw_planes with a KIND per evaluation (HOST array, null = all 0; bits 8-11: the r of that evaluation's
+ * mnrf_field_backward_planes call): 0 = (x_planes, dy_planes, seedmax) of the first-order
  * calls above, 1 = (x2_planes, y2_planes, jmax) of this one -- the weight gradients of a module over all evaluations and both
  * orders in ONE launch (the reference: one loss.backward() through utils/func.py:10-25 with create_graph=True). */
 int64_t mnrf_train_planes2_bytes(int64_t B);

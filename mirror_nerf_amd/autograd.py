@@ -208,13 +208,14 @@ class FieldFn(torch.autograd.Function):
         p = _lib.ptr
         xs = xyz.shape[1] if xyz is not None else 3
         if B and ctx.planes:
+            red = int(mod.__dict__.get("_mnrf_seed_reduction", 0))      # mirror_nerf._lower_gradient_scale
             dy = torch.empty(max(16, L.mnrf_train_dy_planes_bytes(B)), dtype=torch.uint8, device=dev)
             seed = torch.empty(1, dtype=torch.int32, device=dev)
             _lib.check(L.mnrf_field_backward_planes(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
-                p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut,
+                p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut | (red << 16),
                 _lib.stream()), "mnrf_field_backward_planes")
-            st.tape.append((save_x, dy, B, seed, 0))
+            st.tape.append((save_x, dy, B, seed, red << 8))      # (kind 0 | the gradient-scale reduction of this launch)
         elif B:
             ws = f(max(1, L.mnrf_train_workspace_floats(B)))
             _lib.check(L.mnrf_field_backward(

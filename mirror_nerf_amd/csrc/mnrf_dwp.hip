@@ -418,6 +418,7 @@ struct DwpFinishArgs {
     const float* part;
     const unsigned* seedmax[DWP_MAX_EVAL];
     int kind[DWP_MAX_EVAL];
+    int seed_log2[DWP_MAX_EVAL];      // kind 0: FieldBwdArgs::seed_log2 of the evaluation's backward launch
     short g_lo[DWP_JOBS * DWP_MAX_EVAL], g_hi[DWP_JOBS * DWP_MAX_EVAL];     // owners of virtual job v (g_lo > g_hi: none)
     int n_eval;
     int accumulate;
@@ -426,10 +427,10 @@ struct DwpFinishArgs {
 
 // scale exponent of an evaluation's dY planes: K puts the largest seed magnitude into [2^6, 2^7) (the backward kernel uses
 // the same K) plus the boost of mnrf_dwp.h
-__device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax, int kind) {
+__device__ __forceinline__ int dwp_scale_log2(const unsigned* seedmax, int kind, int seed_log2) {
     const int e = (int)((*seedmax >> 23) & 0xffu);
     // kind 1: *seedmax holds the largest |J^| of the launch and K2 puts it into [1, 2) (field_split_bwd2_kernel uses the same K2)
-    const int K = (e == 0 || e == 255) ? 0 : (kind ? 0 : 6) - (e - 127);
+    const int K = (e == 0 || e == 255) ? 0 : (kind ? 0 : seed_log2) - (e - 127);
     return K + PL_BOOST_LOG2;
 }
 
@@ -477,7 +478,7 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
             if (is_bias) sum[0] += *src;
             else sum += *(const f32x4*)src;
         }
-        const int k = -dwp_scale_log2(F.seedmax[e], F.kind[e]);      // (ldexp: K can exceed 126)
+        const int k = -dwp_scale_log2(F.seedmax[e], F.kind[e], F.seed_log2[e]);      // (ldexp: K can exceed 126)
 #pragma unroll
         for (int r = 0; r < 4; ++r) total[r] += ldexpf(sum[r], k);
     }
@@ -589,7 +590,7 @@ static DwpPlan dwp_make_plan(int n_eval, const int64_t* B, const int* kinds) {
     DwpPlan p;
     p.n_eval = n_eval;
     for (int e = 0; e < DWP_MAX_EVAL; ++e) { p.n_sb[e] = 0; p.kind[e] = 0; }
-    for (int e = 0; e < n_eval; ++e) { p.n_sb[e] = (int)(dwp_tiles128(B[e]) * 4); p.kind[e] = kinds && kinds[e] ? 1 : 0; }
+    for (int e = 0; e < n_eval; ++e) { p.n_sb[e] = (int)(dwp_tiles128(B[e]) * 4); p.kind[e] = kinds && (kinds[e] & 0xff) ? 1 : 0; }
     p.T = dwp_total(p);
     p.G = dwp_pick_G(p.T, dwp_cus());
     return p;
@@ -624,7 +625,11 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     F.part = ws;
     F.n_eval = n_eval;
     F.accumulate = accumulate;
-    for (int e = 0; e < DWP_MAX_EVAL; ++e) { F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr; F.kind[e] = A.plan.kind[e]; }
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) {
+        F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr;
+        F.kind[e] = A.plan.kind[e];
+        F.seed_log2[e] = 6 - ((e < n_eval && kinds) ? (kinds[e] >> 8) & 0xf : 0);      // (bits 8-11 of a kind: mnrf.h)
+    }
     // owners of every virtual job, from the same arithmetic the kernel uses
     {
         long long P = 0;

@@ -261,7 +261,7 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
     float* ws = workspace + (int64_t)DY_FLOATS * B;
     FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
                        g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, dY, d_xyz, d_dir,
-                       flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror};
+                       flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, nullptr, nullptr, 6};
     hipStream_t s = (hipStream_t)stream;
     if (((flags & MNRF_SPLIT_F16) ? launch_split_bwd(A, s) : s2::launch_bwd(A, s)) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward: too many samples for one launch");
@@ -292,7 +292,8 @@ extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const 
     launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s);
     FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
                    g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
-                   flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax};
+                   flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
+                   6 - (int)((flags >> 16) & 0xfu)};
     if (launch_split_bwd(A, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_backward_planes");

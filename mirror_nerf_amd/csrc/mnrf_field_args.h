@@ -72,6 +72,10 @@ struct FieldBwdArgs {
     // per launch, derived from the largest seed magnitude of the evaluation (*seedmax, float bits, filled by seed_max_kernel)
     char* dY_planes;            // [sample blocks][PLY_FB][hi | lo][1 KiB]
     const unsigned* seedmax;
+    // where the per-sample scale puts a sample's largest seed: [2^seed_log2, 2^(seed_log2 + 1)).  6 by default; a training loop
+    // lowers it when scaled gradients outgrow the f16 range (trained weights amplify them on the way down the trunk) -- the
+    // weight-gradient GEMM's finish kernel must be told the same number (mnrf_dw_planes2: kinds)
+    int seed_log2;
 };
 // second-order pass (gradient through the density-gradient normal)
 struct FieldBwd2Args {

@@ -66,7 +66,9 @@ def set_precision(mode):
 # MNRF_GUARD=0 disables the host side.
 GUARD = os.environ.get("MNRF_GUARD", "1") != "0"
 GUARD_NAMES = {1: "an activation reached the f16 maximum (65504)", 2: "a weight is non-finite or >= 65504",
-               4: "a sample position has |x| >= 16 (encoding argument >= 2^13)"}
+               4: "a sample position has |x| >= 16 (encoding argument >= 2^13)",
+               128: "in a forward evaluation", 256: "in the training backward: a scaled activation gradient",
+               512: "in the second-order pass: a scaled tangent or signal"}
 
 
 def precision_of(module):
@@ -144,9 +146,30 @@ def pin_fp32(modules):
             m.__dict__["_mnrf_precision"] = "fp32"
 
 
-def guard_async_end(token):
+GRAD_SCALE_STEP, GRAD_SCALE_MAX = 4, 8       # bits per adaptation / in total (mnrf_field_backward_planes takes r <= 15)
+
+
+def _lower_gradient_scale(m, w):
+    """A trip that was ONLY a scaled activation gradient of the training backward outgrowing the f16 range (trained weights
+    amplify gradients on their way down the trunk; the per-sample scale puts the largest seed at 2^6 and the planes hold up to
+    2^12): lower that scale by 2^4 for this module instead of giving up the split arithmetic -- the loss-scaling move, downwards.
+    Returns True when it did."""
+    if (w & 1) and (w & 256) and not (w & (2 | 4 | 128 | 512)):
+        r = m.__dict__.get("_mnrf_seed_reduction", 0)
+        if r + GRAD_SCALE_STEP <= GRAD_SCALE_MAX:
+            import warnings
+            m.__dict__["_mnrf_seed_reduction"] = r + GRAD_SCALE_STEP
+            warnings.warn(f"mirror_nerf_amd: scaled activation gradients outgrew the f16 range in the previous training step (its update "
+                          f"was skipped); this model's gradient scale is lowered by 2^{GRAD_SCALE_STEP} (now 2^-{r + GRAD_SCALE_STEP} of "
+                          "the default) and it stays on the split arithmetic", RuntimeWarning, stacklevel=4)
+            return True
+    return False
+
+
+def guard_async_end(token, adapt=False):
     """Finish guard_async_begin (waits for that copy only -- it completed long ago when called one step later).  Returns
-    True when a module tripped; it is then pinned to the fp32 kernels like check_guard does."""
+    True when a module tripped; it is then pinned to the fp32 kernels like check_guard does -- unless `adapt` and the trip was
+    a gradient-scale matter (_lower_gradient_scale): then the module stays on the split arithmetic and nothing is reported."""
     if token is None:
         return False
     modules, host, ev = token[:3]
@@ -154,6 +177,8 @@ def guard_async_end(token):
     tripped = False
     for m, w in zip(modules, host.tolist()):
         if w and precision_of(m).startswith("split"):
+            if adapt and _lower_gradient_scale(m, w):
+                continue
             import warnings
             why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
             warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range in the previous training step ({why}); "

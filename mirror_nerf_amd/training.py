@@ -105,7 +105,7 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     token = system.__dict__.pop("_mnrf_guard_token", None)
 
     def settle(token):          # the previous step's flags
-        tripped_here = guard_async_end(token[0])
+        tripped_here = guard_async_end(token[0], adapt=token[1] is None and token[2] == "skip")      # (one rank, update skipped)
         tripped_any = tripped_here if token[1] is None else bool(token[1].item())
         if tripped_any and token[1] is not None:
             pin_fp32(system)    # more than one rank: EVERY rank pins EVERY model, whoever tripped -- the ranks must keep issuing the

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--model", choices=("nerf", "nerf_tcnn"), default="nerf", help="nerf_tcnn: the hash-grid model (BASELINE config 5)")
     ap.add_argument("--bound", type=float, default=4.0, help="nerf_tcnn: half edge of the hash grid's box")
     ap.add_argument("--table-grad", choices=("fixed", "fp32", "f16"), default="fixed", help="nerf_tcnn: how the table gradient is accumulated")
+    ap.add_argument("--flat-adam", action="store_true", help="nerf: training.FlatAdam (mnrf_adam_step) instead of torch's fused Adam")
     ap.add_argument("--mlp-f16", action="store_true", help="nerf_tcnn: single-pass f16 MLPs in the forward kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -59,8 +60,17 @@ def main():
     rays_t, rgbs_t, masks_t = (torch.from_numpy(x).to(dev) for x in (rays, rgbs, masks))
     vr, vc, vm = SC.scene_views(1, 64, 64, held_out=True)
     vr_t, vc_t = torch.from_numpy(vr).to(dev), torch.from_numpy(vc).to(dev)
-    opt = torch.optim.Adam(list(system.parameters()), lr=a.lr, fused=True)
-    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.1 ** (1.0 / max(1, a.steps)))
+    gamma = 0.1 ** (1.0 / max(1, a.steps))
+    if a.flat_adam and a.model == "nerf":
+        opt = training.FlatAdam(list(system.models.values()), lr=a.lr)
+
+        class sched:        # (FlatAdam reads its learning rate from param_groups at every step: the same exponential decay)
+            @staticmethod
+            def step():
+                opt.param_groups[0]["lr"] *= gamma
+    else:
+        opt = torch.optim.Adam(list(system.parameters()), lr=a.lr, fused=True)
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=gamma)
     loss_fn = training.total_loss_fn(SimpleNamespace(model_type=a.model), epoch=a.epoch) if a.loss == "total" else training.color_mask_loss
     g = torch.Generator(device=dev).manual_seed(1)
     emb = system.embeddings

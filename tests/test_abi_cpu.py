@@ -149,3 +149,21 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_gradient_scale_policy():
+    """mirror_nerf._lower_gradient_scale: only a trip that is nothing but a scaled gradient of the training backward lowers the
+    module's gradient scale (2^4 at a time, 2^8 at most); anything else leaves the decision to the fp32 fall-back."""
+    import warnings
+    import torch
+    from mirror_nerf_amd import mirror_nerf as MN
+    m = torch.nn.Linear(1, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert not MN._lower_gradient_scale(m, 1)                 # saturated, but not tagged as the backward
+        assert not MN._lower_gradient_scale(m, 1 | 128 | 256)     # the forward saturated too
+        assert not MN._lower_gradient_scale(m, 1 | 256 | 512)     # ... or the second-order pass
+        assert not MN._lower_gradient_scale(m, 2 | 1 | 256)       # ... or a weight is out of range
+        for want in (4, 8):
+            assert MN._lower_gradient_scale(m, 1 | 256) and m.__dict__["_mnrf_seed_reduction"] == want
+        assert not MN._lower_gradient_scale(m, 1 | 256)           # exhausted: fp32 from here
