@@ -749,7 +749,7 @@ def main():
                        "train_step_workload": "1024 rays per GPU, perturb = noise_std = 1, 25 % GT mirror rays reflected once; train_step: "
                                               "run.sh:266's schedule (64 coarse + 128 fine samples, --N_importance 64); "
                                               "train_step.config3_64_plus_192: BASELINE config 3 as worded (64 + 192, --N_importance 128)",
-                       "collective_backend": (dist.get_backend() + " (RCCL)") if multi else None,
+                       "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (MNRF_SHARE_GPU test aid: timings void)")) if multi else None,
                        "rccl_world_size": dist.get_world_size() if multi else None},
             "samples_per_s": value * evals_per_ray,
             "field_evals_per_ray": evals_per_ray,

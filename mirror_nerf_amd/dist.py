@@ -31,10 +31,16 @@ def init_from_env(device=None):
     """One process per GPU (train.py:577-584 gets the same from Lightning DDP): reads RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* as set by torch.distributed.run, binds this process to GPU LOCAL_RANK and brings up the RCCL group
     (backend "nccl" IS RCCL on ROCm).  A 1-rank group is only created when MNRF_FORCE_COLLECTIVES=1.
+    MNRF_SHARE_GPU=1 is a TEST AID for boxes with fewer GPUs than ranks: every rank binds GPU 0 and the group is "gloo"
+    (RCCL refuses two ranks on one device), so that the N > 1 code paths -- ray sharding, per-rank batches, the bucket
+    all-reduce issued from the backward hooks, max-over-ranks timing -- execute on device tensors; its timings mean nothing.
     Returns (rank, world_size, device)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("MNRF_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     if device is None:
         if local >= torch.cuda.device_count():
             raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
@@ -44,7 +50,7 @@ def init_from_env(device=None):
     if want_group and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if device.type == "cuda":
+        if device.type == "cuda" and not share:
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=ws)

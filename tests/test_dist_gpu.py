@@ -24,8 +24,9 @@ WORKER = textwrap.dedent('''
     from mirror_nerf_amd import dist as D, synthetic as SY, training
 
     rank, ws, dev = D.init_from_env()
-    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == ws
-    assert dev.index == int(os.environ["LOCAL_RANK"]) == torch.cuda.current_device()
+    share = os.environ.get("MNRF_SHARE_GPU") == "1"
+    assert dist.is_initialized() and dist.get_backend() == ("gloo" if share else "nccl") and dist.get_world_size() == ws
+    assert dev.index == (0 if share else int(os.environ["LOCAL_RANK"])) == torch.cuda.current_device()
 
     # max over ranks / flat gradient all-reduce on device tensors
     assert D.max_over_ranks(1.0 + rank, dev) == float(ws)
@@ -89,11 +90,11 @@ def _free_port():
     return p
 
 
-def _run(world):
+def _run(world, **extra):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, MNRF_ROOT=ROOT, MNRF_FORCE_COLLECTIVES="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+        env = dict(os.environ, **extra, MNRF_ROOT=ROOT, MNRF_FORCE_COLLECTIVES="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -115,6 +116,37 @@ def test_rccl_one_rank_group_runs_every_collective():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_rccl_two_ranks():
     _run(2)
+
+
+def test_two_ranks_sharing_the_gpu():
+    """The 2-rank code path on a 1-GPU box: both ranks bind GPU 0 and the group is gloo (MNRF_SHARE_GPU=1, a test aid:
+    RCCL refuses two ranks on one device).  Everything but the transport is what the 8-GPU run executes: distinct ranks
+    and batches, interleaved tiles, gather on rank 0, bucket all-reduce issued from the backward hooks, in-place table
+    gradients, identical parameters after the step."""
+    _run(2, MNRF_SHARE_GPU="1")
+
+
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` end to end (launcher path, weak + strong scaling legs, training step with the all-reduce,
+    the hash-grid leg across ranks) on one GPU shared by both ranks; the numbers are void, the line's shape is not."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MNRF_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_world_size"] == 2 and line["config"]["collective_backend"].startswith("gloo")
+    assert line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line       # rank 0 at N = 1 only
+    ss = line["strong_scaling"]
+    assert ss["rays_per_s"] > 0 and 0 < ss["rays_of_rank0"] < 640000
+    cm = ss["clustered_mask"]
+    assert len(cm["reflected_rays_per_rank"]) == 2 and sum(cm["primary_rays_per_rank"]) == 640000.0
+    assert line["train_step"]["ms_per_step"] > 0 and line["train_step"]["allreduce"]["buckets_in_place"] == 2
+    hg = line["hash_grid_variant"]
+    assert hg["n_gpus"] == 2 and hg["train_ms_per_step"] > 0 and hg["allreduce"] is not None
 
 
 def test_bench_spawns_its_own_ranks():

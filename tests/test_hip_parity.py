@@ -168,6 +168,27 @@ def test_render_rays_golden(name):
         assert np.max(np.abs(got["z_vals_fine"] - fx.outputs["z_vals_fine"])) <= 5e-3
 
 
+def _normal_error_ladder(k, e_hip, e_ref):
+    """Per-sample gradient normals against the fp64 truth, compared as error DISTRIBUTIONS (mean and
+    median alone do not see the tail): every quantile of the HIP error up to 99.9 % within twice the reference's fp32 run's,
+    and no more samples beyond 1e-3 / 1e-2 / 1e-1 than twice the reference's count (+ 2 samples).  The handful of samples
+    with a vanishing density gradient that carry O(1) errors in ANY fp32 run sit above the ladder in both."""
+    eh, er = np.linalg.norm(e_hip.reshape(-1, 3), axis=1), np.linalg.norm(e_ref.reshape(-1, 3), axis=1)
+    assert np.abs(e_hip).mean() <= 2.0 * np.abs(e_ref).mean() + 1e-6, (k, np.abs(e_hip).mean(), np.abs(e_ref).mean())
+    assert np.median(np.abs(e_hip)) <= 2.0 * np.median(np.abs(e_ref)) + 1e-6, k
+    ladder = {}
+    for q in (50.0, 90.0, 99.0, 99.9):
+        a, b = float(np.percentile(eh, q)), float(np.percentile(er, q))
+        ladder[q] = (a, b)
+        assert a <= 2.0 * b + 1e-6, (k, "quantile", q, a, b)
+    for lim in (1e-3, 1e-2, 1e-1):
+        a, b = int((eh > lim).sum()), int((er > lim).sum())
+        ladder[lim] = (a, b)
+        assert a <= 2 * b + 2, (k, "samples beyond", lim, a, b)
+    return ladder
+
+
+
 @pytest.mark.parametrize("base", ["g4_fine_train", "g11_trained_render_train"])
 def test_fine_pass_as_close_to_the_fp64_truth_as_the_reference(base, precision):
     """Fixtures G14 of the FINE pass (tests/golden/make_golden_truth64.py truth_fine): the reference in float64 at the fine
@@ -199,8 +220,7 @@ def test_fine_pass_as_close_to_the_fp64_truth_as_the_reference(base, precision):
         e_ref, e_hip = np.abs(ref32 - truth), np.abs(hip - truth)
         report[k] = (float(e_hip.max()), float(e_ref.max()))
         if k == "normal_fine":
-            assert e_hip.mean() <= 2.0 * e_ref.mean() + 1e-6, (k, e_hip.mean(), e_ref.mean())
-            assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-6, (k, np.median(e_hip), np.median(e_ref))
+            print("normal_fine error ladder (hip, reference fp32):", _normal_error_ladder(k, hip - truth, ref32 - truth))
         else:
             assert e_hip.max() <= 2.0 * e_ref.max() + slack * scale, (k, e_hip.max(), e_ref.max())
         checked += 1
@@ -231,8 +251,7 @@ def test_as_close_to_the_fp64_truth_as_the_reference(precision):
         scale = 8.0 if k.startswith(("depth", "x_surface", "z_vals")) else 1.0
         e_ref, e_hip = np.abs(ref32 - truth), np.abs(hip - truth)
         if k == "normal_coarse":       # per sample: a few samples with a vanishing gradient carry errors of O(1) in any fp32 run
-            assert e_hip.mean() <= 2.0 * e_ref.mean() + 1e-6, (k, e_hip.mean(), e_ref.mean())
-            assert np.median(e_hip) <= 2.0 * np.median(e_ref) + 1e-6, (k, np.median(e_hip), np.median(e_ref))
+            print("normal_coarse error ladder (hip, reference fp32):", _normal_error_ladder(k, hip - truth, ref32 - truth))
         else:
             assert e_hip.max() <= 2.0 * e_ref.max() + 2e-6 * scale, (k, e_hip.max(), e_ref.max())
         checked += 1
