@@ -560,6 +560,13 @@ def main():
                  f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}, or plain "
                  f"python bench.py --gpus {a.gpus})")
 
+    # a rank that stops making progress says where: every thread's stack goes to stderr after MNRF_BENCH_WATCHDOG seconds
+    # (default 900; the run is not interrupted)
+    import faulthandler
+    wd = float(os.environ.get("MNRF_BENCH_WATCHDOG", "900"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, repeat=False, file=sys.stderr)
+
     import torch
     import torch.distributed as dist
     import mirror_nerf_amd as M

@@ -57,6 +57,17 @@ def init_from_env(device=None):
     return rank, ws, device
 
 
+def host_staged():
+    """True under the MNRF_SHARE_GPU test aid (gloo moving device tensors through host memory, several ranks time-slicing one
+    GPU).  Measured on an MI355X (profiles/r04zk_README.txt): with FOUR ranks on one GPU, train_step's blocking flag all-reduce
+    behind two bucket all-reduces still in flight stalls for good at the 14th step -- every rank's collective sequence
+    identical (MNRF_DIST_TRACE=1), the host threads in kfd_wait_on_events, the GPU reported busy -- while 2 and 8 ranks run
+    through, and draining the device before the blocking collective removes it.  An effect of 4 processes x (compute + gloo's
+    pool streams) over-subscribing one GPU's hardware queues, not of the collective protocol; RCCL (one process per GPU,
+    stream-ordered, no host staging) has neither ingredient.  The aid therefore drains the device before that collective."""
+    return os.environ.get("MNRF_SHARE_GPU", "0") == "1" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -294,6 +305,9 @@ class _Overlap:
     def issue(self):
         if self.work is None and dist.is_initialized():
             msgs = _module_messages(self.module)
+            if _TRACE:
+                _trace(f"bucket {_SEQ.index(self) if self in _SEQ else -1} {type(self.module).__name__} left={self.left} "
+                       f"sizes={[int(f.numel()) for f, _ in msgs]}")
             if msgs:
                 self.work = [(flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), deliver) for flat, deliver in msgs]
 
@@ -316,6 +330,26 @@ class _Overlap:
             h.remove()
         if self in _SEQ:
             _SEQ.remove(self)
+
+
+_TRACE = os.environ.get("MNRF_DIST_TRACE", "0") == "1"      # every collective this module (and train_step) issues, per rank, to stderr
+
+
+def _trace(what):
+    import sys
+    import threading
+    print(f"[mnrf.dist rank {dist.get_rank()} {threading.current_thread().name}] {what}", file=sys.stderr, flush=True)
+
+
+def issue_pending():
+    """Send every bucket the backward pass has not sent from its hooks, in the fixed order.  A caller that issues a collective
+    of its own between backward() and allreduce_gradients() (train_step's range-guard flag) calls this FIRST: whether a bucket
+    was ready inside the backward pass is local to a rank, so anything slipped in between would sit at different positions of
+    the ranks' collective sequences."""
+    if dist.is_available() and dist.is_initialized():
+        for ov in _SEQ:
+            if ov.enabled:
+                ov.issue()
 
 
 def _issue_ready_prefix():

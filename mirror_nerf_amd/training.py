@@ -136,10 +136,14 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
         loss.backward()
         return loss
     loss = fwd_bwd()
+    if collective:
+        D.issue_pending()       # the guard's own all-reduce below must come after ALL buckets on every rank (readiness inside backward is rank-local)
     if mode == "sync":
         tripped = check_guard(system)          # (pins the tripping models to fp32)
         if collective:                         # the decision must be the same on every rank: they all recompute, or none
             flag = torch.tensor([1.0 if tripped else 0.0], device=rays.device)
+            if D._TRACE:
+                D._trace("guard flag (sync mode)")
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
             if bool(flag.item()):
                 pin_fp32(system)               # every rank, every model: the ranks stay on the same kernels
@@ -147,12 +151,17 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
         if tripped:
             D.reset_overlap()                  # the first pass's bucket all-reduces (issued from inside backward) are discarded
             loss = fwd_bwd()                   # this step again, exactly
+            D.issue_pending()
     else:
         tok = guard_async_begin(system)        # forward + backward flags of THIS step, read at the next
         found_host = None
         if tok is not None and (mode == "skip" or collective):
             found = (tok[3] != 0).any().to(torch.float32)          # 0-dim, like GradScaler's found_inf
             if collective:
+                if D._TRACE:
+                    D._trace("guard flag (skip mode)")
+                if D.host_staged():
+                    torch.cuda.synchronize()       # (MNRF_SHARE_GPU test aid only; see dist.host_staged)
                 torch.distributed.all_reduce(found, op=torch.distributed.ReduceOp.MAX)
                 found_host = torch.empty((), dtype=torch.float32, pin_memory=True)
                 found_host.copy_(found, non_blocking=True)
