@@ -178,6 +178,22 @@ def _bucket_worker(rank, ws, port, q):
                 assert all(o.work is None for o in ov)
         D.allreduce_gradients([q_ for m_ in mods for q_ in params_of(m_)], modules=mods)
         res.append([float(m_.sigma.weight.grad[0, 0]) for m_ in mods])
+        # ---- diverging ranks AND a collective of the caller's own between backward() and allreduce_gradients() (train_step's
+        # range-guard flag): on rank 0 both buckets left from inside the backward pass, on rank 1 none did (the module at the
+        # head of the fixed order never became ready).  issue_pending() sends the rest first, so the flag is the THIRD collective
+        # on both ranks; without it rank 1 would put it first and the sequences would cross
+        for m_ in mods:
+            for p_ in m_.parameters():
+                p_.grad = None
+        take = mods if rank == 0 else mods[:1]
+        sum(_FakeFieldFn.apply(m_, float(300 * (i + 1) + rank), *params_of(m_)) for i, m_ in enumerate(take)).backward()
+        sent_in_backward = [o.work is not None for o in ov]
+        D.issue_pending()
+        sent_before_flag = [o.work is not None for o in ov]
+        flag = torch.tensor([float(rank)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        D.allreduce_gradients([q_ for m_ in mods for q_ in params_of(m_)], modules=mods)
+        res.append((sent_in_backward, sent_before_flag, float(flag), [float(m_.sigma.weight.grad[0, 0]) for m_ in mods]))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -207,6 +223,7 @@ def test_flat_gradient_buckets_and_overlapped_allreduce():
         assert res[3] == 0.5
         assert res[4] == (True, [1.5, 11.5]), res[4]      # the recomputed pass only: mean(1 + 10 i + rank)
         assert res[5] == [4.0, 4.0], res[5]               # (1 + 2) + mean over ranks of 2 * rank
+        assert res[6] == ([rank == 0] * 2, [True, True], 1.0, [300.5, 300.0]), res[6]
 
 
 # ---- hash-grid model (BASELINE config 5 "... 8xMI355X"): table gradient reduced in place, MLP gradients as one blob
