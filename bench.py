@@ -626,6 +626,118 @@ def main():
     ms_sig = sum(t for _, t in sig)
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
 
+    # everything the line is assembled from, so that emit() can run at any point from here on
+    strong = other_tf = other_rays = other_ms = smi_other = host_maps = fused = train = hash_grid = rough = trained = None
+    legs_done = []
+
+    def emit(incomplete=None):
+        """Rank 0 prints the ONE line.  `incomplete`: legs cut short by the deadline below (N > 1 only)."""
+        if rank == 0:
+            split = a.precision == "split"
+            peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+            h = "h2" if os.environ.get("MNRF_SPLIT48", "1") == "0" else "h3"     # 48 samples per wave is the default tuning (DESIGN 9.2)
+            kernel = f"mnrf::{h}::field_split_kernel<false,false,false,false>" if split else "mnrf::s2::field_kernel<false,false>"
+            traffic, traffic_src, traffic_commit = _traffic(kernel)
+            tele = smi_main.summary()
+            sclk = smi_main.median_sclk()
+            # the peak the kernel could reach at the clock this box granted it (peak is quoted at 2.4 GHz)
+            granted_peak = peak * sclk / 2400.0 if sclk else None
+            res = {
+                "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32 carried as hi/lo f16 pairs (f16 MFMA, f32 accumulate; max |diff| to the fp32 chain 3e-6)"
+                         if split else "f32",
+                "data": "synthetic", "code_commit": _build_commit(),
+                "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
+                                       "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
+                                       "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
+                           "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames",
+                           "train_step_workload": "1024 rays per GPU, perturb = noise_std = 1, 25 % GT mirror rays reflected once; train_step: "
+                                                  "run.sh:266's schedule (64 coarse + 128 fine samples, --N_importance 64); "
+                                                  "train_step.config3_64_plus_192: BASELINE config 3 as worded (64 + 192, --N_importance 128)",
+                           "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (MNRF_SHARE_GPU test aid: timings void)")) if multi else None,
+                           "rccl_world_size": dist.get_world_size() if multi else None},
+                "samples_per_s": value * evals_per_ray,
+                "field_evals_per_ray": evals_per_ray,
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                             "frac": achieved / peak,
+                             "peak_note": ("dense f16 MFMA peak; `achieved` counts ALGORITHMIC fp32 FLOPs (1 318 912 per sample), "
+                                           "the kernel executes 3 f16 products per fp32 product") if split else "fp32 MFMA peak",
+                             "executed_tflops": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL),
+                             "executed_frac": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL) / peak,
+                             "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                             "frac_at_granted_clock": achieved / granted_peak if granted_peak else None,
+                             "granted_clock_note": "frac with `peak` scaled to the median shader clock sampled through the timed frames "
+                                                   "(telemetry.sclk_mhz.median / 2400 MHz): separates what the box granted from what the code does",
+                             "traffic": traffic,
+                             "traffic_source": (f"static profile: profiles/traffic.json, measured at commit {traffic_commit or 'unrecorded'} "
+                                                f"by {traffic_src}") if traffic is not None else None,
+                             "traffic_note": ("HBM bytes per launch = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE from separate rocprofv3 "
+                                              "--pmc passes over one chunk of this workload (PMC counters cannot be read inside this run; "
+                                              "scripts/profile_round.sh regenerates the file); algorithmic bytes are 36 B/sample")
+                                             if traffic is not None else "no PMC pass on record for this kernel (profiles/traffic.json)",
+                             "telemetry": tele,
+                             "kernel": kernel + " (full 4-head evaluation, fine pass)",
+                             "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
+                             "flop_per_sample": MN.FLOP_FULL,
+                             "sclk_mhz_under_load": (tele["sclk_mhz"] or {}).get("median"),
+                             "board_power_w_under_load": (tele["power_w"] or {}).get("median"),
+                             "board_power_cap_w": tele["power_cap_w"],
+                             "power_note": "medians of the 200 ms samples taken through the timed frames (`telemetry` has min/median/max, "
+                                           "throttle bits and the power-limit residency); the split-f16 kernels run at the package power "
+                                           "limit and get ~2.1-2.2 GHz instead of the 2.4 GHz `peak` assumes (profiles/DIARY.md 9.1)",
+                             "sigma_only_kernel_tflops": sig_tf,
+                             "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
+            }
+            if other_tf is not None:
+                res["roofline"]["other_precision"] = {
+                    "precision": other, "achieved": other_tf, "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
+                    "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
+                    "avg_launch_ms": other_ms, "rays_per_s": other_rays, "note": "one frame of the same workload with the other arithmetic",
+                    "telemetry": smi_other.summary() if smi_other is not None else None,
+                    "frac_at_granted_clock": (other_tf / ((PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS) * smi_other.median_sclk() / 2400.0)
+                                              if (smi_other is not None and smi_other.median_sclk()) else None)}
+            if strong is not None:
+                res["strong_scaling"] = strong
+            if host_maps is not None:
+                res["with_host_maps"] = host_maps
+            if fused is not None:
+                res["maps_only_fused"] = fused
+            if train is not None:
+                res["train_step"] = train
+            if hash_grid is not None:
+                res["hash_grid_variant"] = hash_grid
+            if rough is not None:
+                res["roughness_variant"] = rough
+            if trained is not None:
+                res["trained_weights_variant"] = trained
+            if world == 1 and not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
+            if incomplete:
+                res["incomplete_legs"] = incomplete
+            print(json.dumps(res), flush=True)
+
+
+    # N > 1: the legs after the headline measurement are bounded.  A rank that stalls in a secondary leg (a collective that never
+    # completes) must not cost the run its line: after MNRF_BENCH_LEG_DEADLINE seconds (default 900) rank 0 prints what was
+    # measured, names the legs that did not finish, and every rank leaves.  `value` was measured above, before any of this.
+    deadline = None
+    if multi:
+        import threading
+
+        def _expired():
+            try:
+                faulthandler.dump_traceback(file=sys.stderr)
+                emit(incomplete={"finished": list(legs_done), "note": "secondary legs cut by MNRF_BENCH_LEG_DEADLINE; "
+                                 "value / roofline were measured before them"})
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+        deadline = threading.Timer(float(os.environ.get("MNRF_BENCH_LEG_DEADLINE", "900")), _expired)
+        deadline.daemon = True
+        deadline.start()
+
     # strong scaling: ONE frame (rank 0's view) dealt to the ranks in interleaved 4096-ray tiles; no collective while
     # rendering; then the optional assembly of the 20 B/ray maps on rank 0 (SURVEY 8e)
     strong = None
@@ -650,6 +762,7 @@ def main():
                           "collective); gather = all_gather of rgb/depth/mask maps, outside ms_per_frame"}
         res = frame = None
         strong["clustered_mask"] = clustered_balance(dev, models, common, rank, world, sync)
+        legs_done.append("strong_scaling")
 
     # the other arithmetic on ONE whole frame of the same workload, for the record: rays/s and the dominant kernel's rate
     other = "fp32" if a.precision == "split" else "split"
@@ -719,6 +832,7 @@ def main():
     if not a.no_train:
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024)
+        legs_done.append("train_step")
         train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total")
         train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline")
                                     if k in train_total}
@@ -727,94 +841,16 @@ def main():
         train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
         train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
                                                                   "reflected_rays_per_step", "allreduce")}
+        legs_done.append("train_step.with_total_loss + config3_64_plus_192")
 
     hash_grid = hash_grid_leg(dev, rays) if not a.no_train else None
+    legs_done.append("hash_grid_variant")
     rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train) else None
     trained = trained_leg(dev) if (world == 1 and not a.no_train) else None
 
-    if rank == 0:
-        split = a.precision == "split"
-        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-        h = "h2" if os.environ.get("MNRF_SPLIT48", "1") == "0" else "h3"     # 48 samples per wave is the default tuning
-        kernel = f"mnrf::{h}::field_split_kernel<false,false,false,false>" if split else "mnrf::s2::field_kernel<false,false>"
-        traffic, traffic_src, traffic_commit = _traffic(kernel)
-        tele = smi_main.summary()
-        sclk = smi_main.median_sclk()
-        # the peak the kernel could reach at the clock this box granted it (peak is quoted at 2.4 GHz)
-        granted_peak = peak * sclk / 2400.0 if sclk else None
-        res = {
-            "metric": "rendered rays/sec (primary+reflected)", "value": value, "unit": "rays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 carried as hi/lo f16 pairs (f16 MFMA, f32 accumulate; max |diff| to the fp32 chain 3e-6)"
-                     if split else "f32",
-            "data": "synthetic", "code_commit": _build_commit(),
-            "config": {"workload": "eval.batched_inference 800x800, 64 coarse (sigma-only) + 192 fine samples/ray, "
-                                   "chunk 32768, 1 reflection bounce, all-mirror mask: 640000 primary + 640000 "
-                                   "reflected rays per frame per GPU; random-init 8x256 MirrorNeRF pair, seed 0",
-                       "rays_per_step_per_gpu": rays_per_frame, "parallelism": f"{world} x independent frames",
-                       "train_step_workload": "1024 rays per GPU, perturb = noise_std = 1, 25 % GT mirror rays reflected once; train_step: "
-                                              "run.sh:266's schedule (64 coarse + 128 fine samples, --N_importance 64); "
-                                              "train_step.config3_64_plus_192: BASELINE config 3 as worded (64 + 192, --N_importance 128)",
-                       "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (MNRF_SHARE_GPU test aid: timings void)")) if multi else None,
-                       "rccl_world_size": dist.get_world_size() if multi else None},
-            "samples_per_s": value * evals_per_ray,
-            "field_evals_per_ray": evals_per_ray,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak,
-                         "peak_note": ("dense f16 MFMA peak; `achieved` counts ALGORITHMIC fp32 FLOPs (1 318 912 per sample), "
-                                       "the kernel executes 3 f16 products per fp32 product") if split else "fp32 MFMA peak",
-                         "executed_tflops": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL),
-                         "executed_frac": achieved * (SPLIT_EXECUTED_FLOP_FULL / MN.FLOP_FULL if split else 1339392 / MN.FLOP_FULL) / peak,
-                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_at_granted_clock": achieved / granted_peak if granted_peak else None,
-                         "granted_clock_note": "frac with `peak` scaled to the median shader clock sampled through the timed frames "
-                                               "(telemetry.sclk_mhz.median / 2400 MHz): separates what the box granted from what the code does",
-                         "traffic": traffic,
-                         "traffic_source": (f"static profile: profiles/traffic.json, measured at commit {traffic_commit or 'unrecorded'} "
-                                            f"by {traffic_src}") if traffic is not None else None,
-                         "traffic_note": ("HBM bytes per launch = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE from separate rocprofv3 "
-                                          "--pmc passes over one chunk of this workload (PMC counters cannot be read inside this run; "
-                                          "scripts/profile_round.sh regenerates the file); algorithmic bytes are 36 B/sample")
-                                         if traffic is not None else "no PMC pass on record for this kernel (profiles/traffic.json)",
-                         "telemetry": tele,
-                         "kernel": kernel + " (full 4-head evaluation, fine pass)",
-                         "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full),
-                         "flop_per_sample": MN.FLOP_FULL,
-                         "sclk_mhz_under_load": (tele["sclk_mhz"] or {}).get("median"),
-                         "board_power_w_under_load": (tele["power_w"] or {}).get("median"),
-                         "board_power_cap_w": tele["power_cap_w"],
-                         "power_note": "medians of the 200 ms samples taken through the timed frames (`telemetry` has min/median/max, "
-                                       "throttle bits and the power-limit residency); the split-f16 kernels run at the package power "
-                                       "limit and get ~2.1-2.2 GHz instead of the 2.4 GHz `peak` assumes (profiles/DIARY.md 9.1)",
-                         "sigma_only_kernel_tflops": sig_tf,
-                         "field_kernel_time_fraction": (ms_full + ms_sig) * 1e-3 / dt},
-        }
-        if other_tf is not None:
-            res["roofline"]["other_precision"] = {
-                "precision": other, "achieved": other_tf, "peak": PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS,
-                "frac": other_tf / (PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS),
-                "avg_launch_ms": other_ms, "rays_per_s": other_rays, "note": "one frame of the same workload with the other arithmetic",
-                "telemetry": smi_other.summary() if smi_other is not None else None,
-                "frac_at_granted_clock": (other_tf / ((PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS) * smi_other.median_sclk() / 2400.0)
-                                          if (smi_other is not None and smi_other.median_sclk()) else None)}
-        if strong is not None:
-            res["strong_scaling"] = strong
-        if host_maps is not None:
-            res["with_host_maps"] = host_maps
-        if fused is not None:
-            res["maps_only_fused"] = fused
-        if train is not None:
-            res["train_step"] = train
-        if hash_grid is not None:
-            res["hash_grid_variant"] = hash_grid
-        if rough is not None:
-            res["roughness_variant"] = rough
-        if trained is not None:
-            res["trained_weights_variant"] = trained
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
-        print(json.dumps(res), flush=True)
+    if deadline is not None:
+        deadline.cancel()
+    emit()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
