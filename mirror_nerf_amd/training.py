@@ -168,6 +168,10 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
                 tok[2].record()                # (the event the next step waits for now also covers this copy)
             if mode == "skip":
                 optimizer.grad_scale, optimizer.found_inf = None, found       # fused Adam: no update where found_inf != 0
+        elif mode == "skip" and getattr(optimizer, "found_inf", None) is not None:
+            # no split model left (every model pinned to fp32 after a trip): the flag tensor of the tripping step must not keep
+            # vetoing updates -- it would skip every step from here on (found with two ranks, where a trip pins EVERY model)
+            optimizer.grad_scale, optimizer.found_inf = None, None
         system.__dict__["_mnrf_guard_token"] = (tok, found_host, mode)
     # RCCL over xGMI when world_size > 1: per-model flat buckets, the all-reduce of a model issued from inside the backward
     # pass as soon as its gradients are complete (dist.attach_overlap), only waited for here

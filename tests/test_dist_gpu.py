@@ -82,6 +82,61 @@ WORKER = textwrap.dedent('''
 ''')
 
 
+GUARD_WORKER = textwrap.dedent('''
+    import os, sys, warnings
+    sys.path.insert(0, os.environ["MNRF_ROOT"])
+    import torch, torch.distributed as dist
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import dist as D, synthetic as SY, training
+    from mirror_nerf_amd import mirror_nerf as MN
+
+    rank, ws, dev = D.init_from_env()
+    mode = training.GUARD_MODE
+    torch.manual_seed(0)
+    system = M.NeRFSystem(training.default_hparams()).to(dev)          # same weights on every rank
+    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
+    D.attach_overlap(system.models.values())
+    g = torch.Generator(device=dev); g.manual_seed(1 + rank)
+    all_rays = SY.device_rays(64, 64, dev)
+
+    def batch(far_away):
+        rays = all_rays[torch.randint(0, all_rays.shape[0], (256,), device=dev, generator=g)].contiguous()
+        if far_away:
+            rays[:, :3] += 100.0          # positions beyond the fast sin/cos range: the encoding-range bit of the guard word
+        return rays, torch.rand(256, 3, device=dev, generator=g), (torch.rand(256, device=dev, generator=g) < 0.25).float()
+
+    def checksum():
+        c = torch.stack([q.detach().double().sum() for q in system.parameters()]).sum().reshape(1)
+        parts = [torch.zeros_like(c) for _ in range(ws)]
+        dist.all_gather(parts, c)
+        return [float(q) for q in parts]
+
+    before = [q.detach().clone() for q in system.parameters()]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        training.train_step(system, opt, *batch(far_away=(rank == ws - 1)))      # ONLY the last rank leaves the range
+        torch.cuda.synchronize()
+        same = all(torch.equal(a, q.detach()) for a, q in zip(before, system.parameters()))
+        if mode == "skip":
+            assert same, "skip: the update of the tripping step must be skipped on EVERY rank"
+        else:
+            assert not same, "sync: the step is recomputed on the exact kernels and applied on every rank"
+            assert all(MN.precision_of(m) == "fp32" for m in system.models.values())
+        c1 = checksum()
+        training.train_step(system, opt, *batch(False))
+        torch.cuda.synchronize()
+    assert all(MN.precision_of(m) == "fp32" for m in system.models.values()), "every rank pins every model, whoever tripped"
+    c2 = checksum()
+    assert all(abs(c - c1[0]) <= 1e-9 * max(1.0, abs(c1[0])) for c in c1), c1      # the ranks hold the same weights
+    assert all(abs(c - c2[0]) <= 1e-9 * max(1.0, abs(c2[0])) for c in c2), c2
+    assert c2[0] != c1[0], ("the step after the trip did not update the weights", c1, c2)
+    assert all(bool(torch.isfinite(q).all()) for q in system.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+''')
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -90,13 +145,13 @@ def _free_port():
     return p
 
 
-def _run(world, **extra):
+def _run(world, worker=None, **extra):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, **extra, MNRF_ROOT=ROOT, MNRF_FORCE_COLLECTIVES="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([sys.executable, "-c", worker or WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         try:
@@ -124,6 +179,15 @@ def test_two_ranks_sharing_the_gpu():
     and batches, interleaved tiles, gather on rank 0, bucket all-reduce issued from the backward hooks, in-place table
     gradients, identical parameters after the step."""
     _run(2, MNRF_SHARE_GPU="1")
+
+
+@pytest.mark.parametrize("mode", ["skip", "sync"])
+def test_guard_trip_on_one_of_two_ranks(mode):
+    """ADVICE r3 (medium), executed with two ranks: ONE rank's batch leaves the range of the split arithmetic.  "skip": the
+    optimizer update is skipped on BOTH ranks (the flag is all-reduced on the device), the next step pins every model on every
+    rank; "sync": both ranks recompute the step on the exact kernels (collective decision, the first pass's buckets discarded).
+    Either way the ranks end with identical, finite weights and keep issuing the same collectives."""
+    _run(2, worker=GUARD_WORKER, MNRF_SHARE_GPU="1", MNRF_GUARD_MODE=mode)
 
 
 def test_bench_with_two_ranks_sharing_the_gpu():
