@@ -94,7 +94,10 @@ GUARD_WORKER = textwrap.dedent('''
     mode = training.GUARD_MODE
     torch.manual_seed(0)
     system = M.NeRFSystem(training.default_hparams()).to(dev)          # same weights on every rank
-    opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
+    if os.environ.get("MNRF_TEST_OPT") == "flat":      # the bench's optimizer: Adam over one flat tensor per model (mnrf_adam_step)
+        opt = training.FlatAdam(list(system.models.values()), lr=5e-4)
+    else:
+        opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
     D.attach_overlap(system.models.values())
     g = torch.Generator(device=dev); g.manual_seed(1 + rank)
     all_rays = SY.device_rays(64, 64, dev)
@@ -181,13 +184,13 @@ def test_two_ranks_sharing_the_gpu():
     _run(2, MNRF_SHARE_GPU="1")
 
 
-@pytest.mark.parametrize("mode", ["skip", "sync"])
-def test_guard_trip_on_one_of_two_ranks(mode):
+@pytest.mark.parametrize("mode,opt", [("skip", "torch"), ("sync", "torch"), ("skip", "flat")])
+def test_guard_trip_on_one_of_two_ranks(mode, opt):
     """ADVICE r3 (medium), executed with two ranks: ONE rank's batch leaves the range of the split arithmetic.  "skip": the
     optimizer update is skipped on BOTH ranks (the flag is all-reduced on the device), the next step pins every model on every
     rank; "sync": both ranks recompute the step on the exact kernels (collective decision, the first pass's buckets discarded).
     Either way the ranks end with identical, finite weights and keep issuing the same collectives."""
-    _run(2, worker=GUARD_WORKER, MNRF_SHARE_GPU="1", MNRF_GUARD_MODE=mode)
+    _run(2, worker=GUARD_WORKER, MNRF_SHARE_GPU="1", MNRF_GUARD_MODE=mode, MNRF_TEST_OPT=opt)
 
 
 def test_bench_with_two_ranks_sharing_the_gpu():
