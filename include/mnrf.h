@@ -360,6 +360,86 @@ int mnrf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    double beta2, float eps, float weight_decay, int64_t step, int32_t* skipped, const float* grad_scale,
                    const float* found_inf, void* stream);
 
+/* ---- live row counts on the device (round 5): a training step without a host round trip -------------------------------------
+ * Training traces the reflections of exactly the rays the mirror mask selects (train.py:170-178, 248-252).  How many those are
+ * is known on the device only (*count of mnrf_reflect_compact); the reference reads it on the host (`mask.any()`, then boolean
+ * indexing: one stream sync in the middle of every step).  Every `_n` entry point below is its namesake with ONE more argument
+ * in front of `stream`: `n_live`, a DEVICE int32 holding the number of rows (rays; samples / spr for the field entry points)
+ * that exist.  The row-count argument becomes the CAPACITY the buffers are sized for: the launch is sized for it, workgroups
+ * past the live rows leave at once, rows past them are neither read nor written.  n_live == null: exactly the namesake.  With
+ * them the forward, backward and optimizer launches of a whole step are a fixed sequence -- capturable as ONE hipGraph
+ * (mirror_nerf_amd.training.GraphedTrainStep).  Field entry points: MNRF_SPLIT_F16 | MNRF_TRAIN_PLANES route only. */
+int mnrf_embed_n(const float* x, int64_t n, int c, int n_freqs, float* out, const int32_t* n_live, void* stream);
+int mnrf_embed_backward_n(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, const int32_t* n_live, void* stream);
+int mnrf_sample_coarse_n(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp, float perturb,
+                         const float* perturb_rand, float* z_vals, const int32_t* n_live, void* stream);
+int mnrf_composite_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                     const float* noise, const float* rgb, const float* is_mirror,
+                     const float* pred_normal, const float* normal, int white_back,
+                     float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
+                     float* surf_normal, float* surf_normal_grad, float* normal_dif, float* x_surface,
+                     const int32_t* n_live, void* stream);
+int mnrf_composite_backward_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                              const float* noise, const float* rgb, const float* is_mirror,
+                              const float* pred_normal, const float* normal, int white_back,
+                              const float* weights, const float* depth,
+                              const float* g_weights, const float* g_opacity, const float* g_rgb_map,
+                              const float* g_depth, const float* g_mirror_mask, const float* g_surf_normal,
+                              const float* g_surf_normal_grad, const float* g_normal_dif, const float* g_x_surface,
+                              float* d_sigma, float* d_rgb, float* d_is_mirror, float* d_pred_normal,
+                              float* d_normal, float* d_rays, int detach, const float* keep_mirror,
+                              const int32_t* n_live, void* stream);
+int mnrf_sample_fine_n(const float* z_coarse, const float* weights, int64_t n_rays, int S,
+                       const float* u, int u_per_ray, int n_importance, float* z_fine, const int32_t* n_live, void* stream);
+int mnrf_threshold_mask_n(float* mask, int64_t n, int32_t* any, const int32_t* n_live, void* stream);
+/* n_live: the live rows of the INPUT rays (a second bounce: the first bounce's count); *count as in the namesake */
+int mnrf_reflect_compact_n(const float* rays, const float* x_surface, const float* normal,
+                           const float* normal_noise, float noise_std, const float* mask,
+                           int64_t n_rays, int compact, float near2, float* sec_rays, int32_t* index,
+                           int32_t* count, float* reflect_dir, const int32_t* n_live, void* stream);
+/* n_sec_live: live rows of sec / index / g_sec (the reflection's count); n_live: live rows of base / mask / out */
+int mnrf_blend_scatter_n(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                         const float* mask, int64_t n, int c, float* out, float* reflect_out,
+                         const int32_t* n_sec_live, const int32_t* n_live, void* stream);
+int mnrf_reflect_backward_n(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                            const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                            const int32_t* n_sec_live, void* stream);
+int mnrf_blend_backward_n(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                          float* g_base, float* g_sec, const int32_t* n_sec_live, const int32_t* n_live, void* stream);
+int mnrf_ray_grads_n(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                     float* g_de, const int32_t* n_live, void* stream);
+int mnrf_field_forward_train_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                               const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                               int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                               float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                               float* save_inv, float* save_invj, unsigned flags, const int32_t* n_live, void* stream);
+int mnrf_field_backward_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                 const float* rays, const float* z_vals, int spr,
+                                 const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                 const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                                 const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
+                                 void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir, const float* keep_mirror,
+                                 unsigned flags, const int32_t* n_live, void* stream);
+int mnrf_field_backward2_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                  const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                  const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                  void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz,
+                                  const int32_t* n_live, void* stream);
+/* mnrf_dw_planes2 with the sample count of evaluation e on the device: *n_live[e] * spr[e] samples (n_live[e] null: B[e]); B[e]
+ * = the capacity its planes were sized for.  n_live, spr: HOST arrays of n_eval entries.  The work plan of the GEMM (which
+ * workgroup contracts which 32-sample stages) is made by a one-workgroup launch in front of it and lives at the head of the
+ * workspace: mnrf_dw_planes2_n_workspace_floats(n_eval) floats, whatever the counts. */
+int64_t mnrf_dw_planes2_n_workspace_floats(int n_eval);
+int mnrf_dw_planes2_n(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                      const int32_t* const* n_live, const int* spr, const uint32_t* const* seedmax, const int* kinds,
+                      float* workspace, float* const* d_params, int accumulate, void* stream);
+/* mnrf_adam_step with its hyper-parameters and step count in DEVICE memory (a captured step must not freeze them): hyper =
+ * [lr, beta1, beta2, eps, weight_decay] (doubles; lr, eps and weight_decay are rounded to float as the namesake's arguments
+ * are), *step = the count of calls, this one included -- the caller advances it on the stream with mnrf_add_i64. */
+int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
+                       const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf, void* stream);
+int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream);      /* *counter += delta (device), one thread */
+
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);
  * log2_per_level_scale, base_resolution, bound: the encoding configuration (mirror_nerf_tcnn.py:36-49);

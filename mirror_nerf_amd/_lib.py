@@ -107,6 +107,31 @@ SIGNATURES = {
     "mnrf_loss_count": (_int, [ctypes.c_void_p, _c_f, _str]),
     "mnrf_mse_blocks": (_int, []),
     "mnrf_mse_psnr": (_int, [_c_f, _c_f, ctypes.c_void_p, _i64, _int, _c_f, _c_f, _str]),
+    # ---- live row counts on the device (round 5): the namesake's arguments + n_live (device int32) in front of the stream
+    "mnrf_embed_n": (_int, [_c_f, _i64, _int, _int, _c_f, _c_i, _str]),
+    "mnrf_embed_backward_n": (_int, [_c_f, _c_f, _i64, _int, _int, _c_f, _c_i, _str]),
+    "mnrf_sample_coarse_n": (_int, [_c_f, _i64, _c_f, _int, _int, _flt, _c_f, _c_f, _c_i, _str]),
+    "mnrf_composite_n": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
+                                _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
+    "mnrf_composite_backward_n": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_int, _c_f, _c_i, _str]),
+    "mnrf_sample_fine_n": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _c_i, _str]),
+    "mnrf_threshold_mask_n": (_int, [_c_f, _i64, _c_i, _c_i, _str]),
+    "mnrf_reflect_compact_n": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i, _c_i, _c_f, _c_i, _str]),
+    "mnrf_blend_scatter_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),
+    "mnrf_reflect_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _c_i, _str]),
+    "mnrf_blend_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),
+    "mnrf_ray_grads_n": (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_i, _str]),
+    "mnrf_field_forward_train_n": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 9 + [_u32, _c_i, _str]),
+    "mnrf_field_backward_planes_n": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int] + [_c_f] * 9 +
+                                     [ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, _c_f, _u32, _c_i, _str]),
+    "mnrf_field_backward2_planes_n": (_int, [_c_f, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _c_f, _c_f, _c_f,
+                                             ctypes.c_void_p, ctypes.c_void_p, _c_f, _c_f, _c_i, _str]),
+    "mnrf_dw_planes2_n_workspace_floats": (_i64, [_int]),
+    "mnrf_dw_planes2_n": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
+    "mnrf_adam_step_dev": (_int, [_c_f, _c_f, _c_f, _c_f, _i64, ctypes.c_void_p, ctypes.c_void_p, _c_i, _c_f, _c_f, _str]),
+    "mnrf_add_i64": (_int, [ctypes.c_void_p, _i64, _str]),
 }
 
 _lib = None

@@ -25,9 +25,10 @@ class CompositeFn(torch.autograd.Function):
     Differentiable inputs: rays (through x_surface), sigma, rgb, is_mirror, pred_normal, normal."""
 
     @staticmethod
-    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back, detach=0, keep_mirror=None):
+    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back, detach=0, keep_mirror=None, n_live=None):
         """detach: MNRF_DETACH_W_MASK | MNRF_DETACH_W_NORMAL; keep_mirror: (N,) float, 0 = that ray's mirror mask sees
-        weights.detach() (models/rendering.py:223-247: the --detach_density_* options; values are unaffected)."""
+        weights.detach() (models/rendering.py:223-247: the --detach_density_* options; values are unaffected).
+        n_live: device int32 (1,) or None -- the rays that exist, N being the capacity (include/mnrf.h "live row counts")."""
         N, S = z.shape
         dev = z.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -44,10 +45,11 @@ class CompositeFn(torch.autograd.Function):
         xs = f(N, 3) if full else None
         p = _lib.ptr
         if N:
-            _lib.check(_lib.lib().mnrf_composite(
+            _lib.check(_lib.lib().mnrf_composite_n(
                 p(rays), N, S, p(sigma), p(z), p(noise), p(rgb), p(is_mirror), p(pred_normal), p(normal),
                 int(bool(white_back)), p(weights), p(opacity), p(rgb_map), p(depth), p(mask), p(sn), p(sng), p(nd),
-                p(xs), _lib.stream()), "mnrf_composite")
+                p(xs), p(n_live), _lib.stream()), "mnrf_composite")
+        ctx.n_live = n_live
         ctx.save_for_backward(rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, depth)
         ctx.white_back = bool(white_back)
         ctx.detach, ctx.keep_mirror = int(detach), _c(keep_mirror)
@@ -76,18 +78,18 @@ class CompositeFn(torch.autograd.Function):
         p = _lib.ptr
         g = [None if t is None else t.contiguous().float() for t in (g_w, g_op, g_rgb, g_depth, g_mask, g_sn, g_sng, g_nd, g_xs)]
         if N:
-            _lib.check(_lib.lib().mnrf_composite_backward(
+            _lib.check(_lib.lib().mnrf_composite_backward_n(
                 p(rays), N, S, p(sigma), p(z), p(noise), p(rgb), p(is_mirror), p(pred_normal), p(normal),
                 int(ctx.white_back), None, p(depth), p(g[0]), p(g[1]), p(g[2]), p(g[3]), p(g[4]), p(g[5]), p(g[6]),
                 p(g[7]), p(g[8]), p(d_sigma), p(d_rgb), p(d_m), p(d_pn), p(d_n), p(d_rays), ctx.detach, p(ctx.keep_mirror),
-                _lib.stream()), "mnrf_composite_backward")
+                p(ctx.n_live), _lib.stream()), "mnrf_composite_backward")
 
         def like(d, ref):
             return None if d is None else d.view(ref.shape)
         return (d_rays, like(d_sigma, sigma), None, None, like(d_rgb, rgb) if rgb is not None else None,
                 like(d_m, is_mirror) if is_mirror is not None else None,
                 like(d_pn, pred_normal) if pred_normal is not None else None,
-                like(d_n, normal) if normal is not None else None, None, None, None)
+                like(d_n, normal) if normal is not None else None, None, None, None, None)
 
 
 class FieldFn(torch.autograd.Function):
@@ -97,9 +99,10 @@ class FieldFn(torch.autograd.Function):
 
     apply(module, spr, xyz, rays, z_vals, dir_emb, want_normal, *params) ->
         sigma (B), rgb (B,3), pred_normal (B,3), is_mirror (B), normal (B,3 or empty)
-    `want_normal` may also be a tuple (want_normal, cut_flags, keep_mirror): cut_flags = MNRF_CUT_NORMAL_HEAD |
+    `want_normal` may also be a tuple (want_normal, cut_flags, keep_mirror[, n_live]): cut_flags = MNRF_CUT_NORMAL_HEAD |
     MNRF_CUT_MIRROR_HEAD and keep_mirror (per ray / per row of xyz; 0 = cut the mirror head there) make those heads see
-    geo_feat.detach() (models/mirror_nerf.py:154-183, the --detach_density_* options).
+    geo_feat.detach() (models/mirror_nerf.py:154-183, the --detach_density_* options); n_live: device int32 (1,) = the rays
+    (rows) that exist, the tensors being sized for a capacity (include/mnrf.h "live row counts"; planes route only).
     Positions come from `xyz` (B,>=3 columns, row stride = its row length) or from rays (N,8) and
     z_vals (N,spr).  `dir_emb`: (B/spr, 27) view encoding.  `params`: the module's 32 parameters in
     state_dict order (so that autograd routes their gradients).
@@ -111,8 +114,9 @@ class FieldFn(torch.autograd.Function):
         from .weights import packed_of
         from . import mirror_nerf as _mn
         L = _lib.lib()
-        ctx.cut, ctx.keep_mirror = 0, None
+        ctx.cut, ctx.keep_mirror, ctx.n_live = 0, None, None
         if isinstance(want_normal, tuple):
+            ctx.n_live = want_normal[3] if len(want_normal) > 3 else None
             want_normal, ctx.cut, ctx.keep_mirror = want_normal[0], int(want_normal[1]), _c(want_normal[2])
         packed = packed_of(module)
         dev = packed.device
@@ -123,6 +127,8 @@ class FieldFn(torch.autograd.Function):
         normal = f(B, 3) if want_normal else None
         split = _mn.precision_of(module).startswith("split")
         planes = split and DW_PLANES
+        if ctx.n_live is not None and not planes:
+            raise RuntimeError("a live row count (static training step) needs the split arithmetic with operand planes")
         if planes:     # the inputs of every Linear as hi/lo f16 operand tiles of the weight-gradient GEMM (mnrf_dwp.h)
             save_x = torch.empty(max(16, L.mnrf_train_planes_bytes(B)), dtype=torch.uint8, device=dev)
         else:
@@ -133,10 +139,10 @@ class FieldFn(torch.autograd.Function):
         p = _lib.ptr
         xs = xyz.shape[1] if xyz is not None else 3
         if B:
-            _lib.check(L.mnrf_field_forward_train(
+            _lib.check(L.mnrf_field_forward_train_n(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(dir_emb), dir_emb.shape[1], p(sigma), p(rgb),
                 p(pn), p(mir), p(normal), p(save_x), p(save_mask), p(save_inv), p(save_invj),
-                (_lib.MNRF_SPLIT_F16 if split else 0) | (_lib.MNRF_TRAIN_PLANES if planes else 0), _lib.stream()),
+                (_lib.MNRF_SPLIT_F16 if split else 0) | (_lib.MNRF_TRAIN_PLANES if planes else 0), p(ctx.n_live), _lib.stream()),
                 "mnrf_field_forward_train")
         ctx.split, ctx.planes = split, planes    # the backward follows the arithmetic (and the save format) of ITS forward
         ctx.packed = packed                      # ... and reads ITS weights: the image object (31 us of host time per look-up)
@@ -211,11 +217,11 @@ class FieldFn(torch.autograd.Function):
             red = int(mod.__dict__.get("_mnrf_seed_reduction", 0))      # mirror_nerf._lower_gradient_scale
             dy = torch.empty(max(16, L.mnrf_train_dy_planes_bytes(B)), dtype=torch.uint8, device=dev)
             seed = torch.empty(1, dtype=torch.int32, device=dev)
-            _lib.check(L.mnrf_field_backward_planes(
+            _lib.check(L.mnrf_field_backward_planes_n(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
                 p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut | (red << 16),
-                _lib.stream()), "mnrf_field_backward_planes")
-            st.tape.append((save_x, dy, B, seed, red << 8))      # (kind 0 | the gradient-scale reduction of this launch)
+                p(ctx.n_live), _lib.stream()), "mnrf_field_backward_planes")
+            st.tape.append((save_x, dy, B, seed, red << 8, ctx.n_live, spr))      # (kind 0 | the gradient-scale reduction of this launch)
         elif B:
             ws = f(max(1, L.mnrf_train_workspace_floats(B)))
             _lib.check(L.mnrf_field_backward(
@@ -230,10 +236,10 @@ class FieldFn(torch.autograd.Function):
             x2 = torch.empty(max(16, L.mnrf_train_planes2_bytes(B)), dtype=torch.uint8, device=dev)
             y2 = torch.empty(max(16, L.mnrf_train_dy_planes2_bytes(B)), dtype=torch.uint8, device=dev)
             jmax = torch.empty(1, dtype=torch.int32, device=dev)
-            _lib.check(L.mnrf_field_backward2_planes(
+            _lib.check(L.mnrf_field_backward2_planes_n(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_normal.contiguous().float()), p(normal),
-                p(save_invj), p(save_mask), p(x2), p(y2), p(jmax), p(d_xyz), _lib.stream()), "mnrf_field_backward2_planes")
-            st.tape.append((x2, y2, B, jmax, 1))
+                p(save_invj), p(save_mask), p(x2), p(y2), p(jmax), p(d_xyz), p(ctx.n_live), _lib.stream()), "mnrf_field_backward2_planes")
+            st.tape.append((x2, y2, B, jmax, 1, ctx.n_live, spr))
         elif B and g_normal is not None and normal is not None:   # rows route (fp32 arithmetic, MNRF_DW2_PLANES=0)
             if not st.dirty:         # it ADDS to the gradients (trunk weights, sigma.weight): they start from zero then
                 st.flat.zero_()
@@ -276,8 +282,8 @@ class FieldFn(torch.autograd.Function):
                 g_rays = torch.empty_like(rays)      # together with the per-ray sum of the view-encoding gradient
                 if d_dir is not None:
                     g_de = f(rays.shape[0], 27)
-                _lib.check(L.mnrf_ray_grads(p(d_xyz), p(z_vals), p(d_dir), rays.shape[0], spr, p(g_rays), p(g_de), _lib.stream()),
-                           "mnrf_ray_grads")
+                _lib.check(L.mnrf_ray_grads_n(p(d_xyz), p(z_vals), p(d_dir), rays.shape[0], spr, p(g_rays), p(g_de), p(ctx.n_live),
+                                              _lib.stream()), "mnrf_ray_grads")
             else:
                 N = rays.shape[0]
                 dx = d_xyz.view(N, spr, 3)
@@ -287,7 +293,8 @@ class FieldFn(torch.autograd.Function):
         if d_dir is not None and g_de is None:
             if rays is not None and xyz is None and B and RAY_GRADS_KERNEL:
                 g_de = f(rays.shape[0], 27)
-                _lib.check(L.mnrf_ray_grads(None, None, p(d_dir), rays.shape[0], spr, None, p(g_de), _lib.stream()), "mnrf_ray_grads")
+                _lib.check(L.mnrf_ray_grads_n(None, None, p(d_dir), rays.shape[0], spr, None, p(g_de), p(ctx.n_live), _lib.stream()),
+                           "mnrf_ray_grads")
             else:
                 g_de = d_dir.view(-1, spr, 32)[:, :, :27].sum(1)
         n_par = len(ctx.param_shapes)
@@ -349,8 +356,17 @@ class _Pending:
                 bs = (ctypes.c_int64 * n)(*[t[2] for t in grp])
                 sm = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in grp])
                 kd = (ctypes.c_int * n)(*[t[4] for t in grp])      # 0: first-order planes, 1: second-order planes
-                ws = torch.empty(max(1, L.mnrf_dw_planes2_workspace_floats(n, bs, kd)), dtype=torch.float32, device=self.flat.device)
-                _lib.check(L.mnrf_dw_planes2(n, xs, ys, bs, sm, kd, p(ws), arr, 1 if self.dirty else 0, _lib.stream()), "mnrf_dw_planes2")
+                if any(len(t) > 5 and t[5] is not None for t in grp):
+                    # an evaluation whose sample count lives on the device (the reflected rays of a static step): the GEMM's work
+                    # plan is made on the device too (mnrf_dw_planes2_n), B = capacities
+                    nl = (ctypes.c_void_p * n)(*[(t[5].data_ptr() if (len(t) > 5 and t[5] is not None) else None) for t in grp])
+                    sp = (ctypes.c_int * n)(*[(t[6] if len(t) > 6 else 1) for t in grp])
+                    ws = torch.empty(max(1, L.mnrf_dw_planes2_n_workspace_floats(n)), dtype=torch.float32, device=self.flat.device)
+                    _lib.check(L.mnrf_dw_planes2_n(n, xs, ys, bs, nl, sp, sm, kd, p(ws), arr, 1 if self.dirty else 0, _lib.stream()),
+                               "mnrf_dw_planes2_n")
+                else:
+                    ws = torch.empty(max(1, L.mnrf_dw_planes2_workspace_floats(n, bs, kd)), dtype=torch.float32, device=self.flat.device)
+                    _lib.check(L.mnrf_dw_planes2(n, xs, ys, bs, sm, kd, p(ws), arr, 1 if self.dirty else 0, _lib.stream()), "mnrf_dw_planes2")
                 self.dirty = True
         elif not self.dirty:
             self.flat.zero_()      # no samples at all in this pass
@@ -365,14 +381,14 @@ class EmbedFn(torch.autograd.Function):
     reflected rays carries gradient back to the surface normal (train.py:205 "not detach()")."""
 
     @staticmethod
-    def forward(ctx, x, n_freqs):
+    def forward(ctx, x, n_freqs, n_live=None):
         x = x.float().contiguous()
         n, c = x.shape
         out = torch.empty(n, c * (2 * n_freqs + 1), dtype=torch.float32, device=x.device)
         if n:
-            _lib.check(_lib.lib().mnrf_embed(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.stream()), "mnrf_embed")
+            _lib.check(_lib.lib().mnrf_embed_n(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.ptr(n_live), _lib.stream()), "mnrf_embed")
         ctx.save_for_backward(x)
-        ctx.n_freqs = n_freqs
+        ctx.n_freqs, ctx.n_live = n_freqs, n_live
         return out
 
     @staticmethod
@@ -381,38 +397,46 @@ class EmbedFn(torch.autograd.Function):
         n, c = x.shape
         gx = torch.empty_like(x)
         if n:
-            _lib.check(_lib.lib().mnrf_embed_backward(_lib.ptr(x), _lib.ptr(g.contiguous().float()), n, c, ctx.n_freqs,
-                                                      _lib.ptr(gx), _lib.stream()), "mnrf_embed_backward")
-        return gx, None
+            _lib.check(_lib.lib().mnrf_embed_backward_n(_lib.ptr(x), _lib.ptr(g.contiguous().float()), n, c, ctx.n_freqs,
+                                                        _lib.ptr(gx), _lib.ptr(ctx.n_live), _lib.stream()), "mnrf_embed_backward")
+        return gx, None, None
 
 
 class ReflectFn(torch.autograd.Function):
     """mnrf_reflect_compact / mnrf_reflect_backward (train.py:192-252): reflected-ray construction and
     order-preserving compaction.  apply(rays, x_surface, normal, mask, compact) -> (sec (M,8), index (M) int32
-    [empty when not compacted], reflect_dir (N,3) [not differentiable: visualisation output])."""
+    [empty when not compacted], reflect_dir (N,3) [not differentiable: visualisation output]).
+    static=True (round 5): no host read of the count -- sec / index keep their CAPACITY of N rows and a fourth output, count
+    (device int32 (1,)), says how many exist; the consumers take it as their live row count (n_live; the `_n` entry points).
+    n_live: the live rows of the INPUT rays (a second bounce)."""
 
     @staticmethod
-    def forward(ctx, rays, x_surface, normal, mask, compact):
+    def forward(ctx, rays, x_surface, normal, mask, compact, static=False, n_live=None):
         rays, x_surface, normal = _c(rays.float()), _c(x_surface.float()), _c(normal.float())
         N = rays.shape[0]
         dev = rays.device
         sec = torch.empty(N, 8, dtype=torch.float32, device=dev)
         index = torch.empty(N, dtype=torch.int32, device=dev)
-        count = torch.full((1,), 0, dtype=torch.int32, device=dev)      # (torch.zeros is a memset: ~40 us of idle GPU each)
+        count = torch.empty(1, dtype=torch.int32, device=dev)      # (always written by the kernel)
         rdir = torch.empty(N, 3, dtype=torch.float32, device=dev)
         p = _lib.ptr
-        _lib.check(_lib.lib().mnrf_reflect_compact(
+        _lib.check(_lib.lib().mnrf_reflect_compact_n(
             p(rays), p(x_surface), p(normal), None, 0.0, p(_c(mask.float())) if mask is not None else None, N,
-            int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), _lib.stream()), "mnrf_reflect_compact")
-        M = int(count.item()) if compact else N     # the one host sync per level (train.py:175 does the same)
-        sec, index = sec[:M].contiguous(), index[:M].contiguous()
+            int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), p(n_live), _lib.stream()), "mnrf_reflect_compact")
+        ctx.static = bool(static)
+        if static:
+            ctx.count = count
+        else:
+            M = int(count.item()) if compact else N     # the one host sync per level (train.py:175 does the same)
+            sec, index = sec[:M].contiguous(), index[:M].contiguous()
+            ctx.count = None
         ctx.save_for_backward(rays, normal, index)
         ctx.compact = bool(compact)
-        ctx.mark_non_differentiable(index, rdir)
-        return sec, index, rdir
+        ctx.mark_non_differentiable(index, rdir, count)
+        return sec, index, rdir, count
 
     @staticmethod
-    def backward(ctx, g_sec, _gi, _gr):
+    def backward(ctx, g_sec, _gi, _gr, _gc):
         rays, normal, index = ctx.saved_tensors
         N, M = rays.shape[0], index.shape[0]
         dev = rays.device
@@ -420,11 +444,11 @@ class ReflectFn(torch.autograd.Function):
         g_xs, g_n, g_rays = f(N, 3), f(N, 3), f(N, 8)
         p = _lib.ptr
         if g_sec is None:
-            return torch.zeros_like(rays), torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev), None, None
-        _lib.check(_lib.lib().mnrf_reflect_backward(
+            return torch.zeros_like(rays), torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev), None, None, None, None
+        _lib.check(_lib.lib().mnrf_reflect_backward_n(
             p(rays), p(normal), p(index) if ctx.compact else None, M, p(g_sec.contiguous().float()), N, p(g_xs), p(g_n),
-            p(g_rays), _lib.stream()), "mnrf_reflect_backward")
-        return g_rays, g_xs, g_n, None, None
+            p(g_rays), p(ctx.count), _lib.stream()), "mnrf_reflect_backward")
+        return g_rays, g_xs, g_n, None, None, None, None
 
 
 class BlendFn(torch.autograd.Function):
@@ -432,16 +456,18 @@ class BlendFn(torch.autograd.Function):
     scattered through index (rows without a source keep base.detach()).  `index` None/empty + M == N: direct."""
 
     @staticmethod
-    def forward(ctx, base, sec, index, mask, compact, detach_sec=False):
-        """detach_sec: the reflected colour is a constant of the blend (train.py:284-289, --detach_ref_color_for_blend)."""
+    def forward(ctx, base, sec, index, mask, compact, detach_sec=False, n_sec_live=None, n_live=None):
+        """detach_sec: the reflected colour is a constant of the blend (train.py:284-289, --detach_ref_color_for_blend).
+        n_sec_live / n_live: device int32 (1,) or None -- the rows of sec / index, resp. of base / mask, that exist (static step)."""
         base, sec, mask = _c(base.float()), _c(sec.float()), _c(mask.float())
         N = base.shape[0]
         c = base.shape[1] if base.dim() == 2 else 1
         out = torch.empty_like(base)
         p = _lib.ptr
         idx = index if compact else None
-        _lib.check(_lib.lib().mnrf_blend_scatter(p(base), p(sec), p(idx), sec.shape[0], p(mask), N, c, p(out), None,
-                                                 _lib.stream()), "mnrf_blend_scatter")
+        _lib.check(_lib.lib().mnrf_blend_scatter_n(p(base), p(sec), p(idx), sec.shape[0], p(mask), N, c, p(out), None,
+                                                   p(n_sec_live), p(n_live), _lib.stream()), "mnrf_blend_scatter")
+        ctx.n_sec_live, ctx.n_live = n_sec_live, n_live
         ctx.save_for_backward(mask, index)
         ctx.compact, ctx.c, ctx.m, ctx.detach_sec = bool(compact), c, sec.shape[0], bool(detach_sec)
         return out
@@ -454,6 +480,7 @@ class BlendFn(torch.autograd.Function):
         g_base = torch.empty_like(g_out)
         g_sec = None if ctx.detach_sec else torch.empty((ctx.m,) + tuple(g_out.shape[1:]), dtype=torch.float32, device=g_out.device)
         p = _lib.ptr
-        _lib.check(_lib.lib().mnrf_blend_backward(p(g_out), p(mask), p(index) if ctx.compact else None, ctx.m, N, ctx.c,
-                                                  p(g_base), p(g_sec), _lib.stream()), "mnrf_blend_backward")
-        return g_base, g_sec, None, None, None, None
+        _lib.check(_lib.lib().mnrf_blend_backward_n(p(g_out), p(mask), p(index) if ctx.compact else None, ctx.m, N, ctx.c,
+                                                    p(g_base), p(g_sec), p(ctx.n_sec_live), p(ctx.n_live), _lib.stream()),
+                   "mnrf_blend_backward")
+        return g_base, g_sec, None, None, None, None, None, None

@@ -18,9 +18,17 @@ int launch_dw2(const float* so, long long B, float* ws, float* const* d_params, 
 long long dwp_workspace_floats(int n_eval, const int64_t* B, const int* kinds);
 int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
                const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate, hipStream_t s);
+// ... with the sample counts of the evaluations on the device (round 5): B = capacities; evaluation e has *n_live[e] * spr[e]
+// samples (n_live[e] null: B[e]).  Workspace: dwp_workspace_floats_n(n_eval) floats (sized for any counts up to the capacities).
+long long dwp_workspace_floats_n(int n_eval);
+int launch_dwp_n(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B, const int32_t* const* n_live,
+                 const int* spr, const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate,
+                 hipStream_t s);
 // largest |J^| of a second-order pass (float bits) -> *out, as field_split_bwd2_kernel's prologue forms it
-void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s);
+void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
+                     const int* n_live = nullptr, int spr = 1);
 // largest seed magnitude of an evaluation (float bits) -> *out; the seeds are those of field_split_bwd_kernel's prologue
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
-                     const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s);
+                     const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
+                     const int* n_live = nullptr, int spr = 1);
 }  // namespace mnrf

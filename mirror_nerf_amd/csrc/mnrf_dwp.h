@@ -180,6 +180,20 @@ __host__ __device__ inline void dwp_interval(const DwpPlan& p, int g, long long&
     c1 = (long long)(g + 1) * p.T / p.G;
 }
 
+// the owner of the stage that STARTS at cost c: the g with floor(g T / G) <= c < floor((g + 1) T / G), in closed form
+// (g = ceil((c + 1) G / T) - 1).  The owners of a virtual job are owner(P_v) .. owner(P_v + (n - 1) w), every workgroup
+// in between owning at least one of its stages (see above): what the finish kernel sums over.
+__host__ __device__ inline int dwp_owner(const DwpPlan& p, long long c) { return (int)(((c + 1) * p.G - 1) / p.T); }
+
+// ---- round 5: the plan made ON THE DEVICE.  With live row counts (include/mnrf.h) the sample count of an evaluation -- the
+// reflected rays of a training step -- is known to the device only; dwp_plan_kernel writes this block from the counts, the
+// GEMM and the finish kernel read it (the launch is sized for the capacity, workgroups g >= plan.G leave at once).
+struct DwpDevPlan {
+    DwpPlan plan;
+    short g_lo[DWP_JOBS * DWP_MAX_EVAL], g_hi[DWP_JOBS * DWP_MAX_EVAL];     // owners of virtual job v (g_lo > g_hi: none)
+};
+constexpr int DWP_DEVPLAN_FLOATS = (int)((sizeof(DwpDevPlan) + 15) / 16 * 4);     // its room at the head of the workspace
+
 // smallest s with P + s w >= c, clamped to [0, n]   (32-bit division: 64-bit ones cost hundreds of instructions on the GPU)
 __host__ __device__ inline int dwp_first_stage_at(long long c, long long P, int w, int n) {
     const long long d = c - P;

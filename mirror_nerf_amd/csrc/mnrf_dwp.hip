@@ -44,6 +44,7 @@ struct DwpArgs {
     DwpEval ev[DWP_MAX_EVAL];
     DwpPlan plan;
     float* part;              // [G + DWP_JOBS * n_eval slots][DWP_SLOT_FLOATS]
+    const DwpDevPlan* dev;    // DEV kernels: the plan comes from here (dwp_plan_kernel), `plan` is unused
 };
 
 __device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -353,10 +354,12 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
     }
 }
 
-template <bool HALF>
+// DEV: the plan was made on the device (DwpDevPlan, live row counts); the launch has one workgroup per CU
+template <bool HALF, bool DEV = false>
 __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) {
     const int g = blockIdx.x;
-    const DwpPlan& p = A.plan;
+    const DwpPlan& p = DEV ? A.dev->plan : A.plan;
+    if (DEV && (g >= p.G || p.T == 0)) return;
     long long P = 0, c0, c1;
     dwp_interval(p, g, c0, c1);
     for (int j = 0; j < DWP_JOBS; ++j) {
@@ -423,6 +426,7 @@ struct DwpFinishArgs {
     int n_eval;
     int accumulate;
     short encpos[64];
+    const DwpDevPlan* dev;     // non-null: the owners come from the device plan instead of g_lo / g_hi
 };
 
 // scale exponent of an evaluation's dY planes: K puts the largest seed magnitude into [2^6, 2^7) (the backward kernel uses
@@ -471,9 +475,10 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
     for (int e = 0; e < F.n_eval; ++e) {
         const int v = job * F.n_eval + e;
         if (is_bias && F.kind[e]) continue;      // the second-order term has no bias gradient (its jobs write no bias sums)
-        if (F.g_lo[v] > F.g_hi[v]) continue;
+        const int g_lo = F.dev ? F.dev->g_lo[v] : F.g_lo[v], g_hi = F.dev ? F.dev->g_hi[v] : F.g_hi[v];
+        if (g_lo > g_hi) continue;
         f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int g = F.g_lo[v]; g <= F.g_hi[v]; ++g) {
+        for (int g = g_lo; g <= g_hi; ++g) {
             const float* src = F.part + (long long)(g + v) * DWP_SLOT_FLOATS + idx;
             if (is_bias) sum[0] += *src;
             else sum += *(const f32x4*)src;
@@ -501,7 +506,12 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
 __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* __restrict__ g_rgb, const float* __restrict__ g_pn,
                                 const float* __restrict__ g_m, const float* __restrict__ rgb, const float* __restrict__ pn,
                                 const float* __restrict__ is_mirror, const float* __restrict__ save_inv, long long B,
-                                unsigned* __restrict__ out) {
+                                unsigned* __restrict__ out, const int* __restrict__ n_live, int spr) {
+    if (n_live) {      // live row count: B is the capacity
+        long long bl = (long long)*n_live * spr;
+        bl = bl < 0 ? 0 : bl;
+        B = bl < B ? bl : B;
+    }
     float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
         if (g_sigma) mx = fmaxf(mx, fabsf(g_sigma[i]));
@@ -537,17 +547,23 @@ __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* 
 }
 
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
-                     const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s) {
+                     const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
+                     const int* n_live, int spr) {
     zero_fill(s, out, sizeof(unsigned));
     long long blocks = (B + 1023) / 1024;       // four samples per thread
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
-                       save_inv, B, out);
+                       save_inv, B, out, n_live, spr);
 }
 
 // largest |J^| (the seed of the second-order pass) exactly as field_split_bwd2_kernel's prologue forms it
 __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float* __restrict__ normal, const float* __restrict__ save_invj,
-                                long long B, unsigned* __restrict__ out) {
+                                long long B, unsigned* __restrict__ out, const int* __restrict__ n_live, int spr) {
+    if (n_live) {      // live row count: B is the capacity
+        long long bl = (long long)*n_live * spr;
+        bl = bl < 0 ? 0 : bl;
+        B = bl < B ? bl : B;
+    }
     float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
         const float inv = save_invj[i];
@@ -567,11 +583,12 @@ __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float*
     if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
 }
 
-void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s) {
+void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
+                     const int* n_live, int spr) {
     zero_fill(s, out, sizeof(unsigned));
     long long blocks = (B + 1023) / 1024;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out);
+    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out, n_live, spr);
 }
 
 // ---------------------------------------------------------------------------------------------------------- driver
@@ -601,57 +618,111 @@ long long dwp_workspace_floats(int n_eval, const int64_t* B, const int* kinds) {
     return (long long)(p.G + DWP_JOBS * n_eval) * DWP_SLOT_FLOATS;
 }
 
-int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
-               const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate, hipStream_t s) {
-    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return -1;
+// ---- the plan on the device (live row counts, mnrf_dwp.h DwpDevPlan)
+struct DwpPlanArgs {
+    int n_eval, cus;
+    int cap_sb[DWP_MAX_EVAL];            // sample blocks of the capacity
+    int kind[DWP_MAX_EVAL];
+    int spr[DWP_MAX_EVAL];
+    const int* n_live[DWP_MAX_EVAL];     // null: the capacity
+    DwpDevPlan* out;
+};
+__global__ void dwp_plan_kernel(DwpPlanArgs A) {
+    __shared__ DwpPlan sp;
+    if (threadIdx.x == 0) {
+        sp.n_eval = A.n_eval;
+        for (int e = 0; e < DWP_MAX_EVAL; ++e) {
+            int n = 0;
+            if (e < A.n_eval) {
+                n = A.cap_sb[e];
+                if (A.n_live[e]) {
+                    long long b = (long long)*A.n_live[e] * A.spr[e];
+                    b = b < 0 ? 0 : b;
+                    const long long live = dwp_sample_blocks(b);
+                    n = live < n ? (int)live : n;
+                }
+            }
+            sp.n_sb[e] = n;
+            sp.kind[e] = e < A.n_eval ? A.kind[e] : 0;
+        }
+        sp.T = dwp_total(sp);
+        sp.G = dwp_pick_G(sp.T, A.cus);
+        A.out->plan = sp;
+    }
+    __syncthreads();
+    const int v = threadIdx.x;
+    if (v >= DWP_JOBS * DWP_MAX_EVAL) return;
+    int lo = 1, hi = 0;
+    if (v < DWP_JOBS * A.n_eval && sp.T > 0) {
+        const int j = v / A.n_eval, e = v % A.n_eval;
+        long long P = 0;      // cost at which virtual job v starts: everything before it on the line (job-major)
+        for (int jj = 0; jj <= j; ++jj)
+            for (int ee = 0; ee < (jj < j ? A.n_eval : e); ++ee) P += (long long)dwp_stages(sp, jj, ee) * dwp_weight(jj);
+        const int n = dwp_stages(sp, j, e);
+        if (n > 0) {
+            lo = dwp_owner(sp, P);
+            hi = dwp_owner(sp, P + (long long)(n - 1) * dwp_weight(j));
+        }
+    }
+    A.out->g_lo[v] = (short)lo;
+    A.out->g_hi[v] = (short)hi;
+}
+
+long long dwp_workspace_floats_n(int n_eval) {
+    return DWP_DEVPLAN_FLOATS + (long long)(dwp_cus() + DWP_JOBS * n_eval) * DWP_SLOT_FLOATS;
+}
+
+// both plans: `plan` made on the host (dev == null) or on the device (dev: where dwp_plan_kernel left it; the launch then has
+// one workgroup per CU and `plan` carries n_eval / kinds only)
+static int dwp_run(const DwpPlan& plan, const DwpDevPlan* dev, int n_eval, const void* const* x_planes, const void* const* dy_planes,
+                   const unsigned* const* seedmax, const int* kinds, float* part, float* const* d_params, int accumulate, hipStream_t s) {
     DwpArgs A;
-    A.plan = dwp_make_plan(n_eval, B, kinds);
-    if (A.plan.T == 0) return accumulate ? 0 : -2;      // nothing to add; an overwrite of nothing is the caller's business
+    A.plan = plan;
+    A.dev = dev;
     for (int e = 0; e < n_eval; ++e) A.ev[e] = DwpEval{(const char*)x_planes[e], (const char*)dy_planes[e], seedmax[e]};
     for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr};
-    A.part = ws;
+    A.part = part;
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
         (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_RING_LDS);
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
+        (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_RING_LDS);
         return true;
     }();
     (void)once;
     // the ring of half-stages (dwp_segment_run_h) is the default; MNRF_DWP_RING=0 (read once) selects the two-buffer version
     static const bool ring = [] { const char* e = getenv("MNRF_DWP_RING"); return !(e && atoi(e) == 0); }();
-    if (ring) hipLaunchKernelGGL(dwp_gemm_kernel<true>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_RING_LDS, s, A);
-    else hipLaunchKernelGGL(dwp_gemm_kernel<false>, dim3(A.plan.G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    const int G = dev ? dwp_cus() : plan.G;
+    if (dev) {
+        if (ring) hipLaunchKernelGGL((dwp_gemm_kernel<true, true>), dim3(G), dim3(DWP_WG_THREADS), DWP_RING_LDS, s, A);
+        else hipLaunchKernelGGL((dwp_gemm_kernel<false, true>), dim3(G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    } else {
+        if (ring) hipLaunchKernelGGL(dwp_gemm_kernel<true>, dim3(G), dim3(DWP_WG_THREADS), DWP_RING_LDS, s, A);
+        else hipLaunchKernelGGL(dwp_gemm_kernel<false>, dim3(G), dim3(DWP_WG_THREADS), DWP_LDS, s, A);
+    }
 
     DwpFinishArgs F;
-    F.part = ws;
+    F.part = part;
     F.n_eval = n_eval;
     F.accumulate = accumulate;
+    F.dev = dev;
     for (int e = 0; e < DWP_MAX_EVAL; ++e) {
         F.seedmax[e] = e < n_eval ? seedmax[e] : nullptr;
-        F.kind[e] = A.plan.kind[e];
+        F.kind[e] = plan.kind[e];
         F.seed_log2[e] = 6 - ((e < n_eval && kinds) ? (kinds[e] >> 8) & 0xf : 0);      // (bits 8-11 of a kind: mnrf.h)
     }
-    // owners of every virtual job, from the same arithmetic the kernel uses
-    {
+    // owners of every virtual job (host plan), in closed form -- tests/csrc/dwp_plan_check.cpp holds it to the stage-by-stage search
+    for (int v = 0; v < DWP_JOBS * DWP_MAX_EVAL; ++v) { F.g_lo[v] = 1; F.g_hi[v] = 0; }
+    if (!dev) {
         long long P = 0;
         for (int j = 0; j < DWP_JOBS; ++j) {
             const int w = dwp_weight(j);
             for (int e = 0; e < n_eval; ++e) {
-                const int v = j * n_eval + e, n = dwp_stages(A.plan, j, e);
-                int lo = 1, hi = 0;
-                bool any = false;
-                for (int g = 0; g < A.plan.G; ++g) {
-                    int s_lo, s_hi;
-                    long long c0, c1;
-                    dwp_interval(A.plan, g, c0, c1);
-                    dwp_segment(c0, c1, P, w, n, s_lo, s_hi);
-                    if (s_hi > s_lo) {
-                        if (!any) lo = g;
-                        hi = g;
-                        any = true;
-                    }
+                const int v = j * n_eval + e, n = dwp_stages(plan, j, e);
+                if (n > 0) {
+                    F.g_lo[v] = (short)dwp_owner(plan, P);
+                    F.g_hi[v] = (short)dwp_owner(plan, P + (long long)(n - 1) * w);
                 }
-                F.g_lo[v] = (short)lo;
-                F.g_hi[v] = (short)hi;
                 P += (long long)n * w;
             }
         }
@@ -683,6 +754,36 @@ int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_pl
     layer(15, 1, 128, DwpSource{16, 0, 0, 0}, none, 128, 16, 0);                               // is_mirror_net.2
     hipLaunchKernelGGL(dwp_finish_kernel, dim3((64 * 319 + 256 + 255) / 256, 16), dim3(256), 0, s, F);      // (out_f / 4) x in_f + out_f threads at most
     return 0;
+}
+
+int launch_dwp(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+               const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate, hipStream_t s) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return -1;
+    const DwpPlan plan = dwp_make_plan(n_eval, B, kinds);
+    if (plan.T == 0) return accumulate ? 0 : -2;      // nothing to add; an overwrite of nothing is the caller's business
+    return dwp_run(plan, nullptr, n_eval, x_planes, dy_planes, seedmax, kinds, ws, d_params, accumulate, s);
+}
+
+int launch_dwp_n(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B, const int32_t* const* n_live,
+                 const int* spr, const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate,
+                 hipStream_t s) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return -1;
+    DwpPlan cap = dwp_make_plan(n_eval, B, kinds);      // capacities: n_eval, kinds (the device plan has the live counts)
+    DwpPlanArgs PA;
+    PA.n_eval = n_eval;
+    PA.cus = dwp_cus();
+    for (int e = 0; e < DWP_MAX_EVAL; ++e) {
+        PA.cap_sb[e] = cap.n_sb[e];
+        PA.kind[e] = cap.kind[e];
+        PA.spr[e] = e < n_eval && spr ? spr[e] : 1;
+        PA.n_live[e] = e < n_eval && n_live ? n_live[e] : nullptr;
+    }
+    DwpDevPlan* dev = (DwpDevPlan*)ws;
+    PA.out = dev;
+    hipLaunchKernelGGL(dwp_plan_kernel, dim3(1), dim3(192), 0, s, PA);
+    static_assert(DWP_JOBS * DWP_MAX_EVAL <= 192, "one thread per virtual job");
+    // with nothing live (T == 0) the GEMM workgroups leave at once and the finish kernel writes zeros (or adds nothing)
+    return dwp_run(cap, dev, n_eval, x_planes, dy_planes, seedmax, kinds, ws + DWP_DEVPLAN_FLOATS, d_params, accumulate, s);
 }
 
 }  // namespace mnrf

@@ -215,11 +215,13 @@ extern "C" int64_t mnrf_train_save_floats(int64_t B) { return (int64_t)SAVE_FLOA
 extern "C" int64_t mnrf_train_mask_words(int64_t B) { return train_tiles(B) * N_MASKS * s2::S * s2::WG_THREADS; }
 extern "C" int64_t mnrf_train_workspace_floats(int64_t B) { return (int64_t)DY_FLOATS * B + dw_workspace_floats(B); }
 
-extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
-                                        const float* rays, const float* z_vals, int spr, const float* dir_emb,
-                                        int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
-                                        float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
-                                        float* save_inv, float* save_invj, unsigned flags, void* stream) {
+static int field_forward_train_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                    const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                                    int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                    float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                                    float* save_inv, float* save_invj, unsigned flags, const int32_t* n_live, void* stream) {
+    if (n_live && !(flags & MNRF_TRAIN_PLANES))
+        return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_field_forward_train_n: a live row count needs MNRF_TRAIN_PLANES (the fp32-row layout depends on B)");
     if (!packed || !save_x || !save_mask || !save_inv) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: null pointer");
     const bool planes = flags & MNRF_TRAIN_PLANES;
     if (planes && !(flags & MNRF_SPLIT_F16))
@@ -232,6 +234,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
     FieldArgs A{packed, MNRF_GRAD_NORMAL, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, dir_emb,
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
                 planes ? nullptr : save_x, (unsigned long long*)save_mask, save_inv, save_invj, planes ? (char*)save_x : nullptr};
+    A.n_live = n_live;
     // always a 128-sample tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map.
     // MNRF_SPLIT_F16: the split-f16 tuning (same saved quantities, fp32 activations from its fp32 accumulators)
     const int rc = (flags & MNRF_SPLIT_F16) ? launch_split(A, false, true, 0, (hipStream_t)stream)
@@ -239,6 +242,22 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
     if (rc != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_forward_train");
+}
+extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                        const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                                        int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                        float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                                        float* save_inv, float* save_invj, unsigned flags, void* stream) {
+    return field_forward_train_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, dir_emb, dir_stride, sigma, rgb, pred_normal, is_mirror,
+                                    normal, save_x, save_mask, save_inv, save_invj, flags, nullptr, stream);
+}
+extern "C" int mnrf_field_forward_train_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                          const float* rays, const float* z_vals, int spr, const float* dir_emb,
+                                          int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                          float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
+                                          float* save_inv, float* save_invj, unsigned flags, const int32_t* n_live, void* stream) {
+    return field_forward_train_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, dir_emb, dir_stride, sigma, rgb, pred_normal, is_mirror,
+                                    normal, save_x, save_mask, save_inv, save_invj, flags, n_live, stream);
 }
 
 extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
@@ -276,6 +295,30 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
 extern "C" int64_t mnrf_train_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLX_SB_BYTES; }
 extern "C" int64_t mnrf_train_dy_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLY_SB_BYTES; }
 
+static int field_backward_planes_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                      const float* rays, const float* z_vals, int spr,
+                                      const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                      const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                                      const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
+                                      void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir,
+                                      const float* keep_mirror, unsigned flags, const int32_t* n_live, void* stream) {
+    if (!packed || !save_mask || !save_inv || !dy_planes || !seedmax)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: null pointer");
+    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: negative sample count");
+    if (!rgb || !pred_normal || !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: forward outputs missing");
+    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: need xyz or rays+z_vals");
+    hipStream_t s = (hipStream_t)stream;
+    if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: bad spr");
+    launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s, n_live, spr);
+    FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
+                   g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
+                   flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
+                   6 - (int)((flags >> 16) & 0xfu)};
+    A.n_live = n_live;
+    if (launch_split_bwd(A, s) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
+    return mnrf_check_launch("mnrf_field_backward_planes");
+}
 extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                           const float* rays, const float* z_vals, int spr,
                                           const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
@@ -283,20 +326,20 @@ extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const 
                                           const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
                                           void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir,
                                           const float* keep_mirror, unsigned flags, void* stream) {
-    if (!packed || !save_mask || !save_inv || !dy_planes || !seedmax)
-        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: null pointer");
-    if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: negative sample count");
-    if (!rgb || !pred_normal || !is_mirror) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: forward outputs missing");
-    if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: need xyz or rays+z_vals");
-    hipStream_t s = (hipStream_t)stream;
-    launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s);
-    FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
-                   g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
-                   flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
-                   6 - (int)((flags >> 16) & 0xfu)};
-    if (launch_split_bwd(A, s) != 0)
-        return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
-    return mnrf_check_launch("mnrf_field_backward_planes");
+    return field_backward_planes_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb,
+                                      pred_normal, is_mirror, save_mask, save_inv, dy_planes, seedmax, d_xyz, d_dir, keep_mirror, flags,
+                                      nullptr, stream);
+}
+extern "C" int mnrf_field_backward_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                            const float* rays, const float* z_vals, int spr,
+                                            const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                            const float* g_is_mirror, const float* rgb, const float* pred_normal,
+                                            const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
+                                            void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir,
+                                            const float* keep_mirror, unsigned flags, const int32_t* n_live, void* stream) {
+    return field_backward_planes_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb,
+                                      pred_normal, is_mirror, save_mask, save_inv, dy_planes, seedmax, d_xyz, d_dir, keep_mirror, flags,
+                                      n_live, stream);
 }
 
 extern "C" int64_t mnrf_dw_planes_workspace_floats(int n_eval, const int64_t* B) {
@@ -334,24 +377,67 @@ extern "C" int mnrf_dw_planes2(int n_eval, const void* const* x_planes, const vo
     return mnrf_check_launch("mnrf_dw_planes");
 }
 
+extern "C" int64_t mnrf_dw_planes2_n_workspace_floats(int n_eval) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return 0;
+    return dwp_workspace_floats_n(n_eval);
+}
+extern "C" int mnrf_dw_planes2_n(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
+                                 const int32_t* const* n_live, const int* spr, const uint32_t* const* seedmax, const int* kinds,
+                                 float* workspace, float* const* d_params, int accumulate, void* stream) {
+    if (n_eval < 1 || n_eval > DWP_MAX_EVAL) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: 1..8 evaluations per call");
+    if (!x_planes || !dy_planes || !B || !seedmax || !workspace || !d_params || !n_live || !spr)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: null pointer");
+    long long total = 0;
+    for (int e = 0; e < n_eval; ++e) {
+        if (B[e] <= 0 || spr[e] < 1 || !x_planes[e] || !dy_planes[e] || !seedmax[e])
+            return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: every evaluation needs a capacity B > 0, spr >= 1 and its three buffers");
+        total += dwp_sample_blocks(B[e]);
+    }
+    if (total * (812 + DWP_JOBS * DWP_STAGE_KIB) >= (1LL << 31)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: too many samples for one call (split the evaluations)");
+    for (int i = 0; i < MNRF_N_PARAMS; ++i)
+        if (!d_params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: null gradient pointer");
+    if (launch_dwp_n(n_eval, x_planes, dy_planes, B, n_live, spr, (const unsigned* const*)seedmax, kinds, workspace, d_params,
+                     accumulate ? 1 : 0, (hipStream_t)stream) != 0)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_dw_planes2_n: bad plan");
+    return mnrf_check_launch("mnrf_dw_planes2_n");
+}
+
 extern "C" int64_t mnrf_train_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2X_SB_BYTES; }
 extern "C" int64_t mnrf_train_dy_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2Y_SB_BYTES; }
 
-extern "C" int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
-                                           const float* rays, const float* z_vals, int spr, const float* g_normal,
-                                           const float* normal, const float* save_invj, const uint64_t* save_mask,
-                                           void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream) {
+static int field_backward2_planes_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                       const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                       const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                       void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, const int32_t* n_live,
+                                       void* stream) {
     if (!packed || !g_normal || !normal || !save_invj || !save_mask || !x2_planes || !y2_planes || !jmax)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: null pointer");
     if (B <= 0) return B == 0 ? MNRF_OK : mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: negative sample count");
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: need xyz or rays+z_vals");
     hipStream_t s = (hipStream_t)stream;
-    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s);
+    if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: bad spr");
+    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s, n_live, spr);
     FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
                     (const unsigned long long*)save_mask, nullptr, d_xyz, (char*)x2_planes, (char*)y2_planes, jmax};
+    A.n_live = n_live;
     if (launch_split_bwd2(A, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_backward2_planes");
+}
+extern "C" int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                           const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                           const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                           void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream) {
+    return field_backward2_planes_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj, save_mask, x2_planes,
+                                       y2_planes, jmax, d_xyz, nullptr, stream);
+}
+extern "C" int mnrf_field_backward2_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+                                             const float* rays, const float* z_vals, int spr, const float* g_normal,
+                                             const float* normal, const float* save_invj, const uint64_t* save_mask,
+                                             void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz,
+                                             const int32_t* n_live, void* stream) {
+    return field_backward2_planes_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj, save_mask, x2_planes,
+                                       y2_planes, jmax, d_xyz, n_live, stream);
 }
 
 extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_FLOATS * B + dw2_workspace_floats(B); }

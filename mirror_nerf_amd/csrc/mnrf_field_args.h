@@ -51,6 +51,10 @@ struct FieldArgs {
     int white_back;
     float* f_weights;              // (n_rays, spr) or null
     float* f_opacity; float* f_rgb_map; float* f_depth; float* f_mirror_mask; float* f_surf_normal; float* f_x_surface;
+    // live row count (round 5, include/mnrf.h "live row counts on the device"): device int32 or null.  B is then the CAPACITY the
+    // launch and the buffers are sized for, the kernel evaluates the first *n_live * spr samples (workgroups past them leave at
+    // once).  Training forward with operand planes only (the fp32-row layouts depend on B).
+    const int* n_live;
 };
 
 // training backward (activation gradients): mnrf_field_bwd.inc (fp32) and mnrf_field_split_bwd.inc (split-f16)
@@ -76,6 +80,7 @@ struct FieldBwdArgs {
     // lowers it when scaled gradients outgrow the f16 range (trained weights amplify them on the way down the trunk) -- the
     // weight-gradient GEMM's finish kernel must be told the same number (mnrf_dw_planes2: kinds)
     int seed_log2;
+    const int* n_live;          // live rows (B = capacity): see FieldArgs::n_live; planes route only
 };
 // second-order pass (gradient through the density-gradient normal)
 struct FieldBwd2Args {
@@ -93,6 +98,7 @@ struct FieldBwd2Args {
     char* x2_planes;           // [sample blocks][PL2X_FB][hi | lo][1 KiB]
     char* y2_planes;           // [sample blocks][PL2Y_FB][hi | lo][1 KiB]
     const unsigned* jmax;
+    const int* n_live;         // live rows (B = capacity): see FieldArgs::n_live; planes route only
 };
 
 // split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.

@@ -25,9 +25,16 @@ struct AdamArgs {
     int* skipped;              // device: how many of them found_inf has skipped so far
     const float* grad_scale;   // device scalars or null
     const float* found_inf;
+    // device-resident hyper-parameters and step count (mnrf_adam_step_dev: a step captured in a hipGraph must not freeze them)
+    const double* hyper;       // [lr, beta1, beta2, eps, weight_decay] or null
+    const long long* step_dev; // the count of step() calls, this one included, or null
 };
 
 __global__ void adam_kernel(AdamArgs A) {
+    if (A.hyper) {
+        A.lr = (float)A.hyper[0]; A.beta1 = A.hyper[1]; A.beta2 = A.hyper[2]; A.eps = (float)A.hyper[3]; A.wd = (float)A.hyper[4];
+        A.step = *A.step_dev;
+    }
     if (A.found_inf && *A.found_inf != 0.f) {      // the whole grid leaves; one thread records that this call did not count
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.skipped, 1);
         return;
@@ -90,8 +97,34 @@ extern "C" int mnrf_adam_step(float* param, const float* grad, float* exp_avg, f
     if (n == 0) return MNRF_OK;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step: tensors must be 16-byte aligned");
-    AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, eps, weight_decay, beta1, beta2, (long long)step, skipped, grad_scale, found_inf};
+    AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, eps, weight_decay, beta1, beta2, (long long)step, skipped, grad_scale, found_inf,
+               nullptr, nullptr};
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step");
+}
+
+// counter += delta, one thread (the step count of mnrf_adam_step_dev inside a captured step)
+namespace mnrf {
+__global__ void add_i64_kernel(long long* c, long long d) { *c += d; }
+}  // namespace mnrf
+extern "C" int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream) {
+    if (!counter) return mnrf_fail(MNRF_ERR_ARG, "mnrf_add_i64: null pointer");
+    hipLaunchKernelGGL(mnrf::add_i64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)counter, (long long)delta);
+    return mnrf_check_launch("mnrf_add_i64");
+}
+
+extern "C" int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
+                                  const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf, void* stream) {
+    using namespace mnrf;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !skipped || !hyper || !step) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null pointer");
+    if (n < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: n >= 0");
+    if (n == 0) return MNRF_OK;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: tensors must be 16-byte aligned");
+    AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, 0.f, 0.f, 0.f, 0.0, 0.0, 1, skipped, grad_scale, found_inf, hyper,
+               (const long long*)step};
+    const long long threads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_adam_step_dev");
 }

@@ -38,6 +38,14 @@ namespace {
 
 constexpr float EPS32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps, utils/func.py:5
 
+// Live row count of the `_n` entry points (include/mnrf.h "live row counts on the device"): the launch is sized for the capacity
+// `cap`, *n_live (device, written by an earlier launch on the stream: mnrf_reflect_compact's count) says how many rows exist.
+__device__ __forceinline__ long long live_rows(long long cap, const int* __restrict__ n_live) {
+    if (!n_live) return cap;
+    const long long v = *n_live;
+    return v < 0 ? 0 : (v < cap ? v : cap);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -47,9 +55,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ------------------------------------------------------------------ Embedding.forward
 // models/mirror_nerf.py:20-38: out = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)]
-__global__ void embed_kernel(const float* __restrict__ x, long long n, int c, int n_freqs, float* __restrict__ out) {
+__global__ void embed_kernel(const float* __restrict__ x, long long n, int c, int n_freqs, float* __restrict__ out,
+                             const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * c) return;
+    if (i >= live_rows(n, n_live) * c) return;
     const long long row = i / c;
     const int ch = (int)(i % c);
     const int ld = c * (2 * n_freqs + 1);
@@ -68,9 +77,9 @@ __global__ void embed_kernel(const float* __restrict__ x, long long n, int c, in
 // models/rendering.py:283-300
 __global__ void sample_coarse_kernel(const float* __restrict__ rays, long long n_rays, const float* __restrict__ z_steps,
                                      int ns, int use_disp, float perturb, const float* __restrict__ prand,
-                                     float* __restrict__ z_out) {
+                                     float* __restrict__ z_out, const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rays * ns) return;
+    if (i >= live_rows(n_rays, n_live) * ns) return;
     const long long r = i / ns;
     const int s = (int)(i % ns);
     const float near = rays[r * 8 + 6], far = rays[r * 8 + 7];
@@ -98,6 +107,7 @@ struct CompArgs {
     const float* pred_normal; const float* normal; int white_back;
     float* weights; float* opacity; float* rgb_map; float* depth; float* mirror_mask;
     float* surf_normal; float* surf_normal_grad; float* normal_dif; float* x_surface;
+    const int* n_live;
 };
 
 // per-sample inputs of one ray straight from the flat (n_rays * S) tensors in HBM
@@ -121,7 +131,7 @@ struct CompGlobalSrc {
 __global__ __launch_bounds__(256) void composite_kernel(CompArgs A) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= A.n_rays) return;
+    if (ray >= live_rows(A.n_rays, A.n_live)) return;
     const CompGlobalSrc src{A, ray};
     const CompMaps out{A.weights ? A.weights + ray * A.S : nullptr, A.opacity, A.rgb_map, A.depth, A.mirror_mask, A.surf_normal,
                        A.surf_normal_grad, A.normal_dif, A.x_surface, A.rays, A.white_back};
@@ -146,13 +156,14 @@ struct CompBwdArgs {
     // gradient steering (models/rendering.py:222-264): which composited outputs see the weights as constants
     int detach;                 // MNRF_DETACH_W_MASK: mirror mask of every ray; MNRF_DETACH_W_NORMAL: the three normal outputs
     const float* keep_mirror;   // (n_rays) or null: rays whose entry is 0 see detached weights in the mirror mask
+    const int* n_live;
 };
 constexpr int CB_MAXB = 4;
 
 __global__ __launch_bounds__(256) void composite_backward_kernel(CompBwdArgs A) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= A.n_rays) return;
+    if (ray >= live_rows(A.n_rays, A.n_live)) return;
     const int S = A.S;
     const float* r8 = A.rays ? A.rays + ray * 8 : nullptr;
     float gop = A.g_op ? A.g_op[ray] : 0.f;
@@ -301,13 +312,15 @@ __device__ __forceinline__ void sort_store(const float* srt, int lane, float* ou
 
 __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
                                                           long long n_rays, int S, const float* __restrict__ u, int u_per_ray,
-                                                          int n_imp, float* __restrict__ z_fine) {
+                                                          int n_imp, float* __restrict__ z_fine, const int* __restrict__ n_live) {
     __shared__ float s_cdf[4][256];
     __shared__ float s_bin[4][256];
     __shared__ float s_sort[4][SF_MAX];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     long long ray = (long long)blockIdx.x * 4 + wv;
+    n_rays = live_rows(n_rays, n_live);
+    if ((long long)blockIdx.x * 4 >= n_rays) return;      // (the whole workgroup: the barriers below stay uniform)
     const bool live = ray < n_rays;
     if (!live) ray = n_rays - 1;
     const float* zc = z_coarse + ray * S;
@@ -373,10 +386,10 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 
 // ------------------------------------------------------------------ mask threshold
 // train.py:165-166 / eval.py:305-306: m[m>0.5]=1; m[m<0.5]=0 (exactly 0.5 stays), any(m != 0)
-__global__ void threshold_kernel(float* __restrict__ m, long long n, int* __restrict__ any) {
+__global__ void threshold_kernel(float* __restrict__ m, long long n, int* __restrict__ any, const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool nz = false;
-    if (i < n) {
+    if (i < live_rows(n, n_live)) {
         float v = m[i];
         if (v > 0.5f) v = 1.f;
         else if (v < 0.5f) v = 0.f;
@@ -393,6 +406,7 @@ struct ReflArgs {
     const float* rays; const float* x_surface; const float* normal; const float* normal_noise; float noise_std;
     const float* mask; long long n; int compact; float near2;
     float* sec; int* index; int* count; float* reflect_dir;
+    const int* n_live;
 };
 
 __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
+    A.n = live_rows(A.n, A.n_live);
     for (long long start = 0; start < A.n; start += 1024) {
         const long long i = start + tid;
         const bool in = i < A.n;
@@ -452,6 +467,7 @@ __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
 // per ray over the whole chip instead of one workgroup walking the chunk (158 us per 32768-ray chunk, 3 ms per frame).
 __global__ __launch_bounds__(256) void reflect_all_kernel(ReflArgs A) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    A.n = live_rows(A.n, A.n_live);
     if (i == 0) *A.count = (int)A.n;
     if (i >= A.n) return;
     float nv[3], wvv[3], r[3];
@@ -481,9 +497,10 @@ __global__ __launch_bounds__(256) void reflect_all_kernel(ReflArgs A) {
 // ------------------------------------------------------------------ blend / scatter
 // train.py:261-296, eval.py:676-697
 __global__ void blend_all_kernel(const float* __restrict__ base, const float* __restrict__ sec, const float* __restrict__ mask,
-                                 long long n, int c, int direct, float* __restrict__ out, float* __restrict__ refl) {
+                                 long long n, int c, int direct, float* __restrict__ out, float* __restrict__ refl,
+                                 const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * c) return;
+    if (i >= live_rows(n, n_live) * c) return;
     const float m = mask[i / c];
     const float b = base[i];
     const float part = direct ? sec[i] : b;   // compacted case: rows without a source keep base
@@ -493,9 +510,9 @@ __global__ void blend_all_kernel(const float* __restrict__ base, const float* __
 
 __global__ void blend_scatter_kernel(const float* __restrict__ base, const float* __restrict__ sec, const int* __restrict__ index,
                                      long long n_sec, const float* __restrict__ mask, int c, float* __restrict__ out,
-                                     float* __restrict__ refl) {
+                                     float* __restrict__ refl, const int* __restrict__ n_sec_live) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_sec * c) return;
+    if (j >= live_rows(n_sec, n_sec_live) * c) return;
     const long long row = index[j / c];
     const int ch = (int)(j % c);
     const float m = mask[row];
@@ -529,9 +546,10 @@ __global__ void generate_rays_kernel(int H, int W, float focal, Pose c2w, float 
 // reflect: r = 2 (w.n) n - w with n = l2n(normal), w = l2n(-d); secondary = [x_surface, r, near2, far]
 __global__ void reflect_backward_kernel(const float* __restrict__ rays, const float* __restrict__ normal,
                                         const int* __restrict__ index, long long n_sec, const float* __restrict__ g_sec,
-                                        float* __restrict__ g_xs, float* __restrict__ g_normal, float* __restrict__ g_rays) {
+                                        float* __restrict__ g_xs, float* __restrict__ g_normal, float* __restrict__ g_rays,
+                                        const int* __restrict__ n_sec_live) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_sec) return;
+    if (j >= live_rows(n_sec, n_sec_live)) return;
     const long long i = index ? index[j] : j;
     float nv[3], wv[3], gr[3];
 #pragma unroll
@@ -560,24 +578,25 @@ __global__ void reflect_backward_kernel(const float* __restrict__ rays, const fl
 
 // blend: out = m*part + (1-m)*base, part = sec scattered by index (rows without a source: base.detach())
 __global__ void blend_backward_kernel(const float* __restrict__ g_out, const float* __restrict__ mask, long long n, int c,
-                                      float* __restrict__ g_base) {
+                                      float* __restrict__ g_base, const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * c) return;
+    if (i >= live_rows(n, n_live) * c) return;
     g_base[i] = (1.f - mask[i / c]) * g_out[i];
 }
 __global__ void blend_backward_sec_kernel(const float* __restrict__ g_out, const float* __restrict__ mask,
-                                          const int* __restrict__ index, long long n_sec, int c, float* __restrict__ g_sec) {
+                                          const int* __restrict__ index, long long n_sec, int c, float* __restrict__ g_sec,
+                                          const int* __restrict__ n_sec_live) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_sec * c) return;
+    if (j >= live_rows(n_sec, n_sec_live) * c) return;
     const long long row = index ? index[j / c] : j / c;
     g_sec[j] = mask[row] * g_out[row * c + (j % c)];
 }
 
 // Embedding backward: dx = g_x + sum_k 2^k (g_sin_k cos(2^k x) - g_cos_k sin(2^k x))
 __global__ void embed_backward_kernel(const float* __restrict__ x, const float* __restrict__ g, long long n, int c,
-                                      int n_freqs, float* __restrict__ gx) {
+                                      int n_freqs, float* __restrict__ gx, const int* __restrict__ n_live) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * c) return;
+    if (i >= live_rows(n, n_live) * c) return;
     const long long row = i / c;
     const int ch = (int)(i % c);
     const int ld = c * (2 * n_freqs + 1);
@@ -597,31 +616,47 @@ inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + th
 }  // namespace
 
 // ====================================================================== C ABI
-extern "C" int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* stream) {
+// Every entry point with a row count exists twice: `mnrf_x(..., stream)` and `mnrf_x_n(..., n_live, stream)` (include/mnrf.h
+// "live row counts on the device"); both are the `_impl` below, the first with n_live = null.
+static int embed_impl(const float* x, int64_t n, int c, int n_freqs, float* out, const int32_t* n_live, void* stream) {
     if (n < 0 || c < 1 || n_freqs < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed: bad size");
     if (n == 0) return MNRF_OK;
     if (!x || !out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed: null pointer");
     hipLaunchKernelGGL(embed_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, c,
-                       n_freqs, out);
+                       n_freqs, out, n_live);
     return mnrf_check_launch("mnrf_embed");
 }
+extern "C" int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* stream) {
+    return embed_impl(x, n, c, n_freqs, out, nullptr, stream);
+}
+extern "C" int mnrf_embed_n(const float* x, int64_t n, int c, int n_freqs, float* out, const int32_t* n_live, void* stream) {
+    return embed_impl(x, n, c, n_freqs, out, n_live, stream);
+}
 
-extern "C" int mnrf_sample_coarse(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp,
-                                  float perturb, const float* perturb_rand, float* z_vals, void* stream) {
+static int sample_coarse_impl(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp,
+                              float perturb, const float* perturb_rand, float* z_vals, const int32_t* n_live, void* stream) {
     if (n_rays < 0 || n_samples < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: bad size");
     if (n_rays == 0) return MNRF_OK;
     if (!rays || !z_steps || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: null pointer");
     if (perturb > 0.f && !perturb_rand) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_coarse: perturb > 0 needs perturb_rand");
     hipLaunchKernelGGL(sample_coarse_kernel, dim3(blocks_for(n_rays * n_samples, 256)), dim3(256), 0, (hipStream_t)stream,
-                       rays, (long long)n_rays, z_steps, n_samples, use_disp, perturb, perturb_rand, z_vals);
+                       rays, (long long)n_rays, z_steps, n_samples, use_disp, perturb, perturb_rand, z_vals, n_live);
     return mnrf_check_launch("mnrf_sample_coarse");
 }
+extern "C" int mnrf_sample_coarse(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp,
+                                  float perturb, const float* perturb_rand, float* z_vals, void* stream) {
+    return sample_coarse_impl(rays, n_rays, z_steps, n_samples, use_disp, perturb, perturb_rand, z_vals, nullptr, stream);
+}
+extern "C" int mnrf_sample_coarse_n(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp,
+                                    float perturb, const float* perturb_rand, float* z_vals, const int32_t* n_live, void* stream) {
+    return sample_coarse_impl(rays, n_rays, z_steps, n_samples, use_disp, perturb, perturb_rand, z_vals, n_live, stream);
+}
 
-extern "C" int mnrf_composite(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
-                              const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
-                              const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
-                              float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
-                              float* normal_dif, float* x_surface, void* stream) {
+static int composite_impl(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                          const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
+                          const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
+                          float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
+                          float* normal_dif, float* x_surface, const int32_t* n_live, void* stream) {
     if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: bad size");
     if (n_rays == 0) return MNRF_OK;
     if (!sigma || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: sigma and z_vals are required");
@@ -632,21 +667,37 @@ extern "C" int mnrf_composite(const float* rays, int64_t n_rays, int S, const fl
     if (normal_dif && !(normal && pred_normal)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: normal_dif needs both normals");
     if (x_surface && !rays) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: x_surface needs rays");
     CompArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
-               weights, opacity, rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface};
+               weights, opacity, rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, n_live};
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_composite");
 }
+extern "C" int mnrf_composite(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                              const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
+                              const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
+                              float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
+                              float* normal_dif, float* x_surface, void* stream) {
+    return composite_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, opacity,
+                          rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, nullptr, stream);
+}
+extern "C" int mnrf_composite_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
+                                const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
+                                float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
+                                float* normal_dif, float* x_surface, const int32_t* n_live, void* stream) {
+    return composite_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, opacity,
+                          rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, n_live, stream);
+}
 
-extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
-                                       const float* noise, const float* rgb, const float* is_mirror,
-                                       const float* pred_normal, const float* normal, int white_back,
-                                       const float* weights, const float* depth, const float* g_weights,
-                                       const float* g_opacity, const float* g_rgb_map, const float* g_depth,
-                                       const float* g_mirror_mask, const float* g_surf_normal,
-                                       const float* g_surf_normal_grad, const float* g_normal_dif,
-                                       const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
-                                       float* d_pred_normal, float* d_normal, float* d_rays, int detach,
-                                       const float* keep_mirror, void* stream) {
+static int composite_backward_impl(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                   const float* noise, const float* rgb, const float* is_mirror,
+                                   const float* pred_normal, const float* normal, int white_back,
+                                   const float* weights, const float* depth, const float* g_weights,
+                                   const float* g_opacity, const float* g_rgb_map, const float* g_depth,
+                                   const float* g_mirror_mask, const float* g_surf_normal,
+                                   const float* g_surf_normal_grad, const float* g_normal_dif,
+                                   const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
+                                   float* d_pred_normal, float* d_normal, float* d_rays, int detach,
+                                   const float* keep_mirror, const int32_t* n_live, void* stream) {
     (void)weights;   // recomputed in-kernel from sigma and z (cheaper than reading them back)
     if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: bad size");
     if (S > 64 * CB_MAXB) return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_composite_backward: needs S <= 256");
@@ -661,51 +712,109 @@ extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S,
     if (d_rays && !depth) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_backward: d_rays needs the forward depth");
     CompBwdArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
                   depth, g_weights, g_opacity, g_rgb_map, g_depth, g_mirror_mask, g_surf_normal, g_surf_normal_grad,
-                  g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays, detach, keep_mirror};
+                  g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays, detach, keep_mirror, n_live};
     hipLaunchKernelGGL(composite_backward_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_composite_backward");
 }
+extern "C" int mnrf_composite_backward(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                       const float* noise, const float* rgb, const float* is_mirror,
+                                       const float* pred_normal, const float* normal, int white_back,
+                                       const float* weights, const float* depth, const float* g_weights,
+                                       const float* g_opacity, const float* g_rgb_map, const float* g_depth,
+                                       const float* g_mirror_mask, const float* g_surf_normal,
+                                       const float* g_surf_normal_grad, const float* g_normal_dif,
+                                       const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
+                                       float* d_pred_normal, float* d_normal, float* d_rays, int detach,
+                                       const float* keep_mirror, void* stream) {
+    return composite_backward_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, depth,
+                                   g_weights, g_opacity, g_rgb_map, g_depth, g_mirror_mask, g_surf_normal, g_surf_normal_grad,
+                                   g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays, detach,
+                                   keep_mirror, nullptr, stream);
+}
+extern "C" int mnrf_composite_backward_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                         const float* noise, const float* rgb, const float* is_mirror,
+                                         const float* pred_normal, const float* normal, int white_back,
+                                         const float* weights, const float* depth, const float* g_weights,
+                                         const float* g_opacity, const float* g_rgb_map, const float* g_depth,
+                                         const float* g_mirror_mask, const float* g_surf_normal,
+                                         const float* g_surf_normal_grad, const float* g_normal_dif,
+                                         const float* g_x_surface, float* d_sigma, float* d_rgb, float* d_is_mirror,
+                                         float* d_pred_normal, float* d_normal, float* d_rays, int detach,
+                                         const float* keep_mirror, const int32_t* n_live, void* stream) {
+    return composite_backward_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, depth,
+                                   g_weights, g_opacity, g_rgb_map, g_depth, g_mirror_mask, g_surf_normal, g_surf_normal_grad,
+                                   g_normal_dif, g_x_surface, d_sigma, d_rgb, d_is_mirror, d_pred_normal, d_normal, d_rays, detach,
+                                   keep_mirror, n_live, stream);
+}
 
-extern "C" int mnrf_sample_fine(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,
-                                int u_per_ray, int n_importance, float* z_fine, void* stream) {
+static int sample_fine_impl(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,
+                            int u_per_ray, int n_importance, float* z_fine, const int32_t* n_live, void* stream) {
     if (n_rays < 0 || S < 3 || n_importance < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_fine: bad size");
     if (S > 256 || S + n_importance > SF_MAX)
         return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_sample_fine: needs S <= 256 and S + n_importance <= 512");
     if (n_rays == 0) return MNRF_OK;
     if (!z_coarse || !weights || !u || !z_fine) return mnrf_fail(MNRF_ERR_ARG, "mnrf_sample_fine: null pointer");
     hipLaunchKernelGGL(sample_fine_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, z_coarse, weights,
-                       (long long)n_rays, S, u, u_per_ray, n_importance, z_fine);
+                       (long long)n_rays, S, u, u_per_ray, n_importance, z_fine, n_live);
     return mnrf_check_launch("mnrf_sample_fine");
 }
+extern "C" int mnrf_sample_fine(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,
+                                int u_per_ray, int n_importance, float* z_fine, void* stream) {
+    return sample_fine_impl(z_coarse, weights, n_rays, S, u, u_per_ray, n_importance, z_fine, nullptr, stream);
+}
+extern "C" int mnrf_sample_fine_n(const float* z_coarse, const float* weights, int64_t n_rays, int S, const float* u,
+                                  int u_per_ray, int n_importance, float* z_fine, const int32_t* n_live, void* stream) {
+    return sample_fine_impl(z_coarse, weights, n_rays, S, u, u_per_ray, n_importance, z_fine, n_live, stream);
+}
 
-extern "C" int mnrf_threshold_mask(float* mask, int64_t n, int32_t* any, void* stream) {
+static int threshold_impl(float* mask, int64_t n, int32_t* any, const int32_t* n_live, void* stream) {
     if (n < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_threshold_mask: bad size");
     if (n == 0) return MNRF_OK;
     if (!mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_threshold_mask: null pointer");
-    hipLaunchKernelGGL(threshold_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long long)n, any);
+    hipLaunchKernelGGL(threshold_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mask, (long long)n, any, n_live);
     return mnrf_check_launch("mnrf_threshold_mask");
 }
+extern "C" int mnrf_threshold_mask(float* mask, int64_t n, int32_t* any, void* stream) { return threshold_impl(mask, n, any, nullptr, stream); }
+extern "C" int mnrf_threshold_mask_n(float* mask, int64_t n, int32_t* any, const int32_t* n_live, void* stream) {
+    return threshold_impl(mask, n, any, n_live, stream);
+}
 
-extern "C" int mnrf_reflect_compact(const float* rays, const float* x_surface, const float* normal,
-                                    const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
-                                    int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
-                                    float* reflect_dir, void* stream) {
+static int reflect_compact_impl(const float* rays, const float* x_surface, const float* normal,
+                                const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
+                                int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
+                                float* reflect_dir, const int32_t* n_live, void* stream) {
     if (n_rays < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: bad size");
     if (!count) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: count is null");
     if (n_rays > 0 && (!rays || !x_surface || !normal || !sec_rays || !index))
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: null pointer");
     if (compact && n_rays > 0 && !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: compaction needs the mask");
     ReflArgs A{rays, x_surface, normal, normal_noise, noise_std, mask, (long long)n_rays, compact, near2,
-               sec_rays, index, count, reflect_dir};
+               sec_rays, index, count, reflect_dir, n_live};
     if (!compact && n_rays > 0)
         hipLaunchKernelGGL(reflect_all_kernel, dim3(blocks_for(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, A);
     else
         hipLaunchKernelGGL(reflect_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_reflect_compact");
 }
+extern "C" int mnrf_reflect_compact(const float* rays, const float* x_surface, const float* normal,
+                                    const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
+                                    int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
+                                    float* reflect_dir, void* stream) {
+    return reflect_compact_impl(rays, x_surface, normal, normal_noise, noise_std, mask, n_rays, compact, near2, sec_rays, index, count,
+                                reflect_dir, nullptr, stream);
+}
+extern "C" int mnrf_reflect_compact_n(const float* rays, const float* x_surface, const float* normal,
+                                      const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
+                                      int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
+                                      float* reflect_dir, const int32_t* n_live, void* stream) {
+    return reflect_compact_impl(rays, x_surface, normal, normal_noise, noise_std, mask, n_rays, compact, near2, sec_rays, index, count,
+                                reflect_dir, n_live, stream);
+}
 
-extern "C" int mnrf_blend_scatter(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
-                                  const float* mask, int64_t n, int c, float* out, float* reflect_out, void* stream) {
+// n_live: live rows of base / mask / out (null: n); n_sec_live: live rows of sec / index (null: n_sec)
+static int blend_scatter_impl(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                              const float* mask, int64_t n, int c, float* out, float* reflect_out, const int32_t* n_sec_live,
+                              const int32_t* n_live, void* stream) {
     if (n < 0 || n_sec < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: bad size");
     if (n == 0) return MNRF_OK;
     if (!base || !mask || !out) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_scatter: null pointer");
@@ -714,16 +823,25 @@ extern "C" int mnrf_blend_scatter(const float* base, const float* sec, const int
     hipStream_t s = (hipStream_t)stream;
     const int direct = index == nullptr;
     hipLaunchKernelGGL(blend_all_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, s, base, sec, mask, (long long)n, c,
-                       direct, out, reflect_out);
+                       direct, out, reflect_out, n_live);
     if (!direct && n_sec > 0)
         hipLaunchKernelGGL(blend_scatter_kernel, dim3(blocks_for(n_sec * c, 256)), dim3(256), 0, s, base, sec, index,
-                           (long long)n_sec, mask, c, out, reflect_out);
+                           (long long)n_sec, mask, c, out, reflect_out, n_sec_live);
     return mnrf_check_launch("mnrf_blend_scatter");
 }
+extern "C" int mnrf_blend_scatter(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                                  const float* mask, int64_t n, int c, float* out, float* reflect_out, void* stream) {
+    return blend_scatter_impl(base, sec, index, n_sec, mask, n, c, out, reflect_out, nullptr, nullptr, stream);
+}
+extern "C" int mnrf_blend_scatter_n(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
+                                    const float* mask, int64_t n, int c, float* out, float* reflect_out,
+                                    const int32_t* n_sec_live, const int32_t* n_live, void* stream) {
+    return blend_scatter_impl(base, sec, index, n_sec, mask, n, c, out, reflect_out, n_sec_live, n_live, stream);
+}
 
-extern "C" int mnrf_reflect_backward(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
-                                     const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
-                                     void* stream) {
+static int reflect_backward_impl(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                                 const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                                 const int32_t* n_sec_live, void* stream) {
     if (n_rays < 0 || n_sec < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward: bad size");
     if (n_rays == 0) return MNRF_OK;
     if (!rays || !normal || !g_x_surface || !g_normal || !g_rays || (n_sec > 0 && !g_sec))
@@ -732,21 +850,39 @@ extern "C" int mnrf_reflect_backward(const float* rays, const float* normal, con
     mnrf::zero_fill(s, g_x_surface, n_rays * 3 * sizeof(float), g_normal, n_rays * 3 * sizeof(float), g_rays, n_rays * 8 * sizeof(float));
     if (n_sec > 0)
         hipLaunchKernelGGL(reflect_backward_kernel, dim3(blocks_for(n_sec, 256)), dim3(256), 0, s, rays, normal, index, (long long)n_sec,
-                           g_sec, g_x_surface, g_normal, g_rays);
+                           g_sec, g_x_surface, g_normal, g_rays, n_sec_live);
     return mnrf_check_launch("mnrf_reflect_backward");
 }
+extern "C" int mnrf_reflect_backward(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                                     const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                                     void* stream) {
+    return reflect_backward_impl(rays, normal, index, n_sec, g_sec, n_rays, g_x_surface, g_normal, g_rays, nullptr, stream);
+}
+extern "C" int mnrf_reflect_backward_n(const float* rays, const float* normal, const int32_t* index, int64_t n_sec,
+                                       const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
+                                       const int32_t* n_sec_live, void* stream) {
+    return reflect_backward_impl(rays, normal, index, n_sec, g_sec, n_rays, g_x_surface, g_normal, g_rays, n_sec_live, stream);
+}
 
-extern "C" int mnrf_blend_backward(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
-                                   float* g_base, float* g_sec, void* stream) {
+static int blend_backward_impl(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                               float* g_base, float* g_sec, const int32_t* n_sec_live, const int32_t* n_live, void* stream) {
     if (n < 0 || n_sec < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_backward: bad size");
     if (n == 0) return MNRF_OK;
     if (!g_out || !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (g_base) hipLaunchKernelGGL(blend_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, s, g_out, mask, (long long)n, c, g_base);
+    if (g_base) hipLaunchKernelGGL(blend_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, s, g_out, mask, (long long)n, c, g_base, n_live);
     if (g_sec && n_sec > 0)
         hipLaunchKernelGGL(blend_backward_sec_kernel, dim3(blocks_for(n_sec * c, 256)), dim3(256), 0, s, g_out, mask, index,
-                           (long long)n_sec, c, g_sec);
+                           (long long)n_sec, c, g_sec, n_sec_live);
     return mnrf_check_launch("mnrf_blend_backward");
+}
+extern "C" int mnrf_blend_backward(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                                   float* g_base, float* g_sec, void* stream) {
+    return blend_backward_impl(g_out, mask, index, n_sec, n, c, g_base, g_sec, nullptr, nullptr, stream);
+}
+extern "C" int mnrf_blend_backward_n(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,
+                                     float* g_base, float* g_sec, const int32_t* n_sec_live, const int32_t* n_live, void* stream) {
+    return blend_backward_impl(g_out, mask, index, n_sec, n, c, g_base, g_sec, n_sec_live, n_live, stream);
 }
 
 // Ray gradients of one field evaluation from its per-sample position / view-encoding gradients: x = o + d z
@@ -755,10 +891,11 @@ extern "C" int mnrf_blend_backward(const float* g_out, const float* mask, const 
 // per evaluation -- zeros, two slices, a product, three reductions -- 28 launches of a training step.)
 __global__ __launch_bounds__(256) void ray_grads_kernel(const float* __restrict__ d_xyz, const float* __restrict__ z,
                                                         const float* __restrict__ d_dir, long long n_rays, int spr,
-                                                        float* __restrict__ g_rays, float* __restrict__ g_de) {
+                                                        float* __restrict__ g_rays, float* __restrict__ g_de,
+                                                        const int* __restrict__ n_live) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
+    if (ray >= live_rows(n_rays, n_live)) return;
     if (g_rays) {
         float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int s = lane; s < spr; s += 64) {
@@ -784,23 +921,39 @@ __global__ __launch_bounds__(256) void ray_grads_kernel(const float* __restrict_
     }
 }
 
-extern "C" int mnrf_ray_grads(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
-                              float* g_de, void* stream) {
+static int ray_grads_impl(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                          float* g_de, const int32_t* n_live, void* stream) {
     if (n_rays < 0 || spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: bad size");
     if (n_rays == 0 || (!g_rays && !g_de)) return MNRF_OK;
     if ((g_rays && (!d_xyz || !z_vals)) || (g_de && !d_dir)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: null pointer");
     hipLaunchKernelGGL(ray_grads_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, d_xyz, z_vals, d_dir,
-                       (long long)n_rays, spr, g_rays, g_de);
+                       (long long)n_rays, spr, g_rays, g_de, n_live);
     return mnrf_check_launch("mnrf_ray_grads");
 }
+extern "C" int mnrf_ray_grads(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                              float* g_de, void* stream) {
+    return ray_grads_impl(d_xyz, z_vals, d_dir, n_rays, spr, g_rays, g_de, nullptr, stream);
+}
+extern "C" int mnrf_ray_grads_n(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
+                                float* g_de, const int32_t* n_live, void* stream) {
+    return ray_grads_impl(d_xyz, z_vals, d_dir, n_rays, spr, g_rays, g_de, n_live, stream);
+}
 
-extern "C" int mnrf_embed_backward(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, void* stream) {
+static int embed_backward_impl(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, const int32_t* n_live,
+                               void* stream) {
     if (n < 0 || c < 1 || n_freqs < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed_backward: bad size");
     if (n == 0) return MNRF_OK;
     if (!x || !g_out || !g_x) return mnrf_fail(MNRF_ERR_ARG, "mnrf_embed_backward: null pointer");
     hipLaunchKernelGGL(embed_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, x, g_out, (long long)n, c,
-                       n_freqs, g_x);
+                       n_freqs, g_x, n_live);
     return mnrf_check_launch("mnrf_embed_backward");
+}
+extern "C" int mnrf_embed_backward(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, void* stream) {
+    return embed_backward_impl(x, g_out, n, c, n_freqs, g_x, nullptr, stream);
+}
+extern "C" int mnrf_embed_backward_n(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x,
+                                     const int32_t* n_live, void* stream) {
+    return embed_backward_impl(x, g_out, n, c, n_freqs, g_x, n_live, stream);
 }
 
 extern "C" int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far, float* rays,

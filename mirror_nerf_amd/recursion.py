@@ -94,16 +94,16 @@ def _reflect_autograd(rays, x_surface, normal, mask, compact):
     """Reflected rays with gradient history (train.py:205 "not detach() to jointly optimize"): the same HIP
     kernel forward, mnrf_reflect_backward backward."""
     from .autograd import ReflectFn
-    sec, index, rdir = ReflectFn.apply(rays, x_surface, normal, mask, bool(compact))
+    sec, index, rdir, _count = ReflectFn.apply(rays, x_surface, normal, mask, bool(compact))
     return sec, (index if compact else None), rdir
 
 
-def _blend_autograd(base, sec, index, mask, want_reflect, detach_sec=False):
+def _blend_autograd(base, sec, index, mask, want_reflect, detach_sec=False, n_sec_live=None, n_live=None):
     """train.py:263-296 with gradient history (BlendFn); the optional visualisation output is detached."""
     from .autograd import BlendFn
     compact = index is not None
     idx = index if compact else torch.empty(0, dtype=torch.int32, device=base.device)
-    out = BlendFn.apply(base, sec, idx, mask, compact, detach_sec)
+    out = BlendFn.apply(base, sec, idx, mask, compact, detach_sec, n_sec_live, n_live)
     refl = None
     if want_reflect:
         refl = torch.zeros_like(base)
@@ -125,13 +125,28 @@ def _pick_normal(r, sel):
 # ----------------------------------------------------------------------------- train semantics
 def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_level,
                                   extra_chunk, white_back=False, train_geometry_stage=False):
-    """train.py:129-348."""
+    """train.py:129-348.
+
+    STATIC STEP (round 5; extra_chunk["_static"], set by training.train_step / GraphedTrainStep): the training route without a
+    single device->host read.  The reference decides on the host whether anything is traced (`mirror_mask.bool().any()`,
+    train.py:175) and how many rays (`secondary_rays[mask.bool()]`, train.py:248-252: a stream sync in the middle of every
+    step).  Here the count of the compacted reflections stays on the device (ReflectFn static=True): the reflected rays keep
+    the CAPACITY of the chunk, every launch of the nested level takes the count as its live row count (`_n_live`,
+    include/mnrf.h) and the blend reads it too.  Values and gradients are those of the host-driven route: with no mirror
+    pixel the nested launches find nothing to do and the blend leaves every ray as it is (m = 0: m*x + (1-m)*base == base).
+    Differences: `rgb_*_direct` is then present although the reference would not have traced (nothing reads it), and whether
+    the ground-truth mask is valid (train.py:153 `(mask >= 0).all()`) is the caller's statement extra_chunk["_gt_valid"]."""
+    static = bool(extra_chunk.get("_static")) and not extra_chunk.get("is_eval", False) and torch.is_grad_enabled()
+    n_live = extra_chunk.get("_n_live")
     r = render_rays(models, embeddings, rays_chunk, hp.N_samples, hp.use_disp, hp.perturb, hp.noise_std,
                     hp.N_importance, hp.chunk, white_back, compute_normal=hp.trace_secondary_rays,
                     **dict(extra_chunk, _guard=False))        # the range guard is read once, in NeRFSystem.forward
     N = rays_chunk.shape[0]
     dev = rays_chunk.device
     sel = "fine" if (hp.N_importance > 0 and not hp.only_one_field) else "coarse"
+    if static and N:
+        return _static_level(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_level, extra_chunk, white_back,
+                             train_geometry_stage, r, sel, n_live)
 
     # -- mirror mask (train.py:153-168)
     gt = extra_chunk["mirror_mask"].float()
@@ -213,6 +228,53 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
         r["secondary_rays_o"] = torch.zeros_like(r[f"rgb_{sel}"])
         r["reflect_direction"] = torch.zeros_like(r[f"rgb_{sel}"])
     del traced
+    return r
+
+
+def _static_level(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_level, extra_chunk, white_back,
+                  train_geometry_stage, r, sel, n_live):
+    """One level of render_rays_chunk_recursively in a static step (see there): train.py:153-296 with the mirror-ray count on
+    the device.  `r`: this level's render_rays result; n_live: the live rows of rays_chunk (None at level 0)."""
+    from .autograd import ReflectFn
+    N = rays_chunk.shape[0]
+    dev = rays_chunk.device
+    can_trace = bool(hp.trace_secondary_rays and (not train_geometry_stage) and recur_level < hp.max_recursive_level)
+    gt = extra_chunk["mirror_mask"].float()
+    gt_valid = extra_chunk.get("_gt_valid")
+    if gt_valid is None:
+        raise RuntimeError("static step: extra['_gt_valid'] must say whether the batch's mirror masks are all valid (train.py:153)")
+    if recur_level > 0 or not gt_valid:                           # train.py:155-166: predicted mask, thresholded in place
+        if "mirror_mask_fine" in r:
+            mask = r["mirror_mask_fine"]
+        elif "mirror_mask_coarse" in r:
+            mask = r["mirror_mask_coarse"]
+        else:
+            mask = torch.zeros(N, device=dev)
+        md = mask.detach()
+        _lib.check(_lib.lib().mnrf_threshold_mask_n(_lib.ptr(md), N, None, _lib.ptr(n_live), _lib.stream()), "mnrf_threshold_mask")
+        mask = md
+    else:
+        mask = gt.contiguous()       # (never written: no clone needed)
+    only_in = hp.only_trace_rays_in_mirrors
+    if (not only_in) and recur_level > 0:
+        mask = mask * mirror_mask_prev.float()                    # train.py:167-168
+    if not can_trace:
+        return r
+    if not r[f"rgb_{sel}"].requires_grad:
+        raise RuntimeError("static step: the render carries no gradient history (use the default route for evaluation)")
+    detach_sec = bool(getattr(hp, "detach_ref_color_for_blend", False)) and \
+        extra_chunk.get("current_epoch", 0) >= getattr(hp, "train_geometry_stage_end_epoch", 4) + 1      # train.py:284-289
+    nrm = _pick_normal(r, sel)
+    if getattr(hp, "detach_normal_in_reflection", False):
+        nrm = nrm.detach()
+    sec, index, _rdir, count = ReflectFn.apply(rays_chunk, r[f"x_surface_{sel}"], nrm, mask, bool(only_in), True, n_live)
+    r2 = render_rays_chunk_recursively(models, embeddings, hp, sec, mask, recur_level + 1, dict(extra_chunk, _n_live=count),
+                                       white_back, train_geometry_stage)
+    for typ in ("coarse", "fine"):                                # train.py:263-296
+        if f"rgb_{typ}" in r and f"rgb_{typ}" in r2:
+            r[f"rgb_{typ}_direct"] = r[f"rgb_{typ}"]
+            r[f"rgb_{typ}"], _ = _blend_autograd(r[f"rgb_{typ}"], r2[f"rgb_{typ}"], index if only_in else None, mask, False,
+                                                 detach_sec=detach_sec, n_sec_live=count, n_live=n_live)
     return r
 
 

@@ -14,6 +14,10 @@ Differences from the reference that do not change values:
     tests can feed the oracle the same numbers; otherwise they come from torch's CUDA generator; `_z_fine` (N, S+N_importance)
     replaces the resampled depths altogether (fixtures G14 of the fine pass);
   * `torch.linspace` tables are built on the CPU like the reference CPU path does and cached;
+  * `_n_live` (a device int32 tensor of one element; training only): `rays` is sized for a CAPACITY and only the first
+    *_n_live rows exist -- the compacted reflected rays of a training step whose count never visits the host (recursion.py
+    "static step"; include/mnrf.h "live row counts on the device").  Every launch is sized for the capacity and leaves the rows past
+    the count alone; the result tensors have the capacity's shape, their rows past the count are undefined;
   * `_maps_only=True` (set by batched_inference for to_cpu="maps" / maps_only=True): in eval the final pass runs ray-fused --
     field evaluation + compositing in one kernel -- and the per-sample keys nobody downstream of eval.py:735-736 reads
     (weights_*, pred_normal_*) are not produced; the per-ray maps are identical bit for bit.
@@ -50,16 +54,16 @@ def _n_freqs(emb):
     return n
 
 
-def _embed(x, n_freqs):
+def _embed(x, n_freqs, n_live=None):
     x = x.float().contiguous()
     n, c = x.shape
     out = torch.empty(n, c * (2 * n_freqs + 1), dtype=torch.float32, device=x.device)
     if n:
-        _lib.check(_lib.lib().mnrf_embed(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.stream()), "mnrf_embed")
+        _lib.check(_lib.lib().mnrf_embed_n(_lib.ptr(x), n, c, n_freqs, _lib.ptr(out), _lib.ptr(n_live), _lib.stream()), "mnrf_embed")
     return out
 
 
-def sample_pdf(bins_z, weights, N_importance, det=False, u=None):
+def sample_pdf(bins_z, weights, N_importance, det=False, u=None, n_live=None):
     """Fine depths for rays whose coarse depths are `bins_z` (N,S) and weights (N,S):
     sample_pdf(mid-points, weights[:,1:-1]) merged with the coarse depths and sorted
     (models/rendering.py:7-51 and 312-326 in one kernel)."""
@@ -71,8 +75,8 @@ def sample_pdf(bins_z, weights, N_importance, det=False, u=None):
     per_ray = 1 if u.dim() == 2 else 0
     z_fine = torch.empty(N, S + N_importance, dtype=torch.float32, device=dev)
     if N:
-        _lib.check(_lib.lib().mnrf_sample_fine(_lib.ptr(bins_z), _lib.ptr(weights), N, S, _lib.ptr(u), per_ray,
-                                               N_importance, _lib.ptr(z_fine), _lib.stream()), "mnrf_sample_fine")
+        _lib.check(_lib.lib().mnrf_sample_fine_n(_lib.ptr(bins_z), _lib.ptr(weights), N, S, _lib.ptr(u), per_ray,
+                                                 N_importance, _lib.ptr(z_fine), _lib.ptr(n_live), _lib.stream()), "mnrf_sample_fine")
     return z_fine
 
 
@@ -101,6 +105,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     train = torch.is_grad_enabled() and (rays.requires_grad or any(
         q.requires_grad for mdl in models.values() for q in params_of(mdl)))
+    n_live = kwargs.get("_n_live")
+    if n_live is not None and (not train or hashgrid or test_time):
+        raise NotImplementedError("_n_live (device-side ray count) is a feature of the training path of the MirrorNeRF field")
 
     # gradient steering (values are unaffected): rendering.py:223-247 for the compositing weights,
     # mirror_nerf.py:154-183 for what the normal / mirror heads send into geo_feat
@@ -111,7 +118,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             cut_heads |= _lib.MNRF_CUT_MIRROR_HEAD
         elif kwargs.get("detach_density_outside_mirror_for_mask_loss", False) and kwargs.get("mirror_mask") is not None:
             mm = kwargs["mirror_mask"]
-            if not bool((mm < 0).any().item()):
+            gv = kwargs.get("_gt_valid")      # (static step: the caller knows; no device->host read)
+            if (gv if gv is not None else not bool((mm < 0).any().item())):
                 if mm.shape[0] != N:
                     # the reference indexes the (N,S) weights with this mask and fails the same way when reflected rays
                     # were compacted (train.py:253-259 passes the un-compacted mask on, SURVEY 8a hazard 10)
@@ -127,7 +135,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     if hashgrid:
         dir_emb = view.float().contiguous()          # Embedding(0): the raw direction (train.py:69-70)
     else:
-        dir_emb = EmbedFn.apply(view, n_fd) if (train and view.requires_grad) else _embed(view.detach(), n_fd)
+        dir_emb = EmbedFn.apply(view, n_fd, n_live) if (train and view.requires_grad) else _embed(view.detach(), n_fd, n_live)
 
     # rendering.py:283-300 -- coarse depths
     z_steps = kwargs.get("_z_steps")
@@ -138,8 +146,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         prand = torch.rand(N, N_samples, device=dev) if prand is None else prand.float().contiguous()
     z_vals = f(N, N_samples)
     if N:
-        _lib.check(L.mnrf_sample_coarse(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
-                                        p(prand), p(z_vals), _lib.stream()), "mnrf_sample_coarse")
+        _lib.check(L.mnrf_sample_coarse_n(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
+                                          p(prand), p(z_vals), p(n_live), _lib.stream()), "mnrf_sample_coarse")
 
     has_fine = "fine" in models
     results = {}
@@ -260,8 +268,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:
             want = bool(compute_normal)
-            if cut_heads or keep_mirror is not None:
-                want = (want, cut_heads, keep_mirror)
+            if cut_heads or keep_mirror is not None or n_live is not None:
+                want = (want, cut_heads, keep_mirror, n_live)
             sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, want, *params_of(model))
         noise = kwargs.get(noise_key)
         if noise is not None:
@@ -276,7 +284,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if not getattr(model, "predict_normal", True):
             pn = None
         weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
-            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror)
+            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live)
         results[f"weights_{typ}"] = weights
         results[f"opacity_{typ}"] = opacity
         results[f"z_vals_{typ}"] = z
@@ -304,7 +312,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             if u is None and perturb == 0:
                 u = kwargs.get("_u_det")
             # weights are detached here, as in the reference (rendering.py:335, 353)
-            return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=u)
+            return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=u, n_live=n_live)
 
         if kwargs.get("only_one_field", False):                           # rendering.py:328-348
             if kwargs.get("current_epoch", 0) > kwargs.get("only_one_field_fine_epoch", 2):

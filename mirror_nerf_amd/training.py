@@ -66,6 +66,20 @@ def total_loss_fn(hparams=None, epoch=5):
     return fn
 
 
+def static_step_ok(system):
+    """Can `system` take the static training route (recursion.render_rays_chunk_recursively "STATIC STEP": the reflected-ray
+    count never visits the host)?  MirrorNeRF fields on the split arithmetic with operand planes; a model the range guard has
+    pinned to fp32, the hash-grid field and MNRF_DW_PLANES=0 use the host-driven route."""
+    from . import autograd as AG
+    from .mirror_nerf import MirrorNeRF, precision_of
+    return AG.DW_PLANES and all(isinstance(m, MirrorNeRF) and precision_of(m) == "split" for m in system.models.values())
+
+
+# MNRF_STATIC_STEP=0: train_step keeps the host-driven route (one device->host read of the reflected-ray count per level and step,
+# like train.py:175) even when the caller states `gt_valid`
+STATIC_STEP = os.environ.get("MNRF_STATIC_STEP", "1") != "0"
+
+
 def extra_info(hp, gt_mask, epoch=0, train_geometry_stage=False):
     """The `extra` dict training_step hands to NeRFSystem.forward (train.py:420-436), incl. the gradient-steering options."""
     return {"mirror_mask": gt_mask, "is_eval": False, "train_geometry_stage": train_geometry_stage,
@@ -95,9 +109,12 @@ def _takes_found_inf(optimizer):
     return bool(getattr(optimizer, "defaults", {}).get("fused")) or hasattr(optimizer, "mnrf_found_inf")
 
 
-def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0):
+def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss, epoch=0, gt_valid=None):
     """One optimisation step: forward (train semantics), loss, backward, gradient all-reduce, optimizer.  See GUARD_MODE for
-    what happens when the split-f16 arithmetic leaves its range during the step."""
+    what happens when the split-f16 arithmetic leaves its range during the step.
+    gt_valid: the caller's statement that every entry of gt_mask is valid (>= 0; True) or that some are not (False) -- what
+    train.py:153 reads from the device.  With it (and MNRF_STATIC_STEP != 0, MirrorNeRF fields on the split arithmetic) the step
+    takes the STATIC route: no device->host read at all, the reflected-ray count stays on the device (recursion.py)."""
     from .mirror_nerf import check_guard, guard_async_begin, guard_async_end, pin_fp32
     rank, world = D.world()
     collective = world > 1 or D.forced()
@@ -125,10 +142,15 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     if token is not None and not late:
         settle(token)
 
+    static = STATIC_STEP and gt_valid is not None and static_step_ok(system)
+
     def fwd_bwd():
         nonlocal late
-        res = system(rays, dict(extra_info(system.hparams, gt_mask, epoch), _guard=False))
-        if late:                # (a trip pins the models for the NEXT forward; this step's own flags gate its own update)
+        ex = dict(extra_info(system.hparams, gt_mask, epoch), _guard=False)
+        if static and static_step_ok(system):      # (re-checked: a recomputed step runs after a trip has pinned the models)
+            ex.update(_static=True, _gt_valid=bool(gt_valid))
+        res = system(rays, ex)
+        if late and not static:  # (a trip pins the models for the NEXT forward; this step's own flags gate its own update)
             settle(token)
             late = False
         loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
@@ -177,6 +199,8 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     # pass as soon as its gradients are complete (dist.attach_overlap), only waited for here
     D.allreduce_gradients(params_of(system), modules=list(system.models.values()))
     optimizer.step()
+    if late:                    # static route: the host never waits inside the step; the previous step's flags are read here, with
+        settle(token)           # this whole step queued (a trip then costs the batch of this step too: its flags trip as well)
     return loss
 
 
@@ -260,6 +284,42 @@ class FlatAdam:
         self._gs = self._fi = None                   # (GradScaler semantics: the flags belong to one step)
         bump_generation()                            # the packed weight images are stale now (torch optimizers do this through a hook)
 
+    # ---- hyper-parameters and the step count in device memory: what a step captured in a hipGraph needs (GraphedTrainStep)
+    def enable_device_state(self):
+        if not self.kernel:
+            raise RuntimeError("FlatAdam(kernel=False) has no device-resident state")
+        dev = self.flats[0].device
+        self._hyper_host = None
+        self._hyper = torch.zeros(5, dtype=torch.float64, device=dev)
+        self._step_dev = torch.tensor([self._calls], dtype=torch.int64, device=dev)
+        self.sync_hyper()
+
+    def sync_hyper(self):
+        """param_groups[0] -> device (call between steps: an lr scheduler changes the group's lr on the host)."""
+        grp = self.param_groups[0]
+        h = (float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]))
+        if h != self._hyper_host:
+            self._hyper.copy_(torch.tensor(h, dtype=torch.float64))
+            self._hyper_host = h
+
+    def step_dev(self, guard_words=()):
+        """step() with every scalar read from device memory: capturable; the host's call count is NOT advanced (replays do not
+        pass through here): GraphedTrainStep keeps it in step with the device count."""
+        from . import _lib
+        L, p = _lib.lib(), _lib.ptr
+        f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1)  # noqa: E731
+        gs, fi = f32(self._gs), f32(self._fi)
+        _lib.check(L.mnrf_add_i64(self._step_dev.data_ptr(), 1, _lib.stream()), "mnrf_add_i64")
+        for i, (m, fp) in enumerate(zip(self.modules, self.flats)):
+            flat = D._flat_bucket(m)
+            if flat is None:
+                flat, _copied = D._module_message(m)
+            fp.grad = flat
+            _lib.check(L.mnrf_adam_step_dev(p(fp.data), p(flat.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(),
+                                            self._hyper.data_ptr(), self._step_dev.data_ptr(), p(self._skipped[i]), p(gs), p(fi),
+                                            _lib.stream()), "mnrf_adam_step_dev")
+        self._gs = self._fi = None
+
     def state_dict(self):
         if not self.kernel:
             return self.inner.state_dict()
@@ -277,10 +337,121 @@ class FlatAdam:
             g.update(saved)
 
 
+class GraphedTrainStep:
+    """A whole optimisation step -- weight packing, forward with reflections (static route), loss, backward, weight-gradient
+    GEMMs, Adam -- captured ONCE as a hipGraph (torch.cuda.CUDAGraph) and replayed per batch: no host work, no device->host
+    read, no launch gaps.  What makes it possible is the static route of the recursion (the reflected-ray count stays on the
+    device, every nested launch is sized for the batch and takes the count as its live row count: include/mnrf.h "live row
+    counts on the device") and FlatAdam's device-resident step count and hyper-parameters.  The reference's step is
+    train.py:386-458 (`training_step` + Lightning's backward / optimizer step); reference behaviour kept: train.py:153-178, 248-296.
+
+        step = GraphedTrainStep(system, FlatAdam(...), batch=1024, gt_valid=True)
+        loss = step(rays, target, gt_mask)        # tensors of the captured shapes; `loss` is a static tensor (read it late)
+
+    One rank only (an all-reduce inside a captured graph is untested on this stack: multi-rank training uses train_step, whose
+    static route removes the host reads all the same).  Range guard: the guard words of the step gate the update ON THE DEVICE
+    (found_inf) and are read by the host one step late; a trip ends the graph -- the models continue on train_step (pinned to fp32,
+    or with a lowered gradient scale: re-captured then)."""
+
+    def __init__(self, system, optimizer, batch, loss_fn=None, epoch=0, gt_valid=True, warmup=2):
+        if D.world()[1] > 1 or D.forced():
+            raise NotImplementedError("GraphedTrainStep: one rank only (use train_step(..., gt_valid=...) across ranks)")
+        if not isinstance(optimizer, FlatAdam) or not optimizer.kernel:
+            raise ValueError("GraphedTrainStep needs training.FlatAdam (its kernel form)")
+        if not static_step_ok(system):
+            raise RuntimeError("GraphedTrainStep: MirrorNeRF fields on the split arithmetic with operand planes only")
+        self.system, self.opt, self.loss_fn, self.epoch, self.gt_valid = system, optimizer, loss_fn or color_mask_loss, epoch, bool(gt_valid)
+        dev = optimizer.flats[0].device
+        self.rays = torch.zeros(batch, 8, device=dev)
+        self.target = torch.zeros(batch, 3, device=dev)
+        self.gt = torch.zeros(batch, device=dev)
+        self.graph, self.loss, self.ended, self._pending = None, None, False, None
+        self.warmup = warmup
+        if not hasattr(optimizer, "_step_dev"):
+            optimizer.enable_device_state()
+
+    def _body(self):
+        from .weights import invalidate_packed
+        models = list(self.system.models.values())
+        for m in models:
+            invalidate_packed(m)          # the packing launches belong to every replay: the weights changed in the step before
+        ex = dict(extra_info(self.system.hparams, self.gt, self.epoch), _guard=False, _static=True, _gt_valid=self.gt_valid)
+        res = self.system(self.rays, ex)
+        fn = self.loss_fn
+        loss = fn(res, self.target, self.gt, self.rays) if getattr(fn, "needs_rays", False) else fn(res, self.target, self.gt)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self._words = torch.cat([m.__dict__["_mnrf_packed"].packed[-1:] for m in models]).view(torch.int32)
+        self.opt.found_inf = (self._words != 0).any().to(torch.float32)       # a saturated step must not reach the weights
+        self.opt.step_dev()
+        return loss.detach()
+
+    def capture(self):
+        opt = self.opt
+        keep = [t.clone() for t in opt.flats] + [t.clone() for t in opt._m + opt._v + opt._skipped] + [opt._step_dev.clone()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):     # warm-up off the capture: lazy initialisations, allocator, autograd threads
+            for _ in range(self.warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():             # the warm-up steps were rehearsals: weights and optimizer state as before
+            for dst, src in zip([t.data for t in opt.flats] + opt._m + opt._v + opt._skipped + [opt._step_dev], keep):
+                dst.copy_(src)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self._host = torch.zeros(len(self.system.models), dtype=torch.int32).pin_memory()
+
+    def __call__(self, rays, target, gt_mask):
+        if not self.ended:
+            self._settle()
+        if self.ended:                    # after a range-guard trip: the host-driven step (models pinned to fp32)
+            return train_step(self.system, self.opt, rays, target, gt_mask, self.loss_fn, self.epoch, gt_valid=self.gt_valid)
+        self.rays.copy_(rays)
+        self.target.copy_(target)
+        self.gt.copy_(gt_mask)
+        if self.graph is None:
+            self.capture()
+        self.opt.sync_hyper()
+        self.graph.replay()
+        self.opt._calls += 1
+        from .weights import bump_generation
+        bump_generation()                 # host-side caches of the packed images are stale (the replay updated the weights)
+        self._host.copy_(self._words, non_blocking=True)      # this step's guard words, read at the next call
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = ev
+        return self.loss
+
+    def _settle(self):
+        """The previous replay's guard words (its update was skipped on the device if any is set)."""
+        from .mirror_nerf import GUARD, GUARD_NAMES, _lower_gradient_scale, pin_fp32
+        ev, self._pending = self._pending, None
+        if ev is None or not GUARD:
+            return
+        ev.synchronize()
+        words = self._host.tolist()
+        if not any(words):
+            return
+        import warnings
+        models = list(self.system.models.values())
+        if all((not w) or _lower_gradient_scale(m, w) for m, w in zip(models, words)):
+            self.graph = None             # scaled activation gradients outgrew f16: the models stay on the split arithmetic with a
+            return                        # lower gradient scale (a launch flag): capture again
+        why = "; ".join(v for k, v in GUARD_NAMES.items() if any(w & k for w in words))
+        warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range in a captured training step ({why}); its update was "
+                      "skipped, the models run on the fp32 kernels through train_step from now on", RuntimeWarning, stacklevel=3)
+        pin_fp32(self.system)
+        self.ended = True
+
+
 def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0, loss_name="color_mask", **hp_over):
     """Returns dict(rays_per_s, ms_per_step, reflected_per_step, loss) for this process group.  hp_over: hparams other than
     default_hparams() (e.g. N_importance=128: BASELINE config 3 as worded)."""
     rank, world = D.world()
+    route_arg = hp_over.pop("_route", None)
     torch.manual_seed(seed)
     system = NeRFSystem(default_hparams(**hp_over)).to(dev)
     with torch.no_grad():   # opaque density so that surfaces and reflections exist
@@ -301,12 +472,23 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
     loss_fn = total_loss_fn() if loss_name == "total" else color_mask_loss
     D.attach_overlap(system.models.values())        # (no-op on one rank)
 
+    # route of the step (round 5): "graph" = the whole step replayed as one hipGraph (GraphedTrainStep; one rank), "static" = the
+    # same launches issued by the host with no device->host read (train_step(gt_valid=True)), "host" = the reference's shape: the
+    # reflected-ray count is read by the host in the middle of the step (train.py:175).  MNRF_TRAIN_ROUTE overrides.
+    route = os.environ.get("MNRF_TRAIN_ROUTE") or route_arg or ("graph" if (world == 1 and not D.forced()) else "static")
+    if route != "host" and not (flat_adam and static_step_ok(system)):
+        route = "host"
+    graphed = GraphedTrainStep(system, opt, batch, loss_fn, gt_valid=True) if route == "graph" else None
+
     def one():
         idx = torch.randint(0, all_rays.shape[0], (batch,), device=dev, generator=g)
         rays = all_rays[idx].contiguous()
         target = torch.rand(batch, 3, device=dev, generator=g)
         gt = (torch.rand(batch, device=dev, generator=g) < 0.25).float()
-        return train_step(system, opt, rays, target, gt, loss_fn), gt.sum()     # (no host read here: it would drain the queue)
+        if graphed is not None:
+            return graphed(rays, target, gt), gt.sum()
+        # (no host read here: it would drain the queue)
+        return train_step(system, opt, rays, target, gt, loss_fn, gt_valid=True if route == "static" else None), gt.sum()
 
     for _ in range(warmup):
         one()
@@ -354,6 +536,7 @@ def synthetic_train_bench(dev, all_rays, steps=10, warmup=3, batch=1024, seed=0,
             "roofline": roofline, "allreduce_bytes_per_step": 4 * sum(q.numel() for q in params_of(system)) if world > 1 or D.forced() else 0,
             "ms_per_step": dt / steps * 1e3, "batch_rays_per_gpu": batch, "reflected_rays_per_step": refl / steps,
             "samples_per_ray": spr, "N_samples": hp.N_samples, "N_importance": hp.N_importance, "steps": steps,
+            "route": route + (" (ended by a range-guard trip)" if graphed is not None and graphed.ended else ""),
             "optimizer": ("training.FlatAdam (Adam over one flat parameter tensor per model, " +
                           ("mnrf_adam_step" if getattr(opt, "kernel", False) else "torch's fused kernel") + ")") if flat_adam else "torch.optim.Adam(fused=True)",
             "loss": float(loss.item()),

@@ -42,6 +42,12 @@ static int check(const DwpPlan& p) {
             }
             for (int s = 0; s < n; ++s)
                 if (owner[s] < 0) { std::printf("stage %d of v=%d has no owner (G=%d T=%lld)\n", s, v, p.G, p.T); return 1; }
+            // the closed form the launcher and the device-side plan (dwp_plan_kernel) use for the finish kernel's owner ranges
+            if (n > 0 && (dwp_owner(p, P) != g_lo || dwp_owner(p, P + (long long)(n - 1) * w) != g_hi)) {
+                std::printf("dwp_owner of v=%d: [%d, %d] but the search says [%d, %d]\n", v, dwp_owner(p, P),
+                            dwp_owner(p, P + (long long)(n - 1) * w), g_lo, g_hi);
+                return 1;
+            }
             P += (long long)n * w;
         }
     }

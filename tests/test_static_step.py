@@ -1,0 +1,243 @@
+"""GPU tests of the STATIC training route (round 5): the reflected-ray count stays on the device, every nested launch is sized
+for the batch and takes the count as its live row count (`_n` entry points of include/mnrf.h), and the whole step can be
+captured as one hipGraph (training.GraphedTrainStep).  Yardstick: the host-driven route of the same package -- the one the
+fixtures G6 / G9 / G9b / G11 / G16 pin against the reference (train.py:129-348) -- on identical weights, rays and draws."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _system(seed=0, **hp):
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import training as T
+    torch.manual_seed(seed)
+    system = M.NeRFSystem(T.default_hparams(**hp)).to(DEV)
+    with torch.no_grad():       # opaque density, a mirror head that straddles 0.5 at the nested level
+        for m in system.models.values():
+            m.sigma.weight.mul_(20.0)
+            m.sigma.bias.fill_(1.0)
+            m.is_mirror_net[2].weight.mul_(40.0)
+    return system
+
+
+def _batch(n=256, frac=0.25, seed=3):
+    from oracle import mirror_nerf_oracle as O
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    rays = torch.from_numpy(O.synthetic_rays(64, 64)[:: max(1, 4096 // n)][:n].copy()).to(DEV)
+    target = torch.rand(n, 3, device=DEV, generator=g)
+    gt = (torch.rand(n, device=DEV, generator=g) < frac).float()
+    return rays, target, gt
+
+
+def _grads(system):
+    from mirror_nerf_amd.weights import params_of
+    return [None if q.grad is None else q.grad.detach().clone() for m in system.models.values() for q in params_of(m)]
+
+
+def _fwd_bwd(system, rays, target, gt, static, loss="color_mask", gt_valid=True):
+    from mirror_nerf_amd import training as T
+    ex = dict(T.extra_info(system.hparams, gt, 5), _guard=False)
+    if static:
+        ex.update(_static=True, _gt_valid=gt_valid)
+    system.zero_grad(set_to_none=True)
+    res = system(rays, ex)
+    fn = T.total_loss_fn() if loss == "total" else T.color_mask_loss
+    val = fn(res, target, gt, rays) if getattr(fn, "needs_rays", False) else fn(res, target, gt)
+    val.backward()
+    return res, float(val), _grads(system)
+
+
+def _cmp_grads(a, b, tol):
+    worst = 0.0
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None)
+        if x is None:
+            continue
+        scale = float(y.abs().max()) + 1e-30
+        worst = max(worst, float((x - y).abs().max()) / scale)
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("frac", [0.25, 0.0, 1.0])
+@pytest.mark.parametrize("loss", ["color_mask", "total"])
+def test_static_route_equals_host_route(frac, loss):
+    """Values of every per-ray map bit for bit (the same kernels see the same rows), gradients to the summation order of the
+    weight-gradient GEMM (its work plan deals the 32-sample stages to workgroups differently when it is made on the device for a
+    launch of one workgroup per CU)."""
+    system = _system(perturb=0.0, noise_std=0.0)
+    rays, target, gt = _batch(frac=frac)
+    res_h, loss_h, g_h = _fwd_bwd(system, rays, target, gt, static=False, loss=loss)
+    res_s, loss_s, g_s = _fwd_bwd(system, rays, target, gt, static=True, loss=loss)
+    for k in ("rgb_coarse", "rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine", "x_surface_fine", "surface_normal_fine"):
+        assert torch.equal(res_h[k], res_s[k]), k
+    if loss_h != loss_h:      # TotalLoss over a batch without a mirror ray is NaN on both routes (a mean over an empty selection,
+        assert loss_s != loss_s     # losses.py:150-173 does the same): nothing to compare beyond that
+        return
+    assert loss_h == loss_s
+    _cmp_grads(g_s, g_h, 2e-5)
+
+
+def test_static_route_with_two_bounces_and_predicted_masks():
+    """max_recursive_level = 2: the second level compacts by the PREDICTED mask, thresholded in place with a live row count, and
+    hands its own count to the third render; invalid ground truth at level 0 takes the predicted mask there too (train.py:153-166)."""
+    system = _system(perturb=0.0, noise_std=0.0, max_recursive_level=2)
+    rays, target, gt = _batch(n=192, frac=0.5)
+    for gt_valid, mask in ((True, gt), (False, torch.full_like(gt, -1.0))):
+        res_h, loss_h, g_h = _fwd_bwd(system, rays, target, mask, static=False)
+        res_s, loss_s, g_s = _fwd_bwd(system, rays, target, mask, static=True, gt_valid=gt_valid)
+        for k in ("rgb_coarse", "rgb_fine", "mirror_mask_fine"):
+            assert torch.equal(res_h[k], res_s[k]), (k, gt_valid)
+        assert loss_h == loss_s
+        _cmp_grads(g_s, g_h, 2e-5)
+
+
+def test_static_route_without_compaction():
+    """only_trace_rays_in_mirrors = False: every ray is reflected as soon as one is a mirror (train.py:248-259); the static route
+    reflects them always -- with no mirror pixel the blend leaves every colour as it is."""
+    system = _system(perturb=0.0, noise_std=0.0, only_trace_rays_in_mirrors=False)
+    for frac in (0.3, 0.0):
+        rays, target, gt = _batch(n=128, frac=frac)
+        res_h, loss_h, g_h = _fwd_bwd(system, rays, target, gt, static=False)
+        res_s, loss_s, g_s = _fwd_bwd(system, rays, target, gt, static=True)
+        assert torch.equal(res_h["rgb_fine"], res_s["rgb_fine"])
+        assert loss_h == loss_s
+        _cmp_grads(g_s, g_h, 2e-5)
+
+
+def test_graphed_step_takes_zero_and_all_mirror_batches_through_one_graph():
+    """One capture, three replays: a batch with NO mirror ray, one with ALL rays mirrors, a mixed one.  After every replay the
+    weights equal those of a twin system stepped by the host-driven train_step on the same batches (same draws: perturb and
+    noise off) to the accuracy of one Adam step's arithmetic."""
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.weights import params_of
+    a = _system(perturb=0.0, noise_std=0.0)
+    b = _system(perturb=0.0, noise_std=0.0)       # (same seed: the same weights)
+    opt_a = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    opt_b = T.FlatAdam(list(b.models.values()), lr=5e-4)
+    n = 256
+    step = T.GraphedTrainStep(a, opt_a, n, gt_valid=True)
+    graphs = []
+    for i, frac in enumerate((0.0, 1.0, 0.3, 0.0)):
+        rays, target, gt = _batch(n=n, frac=frac, seed=10 + i)
+        la = step(rays, target, gt)
+        graphs.append(step.graph)
+        lb = T.train_step(b, opt_b, rays, target, gt)
+        torch.cuda.synchronize()
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))), (i, float(la), float(lb))
+        for qa, qb in zip((q for m in a.models.values() for q in params_of(m)), (q for m in b.models.values() for q in params_of(m))):
+            # Adam's first steps move every weight by ~lr whatever the gradient's size: a gradient entry that differs in its last
+            # bits near zero can flip a whole lr step, so compare against lr
+            assert float((qa - qb).abs().max()) <= 2.5e-4 * (i + 1), i
+    assert all(g is graphs[0] for g in graphs) and not step.ended
+    assert opt_a._calls == 4 and int(opt_a._step_dev.item()) == 4
+
+
+def test_graphed_step_follows_the_learning_rate_and_counts_steps():
+    from mirror_nerf_amd import training as T
+    a = _system(perturb=1.0, noise_std=1.0)
+    opt = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    step = T.GraphedTrainStep(a, opt, 128, gt_valid=True)
+    rays, target, gt = _batch(n=128)
+    w0 = opt.flats[0].detach().clone()
+    step(rays, target, gt)
+    torch.cuda.synchronize()
+    d1 = float((opt.flats[0] - w0).abs().max())
+    assert 1e-4 < d1 <= 5.1e-4          # Adam's first step: |update| <= lr
+    opt.param_groups[0]["lr"] = 0.0      # a scheduler's move
+    w1 = opt.flats[0].detach().clone()
+    step(rays, target, gt)
+    torch.cuda.synchronize()
+    assert float((opt.flats[0] - w1).abs().max()) == 0.0
+    assert int(opt._step_dev.item()) == 2 and int(opt._skipped[0].item()) == 0
+
+
+def test_graphed_step_guard_trip_skips_the_update_and_ends_the_graph():
+    """A weight beyond the f16 range trips the guard inside the captured step: the update is skipped on the device, the host
+    learns it at the next call, pins the models and continues on train_step."""
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.mirror_nerf import precision_of
+    a = _system(perturb=0.0, noise_std=0.0)
+    opt = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    step = T.GraphedTrainStep(a, opt, 128, gt_valid=True)
+    rays, target, gt = _batch(n=128)
+    step(rays, target, gt)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        a.nerf_fine.xyz_encoding_3[0].weight[0, 0] = 1e6        # (through the flat tensor's view; the replay re-packs it)
+    w = opt.flats[1].detach().clone()
+    step(rays, target, gt)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flats[1], w) and int(opt._skipped[1].item()) == 1
+    with pytest.warns(RuntimeWarning):
+        step(rays, target, gt)
+    assert step.ended and precision_of(a.nerf_fine) == "fp32"
+
+
+# ----------------------------------------------------------------------------- the `_n` entry points themselves
+def test_live_row_count_leaves_the_rows_past_it_alone():
+    """mnrf_sample_coarse_n / mnrf_composite_n / mnrf_sample_fine_n with n_live < capacity: the live rows equal the namesake's, the
+    rest of every output keeps its sentinel."""
+    from mirror_nerf_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    torch.manual_seed(0)
+    N, S, live = 70, 64, 23
+    n_live = torch.tensor([live], dtype=torch.int32, device=DEV)
+    rays = torch.randn(N, 8, device=DEV)
+    rays[:, 6], rays[:, 7] = 0.1, 6.0
+    zs = torch.linspace(0, 1, S).to(DEV)
+    z_a, z_b = torch.full((N, S), -7.0, device=DEV), torch.full((N, S), -7.0, device=DEV)
+    _lib.check(L.mnrf_sample_coarse(p(rays), N, p(zs), S, 0, 0.0, None, p(z_a), _lib.stream()), "a")
+    _lib.check(L.mnrf_sample_coarse_n(p(rays), N, p(zs), S, 0, 0.0, None, p(z_b), p(n_live), _lib.stream()), "b")
+    assert torch.equal(z_a[:live], z_b[:live]) and bool((z_b[live:] == -7.0).all())
+    sigma, rgb = torch.randn(N, S, device=DEV) * 3, torch.rand(N * S, 3, device=DEV)
+    outs = {}
+    for tag, nl in (("a", None), ("b", n_live)):
+        w, op, rm, d, xs = (torch.full(s, -7.0, device=DEV) for s in ((N, S), (N,), (N, 3), (N,), (N, 3)))
+        _lib.check(L.mnrf_composite_n(p(rays), N, S, p(sigma), p(z_a), None, p(rgb), None, None, None, 0, p(w), p(op), p(rm), p(d),
+                                      None, None, None, None, p(xs), p(nl), _lib.stream()), "composite")
+        outs[tag] = (w, op, rm, d, xs)
+    for ta, tb in zip(outs["a"], outs["b"]):
+        assert torch.equal(ta[:live], tb[:live]) and bool((tb[live:] == -7.0).all())
+    u = torch.linspace(0, 1, 128).to(DEV)
+    f_a, f_b = torch.full((N, S + 128), -7.0, device=DEV), torch.full((N, S + 128), -7.0, device=DEV)
+    _lib.check(L.mnrf_sample_fine_n(p(z_a), p(outs["a"][0]), N, S, p(u), 0, 128, p(f_a), None, _lib.stream()), "fine a")
+    _lib.check(L.mnrf_sample_fine_n(p(z_a), p(outs["a"][0]), N, S, p(u), 0, 128, p(f_b), p(n_live), _lib.stream()), "fine b")
+    assert torch.equal(f_a[:live], f_b[:live]) and bool((f_b[live:] == -7.0).all())
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)       # nothing live: nothing written
+    f_c = torch.full((N, S + 128), -7.0, device=DEV)
+    _lib.check(L.mnrf_sample_fine_n(p(z_a), p(outs["a"][0]), N, S, p(u), 0, 128, p(f_c), p(zero), _lib.stream()), "fine c")
+    assert bool((f_c == -7.0).all())
+
+
+def test_device_made_gemm_plan_gives_the_host_plan_gradients():
+    """mnrf_dw_planes2_n (work plan made on the device from live counts) against mnrf_dw_planes2 on the same planes: a field
+    evaluation of 300 rays x 64 samples of which 117 rays are live, plus one whose count is zero."""
+    from mirror_nerf_amd import _lib
+    from mirror_nerf_amd.autograd import FieldFn, _Pending
+    from mirror_nerf_amd.weights import params_of
+    system = _system(perturb=0.0, noise_std=0.0)
+    model = system.nerf_coarse
+    torch.manual_seed(1)
+    N, S = 300, 64
+    rays = torch.randn(N, 8, device=DEV) * 0.5
+    z = torch.sort(torch.rand(N, S, device=DEV) * 4 + 0.1, 1)[0]
+    de = torch.randn(N, 27, device=DEV)
+
+    def run(n_live, rows):
+        system.zero_grad(set_to_none=True)
+        want = (False, 0, None, n_live) if n_live is not None else False
+        sigma, rgb, pn, mir, _ = FieldFn.apply(model, S, None, rays[:rows].contiguous(), z[:rows].contiguous(), de[:rows].contiguous(),
+                                               want, *params_of(model))
+        live = rows if n_live is None else int(n_live.item())
+        (sigma.view(rows, S)[:live].sum() + (rgb.view(rows, S, 3)[:live] ** 2).sum() + pn.view(rows, S, 3)[:live, :, 0].sum()
+         + mir.view(rows, S)[:live].sum()).backward()
+        return [q.grad.detach().clone() for q in params_of(model)]
+    ref = run(None, 117)
+    got = run(torch.tensor([117], dtype=torch.int32, device=DEV), N)
+    _cmp_grads(got, ref, 2e-5)
+    none = run(torch.tensor([0], dtype=torch.int32, device=DEV), N)
+    assert all(float(g.abs().max()) == 0.0 for g in none)
