@@ -31,8 +31,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H = W = 800
-N_SAMPLES, N_IMPORTANCE, CHUNK = 64, 128, 32768
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide, dense f16/bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 # MFMA FLOPs the split kernel EXECUTES per full sample: 1308 hi/lo tile pairs x 3 products x 2 groups x 4 waves x
@@ -42,7 +40,8 @@ SPLIT_EXECUTED_FLOP_FULL = 1308 * 3 * 2 * 4 * 16384 // 128
 # roofline.traffic: HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of THIS command
 # (scripts/pmc_passes.sh -> profiles/traffic.json, keyed by kernel name; FETCH_SIZE doubled per the guide's gfx950
 # correction + WRITE_SIZE).  PMC counters cannot be read from inside the run: a kernel without an entry reports null.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
+from mirror_nerf_amd.benchlegs import (ARGS, CHUNK, H, N_IMPORTANCE, N_SAMPLES, W, _pmc, _traffic,  # noqa: E402,F401
+                                       clustered_balance, hash_grid_leg, roughness_leg, trained_leg)
 
 
 def build_models(dev):
@@ -52,22 +51,57 @@ def build_models(dev):
     return models, sds, {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
 
 
-ARGS = dict(predict_normal=True, only_one_field=False, only_one_field_fine_epoch=2, max_recursive_level=1)
+
+def _physical_cores():
+    """Physical cores of the host (the CPU baseline runs on a FIXED thread count = physical cores): distinct
+    (package, core) pairs of /proc/cpuinfo, else the logical count."""
+    try:
+        seen, pkg = set(), "0"
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pkg = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    seen.add((pkg, line.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def _cpu_reps(run, sample, budget_s, reps=3, trial_n=256, cap=16384):
+    """run(rays) -> (seconds, reflected rays).  One warm-up, a trial that sizes the sample for ~budget_s / reps seconds per
+    repetition, then `reps` timed repetitions of the SAME sample -> (n, reflected, [seconds...])."""
+    run(sample(64))                                   # warm-up (thread pools, allocator)
+    dt, _ = run(sample(trial_n))
+    n = int(min(cap, max(trial_n, budget_s / reps / dt * trial_n)))
+    n -= n % 64
+    r = sample(n)
+    times, traced = [], 0
+    for _ in range(reps):
+        dt, traced = run(r)
+        times.append(dt)
+    return n, traced, times
+
+
+def _rate_stats(n_rays, times):
+    rates = sorted(n_rays / t for t in times)
+    return {"median": rates[len(rates) // 2], "min": rates[0], "max": rates[-1], "repetitions": len(rates)}
 
 
 def cpu_baseline(sds, budget_s=20.0):
-    """The reference's path on the host cores, on a bounded sample of the same workload (primary rays spread over
-    the frame + their reflected rays), two ways:
-      * `value`: oracle/torch_port.py -- plain torch CPU ops in the reference's own op structure (cat + linear per
-        layer, chunk 32768, cumprod, searchsorted, sort), torch.set_num_threads(threads): what the reference's CPU
-        path costs here;
-      * `numpy_oracle`: oracle/mirror_nerf_oracle.py, the bit-careful checker the parity tests use, for the record.
-    The sample is sized from a short trial so that each leg takes about `budget_s`/2 seconds."""
+    """The reference's path on the host cores, on a bounded sample of the same workload (primary rays spread over the frame +
+    their reflected rays): oracle/torch_port.py -- plain torch CPU ops in the reference's own op structure (cat + linear per
+    layer, chunk 32768, cumprod, searchsorted, sort).  BASELINE.md section 4: fixed thread count = the host's physical cores,
+    one warm-up, THREE repetitions of one sample, median reported with min / max (rounds 1-4 reported a single shot at a
+    thread count picked by a trial: 405 / 783 / 1312 / 814 rays/s over four rounds was that lottery).  `numpy_oracle`: the
+    bit-careful checker of the parity tests, one repetition, for the record."""
     import torch
     from threadpoolctl import threadpool_limits
     from oracle import mirror_nerf_oracle as O
     from oracle import torch_port as TP
-    ncpu = os.cpu_count() or 1
+    threads = _physical_cores()
     rays = O.synthetic_rays(H, W)
 
     def sample(n):
@@ -86,416 +120,63 @@ def cpu_baseline(sds, budget_s=20.0):
                             CHUNK, ARGS)
         return time.perf_counter() - t0, int((out["mirror_mask_fine"] != 0).any()) * r.shape[0]
 
-    # torch's CPU ops do not scale to every core of a big host (the elementwise sin / cat / relu passes of this path
-    # are memory-bound and the GEMMs are small): try a few thread counts on a short trial and keep the fastest
-    best = None
-    for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
-        torch.set_num_threads(t)
-        with threadpool_limits(limits=t):
-            run_torch(sample(64))
-            dt, _ = run_torch(sample(256))
-        if best is None or dt < best[1]:
-            best = (t, dt)
-    threads = best[0]
     torch.set_num_threads(threads)
-
-    def sized(run, trial_n=256):
-        run(sample(64))                                   # warm-up (thread pools, allocator)
-        dt, _ = run(sample(trial_n))
-        n = int(min(16384, max(trial_n, 0.5 * budget_s / dt * trial_n)))
-        n -= n % 64
-        dt, traced = run(sample(n))
-        return n, traced, dt
-
     with threadpool_limits(limits=threads):
-        n_t, tr_t, dt_t = sized(run_torch)
+        n_t, tr_t, times_t = _cpu_reps(run_torch, sample, 0.75 * budget_s)
         O.set_sgemm(lambda x, w: torch.mm(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(w).t()).numpy())
         try:
-            n_n, tr_n, dt_n = sized(run_numpy)
+            n_n, tr_n, times_n = _cpu_reps(run_numpy, sample, 0.25 * budget_s, reps=1)
         finally:
             O.set_sgemm(None)
-    return {"value": (n_t + tr_t) / dt_t, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{n_t} primary + {tr_t} reflected rays of the same frame, oracle/torch_port.py (plain torch CPU ops in "
-                      f"the reference's op structure, chunk {CHUNK}, {threads} threads = the fastest of a trial over 8..{ncpu}), {dt_t:.1f} s",
-            "numpy_oracle": {"value": (n_n + tr_n) / dt_n, "unit": "rays/s", "cores": threads,
+    st = _rate_stats(n_t + tr_t, times_t)
+    return {"value": st["median"], "unit": "rays/s", "cores": threads, "kind": "port", "min": st["min"], "max": st["max"],
+            "repetitions": st["repetitions"], "logical_cpus": os.cpu_count(),
+            "sample": f"{n_t} primary + {tr_t} reflected rays of the same frame, oracle/torch_port.py (plain torch CPU ops in the "
+                      f"reference's op structure, chunk {CHUNK}), {threads} threads = physical cores, one warm-up + "
+                      f"{len(times_t)} repetitions of {sum(times_t) / len(times_t):.1f} s: median (min / max beside it)",
+            "numpy_oracle": {"value": (n_n + tr_n) / times_n[0], "unit": "rays/s", "cores": threads,
                              "sample": f"{n_n} primary + {tr_n} reflected rays, oracle/mirror_nerf_oracle.py with torch's CPU "
-                                       f"sgemm as its GEMM backend ({threads} threads), {dt_n:.1f} s"}}
+                                       f"sgemm as its GEMM backend ({threads} threads), one repetition of {times_n[0]:.1f} s"}}
 
 
-def hash_grid_leg(dev, rays):
-    """BASELINE config 5 for the record (not `value`): the hash-grid field (MirrorNeRFTcnn, bound 6, 2^19 x 16 x 2 table)
-    on the same 800x800 rays -- one frame of primary rays through render_rays (64 sigma-only + 192 full samples), and the
-    1024-ray training step (forward + hand-written backward + gradient all-reduce + Adam).  With N ranks (config 5 is worded
-    "... 8xMI355X"): every rank renders the whole frame (weak scaling, no data-path collective) and the training step reduces
-    the two table gradients in place and the MLP gradients as one blob per model (dist._module_messages)."""
+def config1_cpu(sd_coarse, budget_s=8.0):
+    """BASELINE config 1 as worded -- 400x400, coarse-only 64 samples, one bounce, "PyTorch CPU path (plumbing, no GPU)" -- on the
+    host cores: the torch port under TRAIN semantics with a ground-truth mirror mask (the centred 25 % rectangle of SURVEY 8d),
+    a bounded sample of the 160 000 + 40 000 rays, three repetitions, median."""
     import torch
-    import mirror_nerf_amd as M
-    from mirror_nerf_amd import dist as D
-    rank, world = D.world()
-    collective = world > 1 or D.forced()
-    torch.manual_seed(0)
-    models = {k: M.MirrorNeRFTcnn(encoding="hashgrid", bound=6.0, predict_normal=True, predict_mirror_mask=True).to(dev)
-              for k in ("coarse", "fine")}
-    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    from threadpoolctl import threadpool_limits
+    from oracle import mirror_nerf_oracle as O
+    from oracle import torch_port as TP
+    threads = _physical_cores()
+    Hc = Wc = 400
+    rays = O.synthetic_rays(Hc, Wc)
+    gt = np.zeros((Hc, Wc), np.float32)
+    gt[Hc // 4: Hc - Hc // 4, Wc // 4: Wc - Wc // 4] = 1.0
+    gt = gt.reshape(-1)
+    mt = {"coarse": {n: torch.from_numpy(v) for n, v in sd_coarse.items()}}
 
-    def frame():
-        with torch.no_grad():
-            for c in range(0, rays.shape[0], CHUNK):
-                M.render_rays(models, emb, rays[c:c + CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, CHUNK, test_time=True,
-                              compute_normal=False)
-    frame()
-    torch.cuda.synchronize()
-    from mirror_nerf_amd import mirror_nerf as MN
-    MN.LAUNCH_LOG = []
-    if collective:
-        torch.distributed.barrier()
-    t0 = time.perf_counter()
-    frame()
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0
-    dt_f = D.max_over_ranks(dt_own, dev)
-    log, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
-    full = [(B, e0.elapsed_time(e1)) for (flags, B, e0, e1) in log if (flags & 0x1000) and not (flags & 1)]
-    ms_full = sum(t for _, t in full)
-    # the dominant kernel of this variant is gather-bound: 16 levels x 8 corners x 8 B (float2) = 1 KiB of table reads per
-    # sample, from a 53 MB table (Infinity-Cache resident: the HBM peak is the contract's yardstick, not the binding limit)
-    gbs = sum(B for B, _ in full) * (1024 + 256) / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
-    # the binding limit: random gathers out of the Infinity Cache, measured on this very table (mnrf_bench_gather)
-    from mirror_nerf_amd import _lib
-    table = models["fine"].encoder.embeddings.detach()
-    sink = torch.zeros(4, device=dev)
-    ceil = {}
-    for key, nbytes, span in (("random_8B", 8, table.numel() * 4), ("random_4B", 4, table.numel() * 4), ("l2_resident_8B", 8, 2 << 20)):
-        n_thr, iters = 256 * 4096, 256
-        _lib.check(_lib.lib().mnrf_bench_gather(_lib.ptr(table), span, nbytes, n_thr, iters, _lib.ptr(sink), _lib.stream()), "gather")
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            _lib.check(_lib.lib().mnrf_bench_gather(_lib.ptr(table), span, nbytes, n_thr, iters, _lib.ptr(sink), _lib.stream()), "gather")
-        e1.record()
-        torch.cuda.synchronize()
-        ceil[key] = 3 * n_thr * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9       # G gathers / s
-    gathers_per_s = sum(B for B, _ in full) * 128 / (ms_full * 1e-3) / 1e9 if ms_full > 0 else 0.0
-    # the level-major encoding launch on its own (mnrf_tcnn_encode) and the whole field evaluation on the same fine-pass samples
-    with torch.no_grad():
-        rc = M.render_rays(models, emb, rays[:CHUNK], N_SAMPLES, False, 0, 0, N_IMPORTANCE, CHUNK, test_time=True, compute_normal=False)
-    zf = rc["z_vals_fine"].contiguous()
-    mfine = models["fine"]
-    from mirror_nerf_amd.mirror_nerf_tcnn import _offsets17
-    offs = _offsets17(mfine.cfg)
-    planes = torch.empty(32 * zf.numel(), device=dev)
-    rchunk = rays[:CHUNK].contiguous()
-    pr = lambda: _lib.check(_lib.lib().mnrf_tcnn_encode(  # noqa: E731
-        _lib.ptr(table), offs, mfine.cfg["S"], mfine.cfg["H"], float(mfine.bound), zf.numel(), None, 0,
-        _lib.ptr(rchunk), _lib.ptr(zf), zf.shape[1], _lib.ptr(planes), _lib.stream()), "encode")
-    pr()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        pr()
-    e1.record()
-    torch.cuda.synchronize()
-    enc_ms = e0.elapsed_time(e1) / 5
-    planes = None
-    MN.LAUNCH_LOG = []
-    with torch.no_grad():
-        for _ in range(3):
-            mfine.field(zf.numel(), rays=rchunk, z_vals=zf, spr=zf.shape[1])
-    torch.cuda.synchronize()
-    same_ms = sum(a_.elapsed_time(b_) for (_f, _B, a_, b_) in MN.LAUNCH_LOG) / 3
-    MN.LAUNCH_LOG = None
-    one_launch_ms = None
-    for m in models.values():
-        m.enc_planes_min = 1 << 62
-    MN.LAUNCH_LOG = []
-    with torch.no_grad():
-        for _ in range(3):
-            mfine.field(zf.numel(), rays=rchunk, z_vals=zf, spr=zf.shape[1])
-    torch.cuda.synchronize()
-    one_launch_ms = sum(a_.elapsed_time(b_) for (_f, _B, a_, b_) in MN.LAUNCH_LOG) / 3
-    MN.LAUNCH_LOG = None
-    for m in models.values():
-        del m.enc_planes_min
-    pmc = _pmc("mnrf::mf::tcnn_encode_kernel")
-    l2_bytes = pmc.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0 if pmc else None      # 128-byte lines requested from the L2 per launch
-    # single-pass f16 MLPs ("fp16 MLP on CDNA4 MFMA", BASELINE config 5; module.mlp_f16): the frame again
-    for m in models.values():
-        m.mlp_f16 = True
-    frame()
-    torch.cuda.synchronize()
-    MN.LAUNCH_LOG = []
-    t0 = time.perf_counter()
-    frame()
-    torch.cuda.synchronize()
-    dt_f16 = D.max_over_ranks(time.perf_counter() - t0, dev)
-    log16, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
-    full16 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log16 if (flags & 0x1000) and not (flags & 1)]
-    sig16 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log16 if (flags & 0x1000) and (flags & 1)]
-    sig32 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log if (flags & 0x1000) and (flags & 1)]
-    for m in models.values():
-        m.mlp_f16 = False
-    ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_encode_kernel")
-    params = [p for m in models.values() for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # (one multi-tensor launch; the default "foreach" form is ~10 passes over the two 49 MB tables)
-    target = torch.rand(1024, 3, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)          # every rank draws its own batch (DistributedSampler semantics, SURVEY 8e)
-    D.attach_overlap(models.values())  # (no-op on one rank) the all-reduces go out from inside the backward pass
-    ar_ms, touched = [], []
+    def sample(n):
+        return np.linspace(0, rays.shape[0] - 1, n).astype(np.int64)
 
-    def step(measure=False):
-        idx = torch.randint(0, rays.shape[0], (1024,), device=dev, generator=gen)
-        res = M.render_rays(models, emb, rays[idx], N_SAMPLES, False, 1, 1, N_IMPORTANCE, compute_normal=False)
-        loss = ((res["rgb_coarse"] - target) ** 2).mean() + ((res["rgb_fine"] - target) ** 2).mean() \
-            + 0.1 * ((res["mirror_mask_fine"] - 0.5) ** 2).mean() + 1e-4 * res["surface_normal_fine"].pow(2).sum(-1).mean()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if measure:      # (host reads: outside the timed loop)
-            touched.append([int((m.encoder.embeddings.grad != 0).any(-1).sum()) for m in models.values()])
-        if collective:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            D.allreduce_gradients(params, modules=list(models.values()))
-            e1.record()
-            ar_ms.append((e0, e1))
-        opt.step()
-    for _ in range(3):
-        step()
-    step(measure=True)
-    torch.cuda.synchronize()
-    del ar_ms[:]
-    if collective:
-        torch.distributed.barrier()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        step()
-    torch.cuda.synchronize()
-    dt_t_own = (time.perf_counter() - t0) / 20
-    dt_t = D.max_over_ranks(dt_t_own, dev)
-    entries = int(models["fine"].encoder.embeddings.shape[0])
-    D.detach_overlap(list(models.values()))
-    allreduce = None
-    if collective:
-        t_all = torch.tensor([dt_own, dt_t_own], dtype=torch.float64, device=dev)
-        parts = [torch.zeros_like(t_all) for _ in range(world)]
-        torch.distributed.all_gather(parts, t_all)
-        per_rank = torch.stack(parts).cpu()
-        allreduce = {"messages_per_step": 4, "bytes_per_step": int(sum(q.numel() for q in params) * 4),
-                     "wait_ms_per_step_rank0": sum(a.elapsed_time(b) for a, b in ar_ms) / max(1, len(ar_ms)),
-                     "frame_s_per_rank": [round(float(v), 4) for v in per_rank[:, 0]],
-                     "train_ms_per_rank": [round(float(v) * 1e3, 3) for v in per_rank[:, 1]],
-                     "imbalance_train": float(per_rank[:, 1].max() / per_rank[:, 1].min()),
-                     "note": "per model: the table gradient (one tensor) all-reduced in place + one blob of the 11 MLP gradients, "
-                             "issued from the post-accumulate hooks of the backward pass; wait = time spent inside "
-                             "allreduce_gradients after the backward (what was not hidden behind it)"}
-    sparse = {"touched_entries_per_step": touched[0], "table_entries": entries,
-              "touched_fraction": [t / entries for t in touched[0]],
-              "dense_bytes_per_model": entries * 8, "sparse_index_value_bytes_per_model": [t * 12 for t in touched[0]],
-              "sparse_over_dense": [t * 12 / (entries * 8) for t in touched[0]],
-              "note": "rows of the table (coarse, fine model) that a 1024-ray batch (65 536 + 196 608 samples x 128 corner reads) "
-                      "touches.  A sparse index + float2 exchange (SURVEY 8e) moves 12 B per touched row PER RANK and needs an "
-                      "all-gather of variable-size lists (world x that, then a local merge); the dense in-place all-reduce moves "
-                      "8 B per row whatever the world size.  With half of the fine table touched by one rank's batch the sparse "
-                      "form is not smaller at 1 rank and strictly larger from 2 ranks on: the dense all-reduce is kept"}
-    # the same step with the table gradient of the big hashed levels accumulated in half2 by packed atomics (tinycudann's
-    # gradient precision: models/mirror_nerf_tcnn.py:36-49 under train.py:586; module.table_grad_f16, off by default)
-    for m in models.values():
-        m.table_grad_f16 = True
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        step()
-    torch.cuda.synchronize()
-    dt_t16 = (time.perf_counter() - t0) / 10
-    for m in models.values():
-        m.table_grad_f16 = False
-    n = rays.shape[0]
-    return {"rays_per_s": world * n / dt_f, "samples_per_s": world * n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
-            "n_gpus": world, "scaling": "weak (every rank renders the frame / draws its own 1024-ray batch)",
-            "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
-            "table_gradient_sparsity": sparse,
-            "train_ms_per_step_f16_table_grads": dt_t16 * 1e3,
-            "train_table_gradient": "default: one packed 64-bit fixed-point atomic per entry (MNRF_TCNN_GRAD_FIXED, exact integer sums); _f16_table_grads: packed half2 atomics",
-            "gather_roofline": {"bound": "l2", "kernel": "mnrf::mf::tcnn_encode_kernel (level-major encoding: 16 levels x 8 corners per sample; "
-                                          "the dominant launch of the two-launch field evaluation)",
-                                "achieved": (l2_bytes / (enc_ms * 1e-3) / 1e9) if l2_bytes else None, "peak": 34500.0, "unit": "GB/s",
-                                "frac": (l2_bytes / (enc_ms * 1e-3) / 1e9 / 34500.0) if l2_bytes else None,
-                                "l2_read_bytes_per_launch": l2_bytes, "l2_hit_rate": (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]))
-                                if pmc and "TCC_HIT_sum" in pmc else None,
-                                "tcp_hit_rate": (1.0 - pmc["TCP_TCC_READ_REQ_sum"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"])
-                                if pmc and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc else None,
-                                "encode_ms": enc_ms, "field_ms_same_samples": same_ms, "encode_share_of_field": enc_ms / same_ms if same_ms else None,
-                                "one_launch_form_ms": one_launch_ms, "G_gathers_per_s": zf.numel() * 128 / (enc_ms * 1e-3) / 1e9,
-                                "context": {"independent_random_8B_gathers_in_a_2MiB_window": ceil["l2_resident_8B"],
-                                            "uniformly_random_over_the_49MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]}},
-                                "counters_source": "static profile: profiles/traffic.json \"pmc\" (scripts/pmc_tcnn.sh), per launch of one 32768-ray chunk",
-                                "note": "every gather that misses the 32 KB vector L1 pulls a 128-byte line out of the L2 for 8 useful bytes; "
-                                        "achieved = those lines (PMC: TCP_TCC_READ_REQ x 128 B per launch) over the live launch time, against "
-                                        "the L2's ~34.5 TB/s (MI355X_MICROARCH.md).  Round 3's one-launch kernel walked all 16 levels per wave: "
-                                        "54 % of its lines missed the L2 too and 20.7 GB per launch crossed the fabric at 7.5 TB/s "
-                                        "(profiles/r04b_pmc_tcnn); level by level the L2 holds the level (hit rate above)."},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": ttr,
-                         "traffic_source": (f"static profile: profiles/traffic.json, commit {tcommit or 'unrecorded'}, {tsrc}") if ttr else None,
-                         "kernel": "mnrf::mf::tcnn_encode_kernel + mnrf::mf::tcnn_mfma_kernel<0,true> (full evaluation, fine pass)",
-                         "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024 + 256,
-                         "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * (1024 + 256),
-                         "note": "ALGORITHMIC bytes (128 float2 table reads + the 128-byte encoding planes written and read once, per "
-                                 "sample) over the time of the two launches; `traffic` = what reached the fabric in the encoding launch "
-                                 "(PMC).  The table is cache-resident: gather_roofline (L2) is the ceiling that binds, this fraction "
-                                 "is kept for the contract"},
-            "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
-                        "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
-                        "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
-                        "sigma_only_launch_ms_default_arithmetic": sum(t for _, t in sig32) / max(1, len(sig32)),
-                        "note": "module.mlp_f16 / MNRF_TCNN_F16: single-pass f16 MLPs on the matrix pipe (one MFMA per product, fp32 "
-                                "accumulation) -- \"fp16 MLP on CDNA4 MFMA\" as BASELINE config 5 words it, the arithmetic of tinycudann "
-                                "under precision=16 (train.py:586); ~1e-3 relative to the default (tests); sigma-only launches on "
-                                "the matrix pipe as well"},
-            "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
-                    "downstream of the encoder pinned by fixtures G17, the encoder's interpolation unpinned (DESIGN.md 2.2); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
-                    "sigma-only launches: the same two launches since round 4 (fp32 VALU kernel below 32768 samples)"}
-
-
-def trained_leg(dev):
-    """Scene-dependent effects need trained weights: the pair of fixture G11 (tests/golden/g11_trained_weights.npz: trained on the
-    analytic mirror scene of make_golden_trained.py through this package, 19.1 dB held-out) rendered at 800x800 from a view of
-    that scene (the scene_views camera at angle 0.2), eval rules with the PREDICTED mirror mask -- plain frame and ray-fused
-    maps-only frame, with mean power x time = energy per frame and the clock.  Not `value` (random-init weights stay the headline)."""
-    import numpy as np
-    import torch
-    import mirror_nerf_amd as M
-    from mirror_nerf_amd import mirror_nerf as MN, synthetic as SY
-    from mirror_nerf_amd.telemetry import SmiSampler
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g11_trained_weights.npz")
-    if not os.path.exists(path):
-        return None
-    z = np.load(path)
-    models = {}
-    for name in ("coarse", "fine"):
-        m = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
-        m.load_state_dict({k[len(name) + 2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "__")})
-        models[name] = m.to(dev)
-    emb = {"xyz": M.Embedding(10), "dir": M.Embedding(4)}
-    a = 0.2
-    pose = SY.look_at_pose(eye=(2.6 * np.sin(a), -2.6 * np.cos(a) + 0.2, 0.9 + 0.5), target=(0.1, 0.6, 0.6))
-    rays = SY.device_rays(H, W, dev, pose=pose, camera_angle_x=0.9)
-    out = {}
-    for key, kw in (("plain", {}), ("maps_only_fused", {"maps_only": True})):
-        f = lambda: M.batched_inference(models, emb, rays, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,  # noqa: E731
-                                        trace_secondary_rays=True, to_cpu=False, **kw)
-        r = f()
-        torch.cuda.synchronize()
-        MN.LAUNCH_LOG = []
-        smi = SmiSampler(dev.index or 0, 0.2)
-        with smi:
-            t0 = time.perf_counter()
-            for _ in range(2):
-                r = f()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 2
-        n_launch = len(MN.LAUNCH_LOG) / 2
-        MN.LAUNCH_LOG = None
-        tele = smi.summary()
-        pw = (tele.get("power_w") or {}).get("median")
-        mask = r["mirror_mask_fine"]
-        n_refl = float((mask > 0.5).sum())
-        out[key] = {"rays_per_s": (H * W + n_refl) / dt, "ms_per_frame": dt * 1e3, "field_launches_per_frame": n_launch,
-                    "power_w_median": pw, "energy_j_per_frame": pw * dt if pw else None,
-                    "sclk_mhz_median": (tele.get("sclk_mhz") or {}).get("median")}
-        out["reflected_rays_per_frame"] = n_refl
-        if key == "plain":
-            w = r.get("weights_fine")
-            out["fine_samples_with_zero_weight"] = float((w == 0).float().mean()) if w is not None else None
-    out["note"] = ("G11 trained pair, 800x800 view of its analytic scene, eval rules (predicted mask: reflected rays = mirror pixels "
-                   "of chunks that hold any); fine_samples_with_zero_weight = the share of samples whose heads exact head skipping "
-                   "(models/rendering.py:190-213: w_i = 0) could leave out -- not built, DESIGN.md 8")
-    return out
-
-
-def roughness_leg(dev, models, emb):
-    """BASELINE config 4 at the shape run.sh:185-208 runs it (mode 5, control_mirror_roughness): 480x360 (run.sh:47-48),
-    64 coarse + 64 importance samples, chunk 16384, one bounce, trace_ray_times = 64 jittered reflections per mirror ray,
-    normal_noise_std = 0.0025, every pixel a mirror (so that the reference's level-0 addition is well-formed):
-    172 800 primary + 65 x 172 800 reflected rays per frame.  The 64 jittered renders of a chunk go through the recursion
-    in groups (recursion.JITTER_RAYS) instead of one by one.  Also: two bounces with eval.py's default trace_ray_times = 4
-    (the jitters nest: (1 + 5) + 5 x ... renders per level)."""
-    import torch
-    import mirror_nerf_amd as M
-    from mirror_nerf_amd import synthetic as SY
-    Hc, Wc = 360, 480
-    rays = SY.device_rays(Hc, Wc, dev)
-    out = {}
-    for name, levels, times in (("one_bounce_64_jitters", 1, 64), ("two_bounces_4_jitters", 2, 4)):
-        args = dict(ARGS, max_recursive_level=levels, app_control_mirror_roughness=True, trace_ray_times=times)
-
-        def frame():
-            return M.batched_inference(models, emb, rays, N_SAMPLES, 64, False, 16384, args=args, trace_secondary_rays=True,
-                                       normal_noise_std=0.0025, to_cpu=False)
-        if name.startswith("one"):
-            M.batched_inference(models, emb, rays[:16384], N_SAMPLES, 64, False, 16384, args=args, trace_secondary_rays=True,
-                                normal_noise_std=0.0025, to_cpu=False)      # warm-up on one chunk
-        torch.cuda.synchronize()
+    def run(idx):
+        r, m = torch.from_numpy(np.ascontiguousarray(rays[idx])), torch.from_numpy(np.ascontiguousarray(gt[idx]))
         t0 = time.perf_counter()
-        frame()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        n = Hc * Wc
-        rays_total = n * (1 + (times + 1)) if levels == 1 else n * (1 + (times + 1) * (1 + (times + 1)))
-        out[name] = {"rays_per_s": rays_total / dt, "frame_s": dt, "rays_per_frame": rays_total,
-                     "samples_per_s": rays_total / dt * (2 * N_SAMPLES + 64)}
-    out["note"] = ("eval.batched_inference with app_control_mirror_roughness on the all-mirror random-init pair, 480x360, "
-                   "64+64 samples, chunk 16384, normal_noise_std 0.0025 (run.sh:185-208); jittered reflections batched per level")
-    return out
-
-
-def clustered_balance(dev, models, rays, rank, world, sync):
-    """Load balance of the ray sharding when mirror pixels CLUSTER: one frame under train semantics
-    (NeRFSystem.forward, train.py:102-348) with a ground-truth mirror mask = the centred rectangle covering 25 % of the
-    pixels and only_trace_rays_in_mirrors -- each rank renders its interleaved 4096-ray tiles plus the reflections of the
-    mirror pixels among them.  Reports every rank's frame time and reflected-ray count, and max / mean of both; next to it
-    the reflected-ray counts a CONTIGUOUS stripe per rank would get (computed, not rendered): the reason for interleaving."""
-    import torch
-    import torch.distributed as dist
-    from mirror_nerf_amd import dist as D
-    from mirror_nerf_amd import training
-    from mirror_nerf_amd.recursion import NeRFSystem
-    hp = training.default_hparams(N_importance=N_IMPORTANCE, perturb=0.0, noise_std=0.0, chunk=CHUNK)
-    system = NeRFSystem(hp).to(dev)
-    system.nerf_coarse.load_state_dict(models["coarse"].state_dict())
-    system.nerf_fine.load_state_dict(models["fine"].state_dict())
-    gt = torch.zeros(H, W, device=dev)
-    gt[H // 4: H - H // 4, W // 4: W - W // 4] = 1.0
-    gt = gt.view(-1)
-    idx = D.shard_indices(rays.shape[0], rank, world, D.TILE, rays.device)
-    r, m = rays[idx].contiguous(), gt[idx].contiguous()
-    extra = {"mirror_mask": m, "is_eval": False, "train_geometry_stage": False}
-    with torch.no_grad():
-        system(r[:CHUNK], {k: (v[:CHUNK] if torch.is_tensor(v) else v) for k, v in extra.items()})      # warm-up
-        sync()
-        t0 = time.perf_counter()
-        system(r, extra)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    mine = torch.tensor([dt, float(m.sum().item()), float(idx.numel())], dtype=torch.float64, device=dev)
-    allr = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allr, mine)
-    allr = torch.stack(allr).cpu()
-    times, refl = allr[:, 0].tolist(), allr[:, 1].tolist()
-    stripe = rays.shape[0] // world
-    contiguous = [float(gt[k * stripe: (k + 1) * stripe].sum().item()) for k in range(world)]
-
-    def imb(v):
-        mean = sum(v) / len(v)
-        return max(v) / mean if mean > 0 else None
-    return {"frame_s_per_rank": times, "reflected_rays_per_rank": refl, "primary_rays_per_rank": allr[:, 2].tolist(),
-            "time_imbalance_max_over_mean": imb(times), "reflected_imbalance_max_over_mean": imb(refl),
-            "contiguous_stripes_reflected_per_rank": contiguous, "contiguous_stripes_imbalance_max_over_mean": imb(contiguous),
-            "note": "train semantics, GT mirror mask = centred 25 % rectangle, only_trace_rays_in_mirrors; interleaved 4096-ray tiles "
-                    "(rendered) vs contiguous stripes (counted only)"}
+        TP.render_train_coarse(mt, r, m, N_SAMPLES, CHUNK)
+        return time.perf_counter() - t0, int(m.sum())
+    torch.set_num_threads(threads)
+    with threadpool_limits(limits=threads):
+        run(sample(64))
+        dt, _ = run(sample(512))
+        n = int(min(65536, max(512, budget_s / 3 / dt * 512)))
+        idx = sample(n - n % 64)
+        times, refl = [], 0
+        for _ in range(3):
+            dt, refl = run(idx)
+            times.append(dt)
+    st = _rate_stats(len(idx) + refl, times)
+    return {"value": st["median"], "min": st["min"], "max": st["max"], "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{len(idx)} primary + {refl} reflected rays spread over the 400x400 frame, coarse-only 64 samples, "
+                      f"oracle/torch_port.render_train_coarse, {threads} threads, 3 repetitions of {sum(times) / 3:.1f} s"}
 
 
 def _respawn(a):
@@ -520,25 +201,6 @@ def _build_commit():
         return None
 
 
-def _pmc(kernel):
-    """Counters of `kernel` (one launch of a 32768-ray chunk) from the static profile, {} when absent."""
-    try:
-        with open(TRAFFIC_JSON) as f:
-            return json.load(f).get("pmc", {}).get(kernel, {})
-    except (OSError, ValueError):
-        return {}
-
-
-def _traffic(kernel):
-    try:
-        with open(TRAFFIC_JSON) as f:
-            t = json.load(f)
-        e = t.get(kernel)
-        return (e["hbm_bytes_per_launch"], e.get("source"), e.get("commit")) if e else (None, None, None)
-    except (OSError, ValueError, KeyError):
-        return None, None, None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,6 +213,11 @@ def main():
                     help="arithmetic of the field kernel's Linears: fp32 operands as hi/lo f16 pairs on the f16 matrix "
                          "pipe (default, ~1e-6 of fp32) or the bit-exact fp32 MFMA chain")
     a = ap.parse_args()
+    # MNRF_BENCH_LEGS=headline,strong,other,host_maps,fused,train,train_total,config3,hash_grid,rough,trained,config1,cpu : run only
+    # these secondary legs (default: all that apply) -- an 8-rank run can be bounded to "headline,strong,train"
+    want = os.environ.get("MNRF_BENCH_LEGS")
+    want = None if not want else {w.strip() for w in want.split(",") if w.strip()}
+    leg = (lambda name: True) if want is None else (lambda name: name in want)
 
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("MNRF_BENCH_SPAWN") == "1"):
         _respawn(a)          # MNRF_BENCH_SPAWN=1: take the launcher path at N = 1 too (tests on a 1-GPU box)
@@ -627,11 +294,14 @@ def main():
     sig_tf = sum(B for B, _ in sig) * MN.FLOP_SIGMA / (ms_sig * 1e-3) / 1e12 if ms_sig > 0 else 0.0
 
     # everything the line is assembled from, so that emit() can run at any point from here on
-    strong = other_tf = other_rays = other_ms = smi_other = host_maps = fused = train = hash_grid = rough = trained = None
+    strong = other_tf = other_rays = other_ms = smi_other = host_maps = fused = train = hash_grid = rough = trained = config1 = None
     legs_done = []
 
-    def emit(incomplete=None):
-        """Rank 0 prints the ONE line.  `incomplete`: legs cut short by the deadline below (N > 1 only)."""
+    def emit(incomplete=None, early=False):
+        """Rank 0 prints the line.  N = 1: ONE line, at the end.  N > 1: the headline line goes out RIGHT AFTER the weak-scaling
+        measurement (`"line": "headline"`, flushed), the complete one replaces it at the end (`"line": "complete"`): a harness
+        takes the last parseable line, and a stall in a secondary leg cannot cost the run its number.  `incomplete`: legs cut
+        short by the deadline below."""
         if rank == 0:
             split = a.precision == "split"
             peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
@@ -656,7 +326,7 @@ def main():
                            "train_step_workload": "1024 rays per GPU, perturb = noise_std = 1, 25 % GT mirror rays reflected once; train_step: "
                                                   "run.sh:266's schedule (64 coarse + 128 fine samples, --N_importance 64); "
                                                   "train_step.config3_64_plus_192: BASELINE config 3 as worded (64 + 192, --N_importance 128)",
-                           "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (MNRF_SHARE_GPU test aid: timings void)")) if multi else None,
+                           "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (not RCCL: timings void)")) if multi else None,
                            "rccl_world_size": dist.get_world_size() if multi else None},
                 "samples_per_s": value * evals_per_ray,
                 "field_evals_per_ray": evals_per_ray,
@@ -712,10 +382,18 @@ def main():
                 res["roughness_variant"] = rough
             if trained is not None:
                 res["trained_weights_variant"] = trained
-            if world == 1 and not a.no_cpu_baseline:
+            if config1 is not None:
+                res["config1"] = config1
+            if world == 1 and not a.no_cpu_baseline and leg("cpu") and not early:
                 res["cpu_baseline"] = cpu_baseline(sds, a.cpu_seconds)
+                if config1 is not None:
+                    config1["cpu_baseline"] = config1_cpu(sds[0])
             if incomplete:
                 res["incomplete_legs"] = incomplete
+            if multi:
+                res["line"] = "headline" if early else "complete"
+            if want is not None:
+                res["legs_requested"] = sorted(want)
             print(json.dumps(res), flush=True)
 
 
@@ -733,15 +411,18 @@ def main():
                                  "value / roofline were measured before them"})
             finally:
                 sys.stdout.flush()
-                os._exit(0)
+                # non-zero: a harness that keys on the return code must not record a cut run (a collective that never
+                # completed) as a pass; the headline line is on stdout all the same (MNRF_BENCH_DEADLINE_RC overrides)
+                os._exit(int(os.environ.get("MNRF_BENCH_DEADLINE_RC", "3")))
         deadline = threading.Timer(float(os.environ.get("MNRF_BENCH_LEG_DEADLINE", "900")), _expired)
         deadline.daemon = True
         deadline.start()
+        emit(early=True)
 
     # strong scaling: ONE frame (rank 0's view) dealt to the ranks in interleaved 4096-ray tiles; no collective while
     # rendering; then the optional assembly of the 20 B/ray maps on rank 0
     strong = None
-    if multi:
+    if multi and leg("strong"):
         common = SY.device_rays(H, W, dev)
         keys = ("rgb_fine", "depth_fine", "mirror_mask_fine")
         idx, res = D.render_sharded(render, common)                       # warm-up
@@ -768,7 +449,7 @@ def main():
     other = "fp32" if a.precision == "split" else "split"
     other_tf = other_rays = other_ms = smi_other = None
     host_maps = None
-    if world == 1:
+    if world == 1 and leg("other"):
         MN.set_precision(other)
         render(rays)                 # warm-up (first launches of the other kernels)
         torch.cuda.synchronize()
@@ -785,7 +466,7 @@ def main():
         other_ms = sum(t for _, t in t_o) / max(1, len(t_o))
         MN.LAUNCH_LOG = None
         MN.set_precision(a.precision)
-
+    if world == 1 and leg("host_maps"):
         # PCIe-inclusive rate (never `value`): frames whose per-ray maps are copied to the host (one untimed first: it pins the
         # staging buffers, as the first frame of an eval run does)
         render(rays, to_cpu="maps")
@@ -804,7 +485,7 @@ def main():
     # the same frame with per-ray maps only, results left on the device: the final pass ray-fused (field evaluation +
     # compositing in one kernel, head outputs in LDS, no per-sample tensor in HBM: SURVEY 3 "result-dict contract")
     fused = None
-    if world == 1:
+    if world == 1 and leg("fused"):
         render_maps = lambda r: M.batched_inference(models, emb, r, N_SAMPLES, N_IMPORTANCE, False, CHUNK, args=ARGS,  # noqa: E731
                                                     trace_secondary_rays=True, to_cpu=False, maps_only=True)
         render_maps(rays)
@@ -829,24 +510,36 @@ def main():
                          "of the final pass are not produced; to_cpu=\"maps\" (with_host_maps) takes the same kernels"}
 
     train = None
-    if not a.no_train:
+    if not a.no_train and leg("train"):
         from mirror_nerf_amd import training
         train = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024)
         legs_done.append("train_step")
-        train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total")
-        train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline")
-                                    if k in train_total}
-        # BASELINE config 3 as worded ("same config" as config 2: 64 coarse + 128 importance samples); the default above is
-        # run.sh:266's training schedule (--N_importance 64)
-        train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
-        train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
-                                                                  "reflected_rays_per_step", "allreduce")}
+        if world == 1 and leg("train_routes"):
+            # the same step on the reference's shape (the host reads the reflected-ray count in the middle of the step,
+            # train.py:175) and as host-issued static launches: what the round-5 routes are measured against
+            train["routes_ms_per_step"] = {train["route"]: train["ms_per_step"]}
+            for r_ in ("static", "host"):
+                t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, _route=r_)
+                train["routes_ms_per_step"][r_] = t_["ms_per_step"]
+        if leg("train_total"):
+            train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total")
+            train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline", "route")
+                                        if k in train_total}
+        if leg("config3"):
+            # BASELINE config 3 as worded ("same config" as config 2: 64 coarse + 128 importance samples); the default above is
+            # run.sh:266's training schedule (--N_importance 64)
+            train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
+            train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
+                                                                      "reflected_rays_per_step", "allreduce", "route")}
         legs_done.append("train_step.with_total_loss + config3_64_plus_192")
 
-    hash_grid = hash_grid_leg(dev, rays) if not a.no_train else None
+    hash_grid = hash_grid_leg(dev, rays) if (not a.no_train and leg("hash_grid")) else None
     legs_done.append("hash_grid_variant")
-    rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train) else None
-    trained = trained_leg(dev) if (world == 1 and not a.no_train) else None
+    rough = roughness_leg(dev, models, emb) if (world == 1 and not a.no_train and leg("rough")) else None
+    trained = trained_leg(dev) if (world == 1 and not a.no_train and leg("trained")) else None
+    if world == 1 and not a.no_train and leg("config1"):
+        from mirror_nerf_amd.benchlegs import config1_leg
+        config1 = config1_leg(dev)
 
     if deadline is not None:
         deadline.cancel()

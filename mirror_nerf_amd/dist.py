@@ -31,16 +31,12 @@ def init_from_env(device=None):
     """One process per GPU (train.py:577-584 gets the same from Lightning DDP): reads RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* as set by torch.distributed.run, binds this process to GPU LOCAL_RANK and brings up the RCCL group
     (backend "nccl" IS RCCL on ROCm).  A 1-rank group is only created when MNRF_FORCE_COLLECTIVES=1.
-    MNRF_SHARE_GPU=1 is a TEST AID for boxes with fewer GPUs than ranks: every rank binds GPU 0 and the group is "gloo"
-    (RCCL refuses two ranks on one device), so that the N > 1 code paths -- ray sharding, per-rank batches, the bucket
-    all-reduce issued from the backward hooks, max-over-ranks timing -- execute on device tensors; its timings mean nothing.
+    (The round-4 test aid that put several ranks on one GPU over gloo lives in tests/shared_gpu/ now: it replaces this
+    function from a sitecustomize hook of the test processes; nothing in the package knows about it.)
     Returns (rank, world_size, device)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    share = os.environ.get("MNRF_SHARE_GPU", "0") == "1"
-    if share:
-        local = 0
     if device is None:
         if local >= torch.cuda.device_count():
             raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
@@ -50,22 +46,11 @@ def init_from_env(device=None):
     if want_group and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if device.type == "cuda" and not share:
+        if device.type == "cuda":
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=ws)
     return rank, ws, device
-
-
-def host_staged():
-    """True under the MNRF_SHARE_GPU test aid (gloo moving device tensors through host memory, several ranks time-slicing one
-    GPU).  Measured on an MI355X (profiles/r04zk_README.txt): with FOUR ranks on one GPU, train_step's blocking flag all-reduce
-    behind two bucket all-reduces still in flight stalls for good at the 14th step -- every rank's collective sequence
-    identical (MNRF_DIST_TRACE=1), the host threads in kfd_wait_on_events, the GPU reported busy -- while 2 and 8 ranks run
-    through, and draining the device before the blocking collective removes it.  An effect of 4 processes x (compute + gloo's
-    pool streams) over-subscribing one GPU's hardware queues, not of the collective protocol; RCCL (one process per GPU,
-    stream-ordered, no host staging) has neither ingredient.  The aid therefore drains the device before that collective."""
-    return os.environ.get("MNRF_SHARE_GPU", "0") == "1" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
 
 
 def world():

@@ -105,6 +105,19 @@ GUARD_MODE = os.environ.get("MNRF_GUARD_MODE") or ("sync" if os.environ.get("MNR
 _SETTLE_LATE = os.environ.get("MNRF_GUARD_SETTLE_LATE", "1") != "0"      # 0: read the previous step's flags at the start of a step (A/B)
 
 
+_STATE_FLAGS = {}
+
+
+def _state_flags(device, has_split, has_pinned):
+    """[0, has_split, has_pinned] on `device`, built once per combination (a torch.tensor(list, device=cuda) per step is a
+    synchronous host-to-device copy: it drains the queue)."""
+    key = (str(device), bool(has_split), bool(has_pinned))
+    t = _STATE_FLAGS.get(key)
+    if t is None:
+        t = _STATE_FLAGS[key] = torch.tensor([0.0, float(has_split), float(has_pinned)], device=device)
+    return t
+
+
 def _takes_found_inf(optimizer):
     return bool(getattr(optimizer, "defaults", {}).get("fused")) or hasattr(optimizer, "mnrf_found_inf")
 
@@ -122,15 +135,21 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     token = system.__dict__.pop("_mnrf_guard_token", None)
 
     def settle(token):          # the previous step's flags
-        tripped_here = guard_async_end(token[0], adapt=token[1] is None and token[2] == "skip")      # (one rank, update skipped)
-        tripped_any = tripped_here if token[1] is None else bool(token[1].item())
-        if tripped_any and token[1] is not None:
-            pin_fp32(system)    # more than one rank: EVERY rank pins EVERY model, whoever tripped -- the ranks must keep issuing the
-                                # same collectives (a rank without a split model left would skip the guard's all-reduce)
+        tok, flags_host, tmode, ev = token
+        tripped_here = guard_async_end(tok, adapt=flags_host is None and tmode == "skip")      # (one rank, update skipped)
+        tripped_any, mixed = tripped_here, False
+        if flags_host is not None:      # more than one rank: [a rank tripped, a rank runs split models, a rank runs pinned ones]
+            if ev is not None:
+                ev.synchronize()
+            f = flags_host.tolist()
+            tripped_any, mixed = f[0] != 0.0, (f[1] != 0.0 and f[2] != 0.0)
+            if tripped_any or mixed:
+                pin_fp32(system)        # EVERY rank pins EVERY model, whoever tripped (or was pinned outside train_step: a validation
+                                        # pass on one rank) -- the ranks stay on the same kernels
         if tripped_any or tripped_here:
             import warnings
             warnings.warn("mirror_nerf_amd: the previous training step left the range of the split-f16 arithmetic; "
-                          + ("its optimizer update was skipped on every rank" if token[2] == "skip" else
+                          + ("its optimizer update was skipped on every rank" if tmode == "skip" else
                              "its update HAS BEEN APPLIED (MNRF_GUARD_MODE=async)")
                           + "; the models run on the fp32 kernels from now on", RuntimeWarning, stacklevel=3)
     # Reading them HERE would wait for the device to finish the previous step's backward pass (their event sits behind it) and
@@ -163,38 +182,58 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
     if mode == "sync":
         tripped = check_guard(system)          # (pins the tripping models to fp32)
         if collective:                         # the decision must be the same on every rank: they all recompute, or none
-            flag = torch.tensor([1.0 if tripped else 0.0], device=rays.device)
+            from .mirror_nerf import MirrorNeRF, precision_of
+            fields = [m for m in system.models.values() if isinstance(m, MirrorNeRF)]
+            flag = torch.tensor([1.0 if tripped else 0.0,      # + the ranks' states, as in skip mode: ranks pinned outside the step
+                                 float(any(precision_of(m).startswith("split") for m in fields)),
+                                 float(any(not precision_of(m).startswith("split") for m in fields))], device=rays.device)
             if D._TRACE:
-                D._trace("guard flag (sync mode)")
+                D._trace("guard flags (sync mode)")
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            if bool(flag.item()):
+            f = flag.tolist()
+            if f[0] != 0.0:
                 pin_fp32(system)               # every rank, every model: the ranks stay on the same kernels
                 tripped = True
+            elif f[1] != 0.0 and f[2] != 0.0:
+                pin_fp32(system)               # ranks in different states (one was pinned by a validation pass): converge; the
+                                               # gradients of this pass are valid on either arithmetic, nothing is recomputed
         if tripped:
             D.reset_overlap()                  # the first pass's bucket all-reduces (issued from inside backward) are discarded
             loss = fwd_bwd()                   # this step again, exactly
             D.issue_pending()
     else:
-        tok = guard_async_begin(system)        # forward + backward flags of THIS step, read at the next
-        found_host = None
-        if tok is not None and (mode == "skip" or collective):
+        tok = guard_async_begin(system)        # forward + backward flags of THIS step, read at the next (None: no split model here)
+        flags_host = flags_ev = found = None
+        if tok is not None and mode == "skip":
             found = (tok[3] != 0).any().to(torch.float32)          # 0-dim, like GradScaler's found_inf
-            if collective:
-                if D._TRACE:
-                    D._trace("guard flag (skip mode)")
-                if D.host_staged():
-                    torch.cuda.synchronize()       # (MNRF_SHARE_GPU test aid only; see dist.host_staged)
-                torch.distributed.all_reduce(found, op=torch.distributed.ReduceOp.MAX)
-                found_host = torch.empty((), dtype=torch.float32, pin_memory=True)
-                found_host.copy_(found, non_blocking=True)
-                tok[2].record()                # (the event the next step waits for now also covers this copy)
+        if collective:
+            # ALWAYS issued, whatever this rank's own state: precision pinning outside train_step is rank-local -- a
+            # validation pass that trips the guard on rank 0 pins rank 0 only -- and a rank that skipped this collective because it
+            # has no split model left would meet the others' flag with its next bucket.  Three MAX-reduced flags: [a rank tripped
+            # in this step | a rank runs split models | a rank runs pinned models]; a trip, or ranks in different states, pins
+            # every model on every rank at the next step's start (settle).
+            from .mirror_nerf import MirrorNeRF, precision_of
+            fields = [m for m in system.models.values() if isinstance(m, MirrorNeRF)]
+            has_split = any(precision_of(m).startswith("split") for m in fields)
+            has_pinned = any(not precision_of(m).startswith("split") for m in fields)
+            vec = _state_flags(rays.device, has_split, has_pinned).clone()
+            if tok is not None:
+                vec[0] = (tok[3] != 0).any()
+            if D._TRACE:
+                D._trace("guard flags (skip / async mode)")
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.MAX)
+            flags_host = torch.empty(3, dtype=torch.float32, pin_memory=rays.is_cuda)
+            flags_host.copy_(vec, non_blocking=True)
+            if rays.is_cuda:
+                flags_ev = torch.cuda.Event()
+                flags_ev.record()
             if mode == "skip":
-                optimizer.grad_scale, optimizer.found_inf = None, found       # fused Adam: no update where found_inf != 0
-        elif mode == "skip" and getattr(optimizer, "found_inf", None) is not None:
-            # no split model left (every model pinned to fp32 after a trip): the flag tensor of the tripping step must not keep
-            # vetoing updates -- it would skip every step from here on (found with two ranks, where a trip pins EVERY model)
-            optimizer.grad_scale, optimizer.found_inf = None, None
-        system.__dict__["_mnrf_guard_token"] = (tok, found_host, mode)
+                found = vec[0]
+        if mode == "skip":
+            # fused Adam: no update where found_inf != 0.  None once no split model is left anywhere: the flag tensor of a tripping
+            # step must not keep vetoing updates (found with two ranks, where a trip pins EVERY model)
+            optimizer.grad_scale, optimizer.found_inf = None, found
+        system.__dict__["_mnrf_guard_token"] = (tok, flags_host, mode, flags_ev)
     # RCCL over xGMI when world_size > 1: per-model flat buckets, the all-reduce of a model issued from inside the backward
     # pass as soon as its gradients are complete (dist.attach_overlap), only waited for here
     D.allreduce_gradients(params_of(system), modules=list(system.models.values()))

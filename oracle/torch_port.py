@@ -141,3 +141,37 @@ def render_eval(models, rays, n_samples, n_importance, chunk, max_level=1):
             if v.dim() <= 2 and (v.dim() == 1 or v.shape[1] <= 3):
                 outs.setdefault(k, []).append(v)
     return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+
+@torch.no_grad()
+def render_train_coarse(models, rays, gt_mask, n_samples, chunk):
+    """BASELINE config 1 on the host cores: train.NeRFSystem.forward (train.py:102-348) with coarse-only sampling
+    (N_importance = 0), a valid ground-truth mirror mask and only_trace_rays_in_mirrors -- render, reflect the masked rays off the
+    composited predicted normal (train.py:192-252), render those, blend (train.py:263-296).  Forward values only (no autograd:
+    the density-gradient normal of compute_normal=True is left out; it is not read when the predicted normal exists)."""
+    w = models["coarse"]
+
+    def render(rc):
+        rays_o, rays_d, near, far = rc[:, 0:3], rc[:, 3:6], rc[:, 6:7], rc[:, 7:8]
+        t = torch.linspace(0, 1, n_samples)
+        z = (near * (1 - t) + far * t).expand(rc.shape[0], n_samples)
+        res = {}
+        _inference(res, w, "coarse", rays_o, rays_d, z, embed(rays_d, 4), False, chunk)
+        return res
+
+    out = []
+    for i in range(0, rays.shape[0], chunk):
+        rc, mb = rays[i:i + chunk], gt_mask[i:i + chunk].bool()
+        r = render(rc)
+        rgb = r["rgb_coarse"]
+        if bool(mb.any()):
+            n = _l2n(r["surface_normal_coarse"])
+            wv = _l2n(-rc[:, 3:6])
+            rdir = 2 * (wv * n).sum(-1, keepdim=True) * n - wv
+            sec = torch.cat([r["x_surface_coarse"], rdir, torch.full_like(rc[:, 6:7], 0.1), rc[:, 7:8]], 1)
+            part = rgb.clone()
+            part[mb] = render(sec[mb])["rgb_coarse"]
+            mf = mb.float()[:, None]
+            rgb = mf * part + (1 - mf) * rgb
+        out.append(rgb)
+    return torch.cat(out, 0)

@@ -289,3 +289,203 @@ def test_hash_grid_model_gradient_allreduce():
         assert started and same_tensor
         assert (t3, t4) == (0.5, 1.0)       # row 3: rank 0 only (factor 1, / 2); row 4: rank 1 only (factor 2, / 2)
         assert w == 15.0 and bias == 15.0
+
+
+# ---- training.train_step's collective sequence with FOUR ranks, a guard trip on rank 2 and a rank pinned outside the step
+class _FakeEvent:
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+    def record(self):
+        pass
+
+
+def _train_step_worker(rank, ws, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MNRF_FORCE_COLLECTIVES"] = "0"
+    os.environ["MNRF_GUARD_MODE"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import mirror_nerf_amd as M
+        from mirror_nerf_amd import mirror_nerf as MN, training as T
+        from mirror_nerf_amd.weights import params_of
+        assert T.GUARD_MODE == mode
+        torch.manual_seed(0)
+
+        class System(torch.nn.Module):          # stands for NeRFSystem on the CPU: two field modules evaluated through _FakeFieldFn
+            def __init__(self):
+                super().__init__()
+                self.hparams = T.default_hparams()
+                self.nerf_coarse = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+                self.nerf_fine = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+                self.models = {"coarse": self.nerf_coarse, "fine": self.nerf_fine}
+
+            def forward(self, rays, extra):
+                return {"loss": sum(_FakeFieldFn.apply(m, float(1 + rank), *params_of(m)) for m in self.models.values()) + rays.sum() * 0.0}
+
+        system = System()
+        words = {"now": [0, 0]}                 # the guard words the fake device would hold after this step's launches
+
+        def begin(sysm):                        # mirror_nerf.guard_async_begin without a device
+            mods = [m for m in sysm.models.values() if MN.precision_of(m).startswith("split")]
+            if not MN.GUARD or not mods:
+                return None
+            w = torch.tensor([words["now"][i] for i, m in enumerate(sysm.models.values()) if m in mods], dtype=torch.int32)
+            return mods, w.clone(), _FakeEvent(), w
+
+        def check(sysm):                        # mirror_nerf.check_guard (sync mode)
+            tripped = False
+            for i, m in enumerate(sysm.models.values()):
+                if MN.precision_of(m).startswith("split") and words["now"][i]:
+                    m.__dict__["_mnrf_precision"] = "fp32"
+                    tripped = True
+            return tripped
+        MN.guard_async_begin, MN.check_guard = begin, check
+
+        class Opt:                              # takes found_inf like torch's fused Adam / FlatAdam
+            mnrf_found_inf = True
+            grad_scale = found_inf = None
+            log = []
+
+            def zero_grad(self, set_to_none=True):
+                for p_ in system.parameters():
+                    p_.grad = None
+
+            def step(self):
+                self.log.append(None if self.found_inf is None else float(self.found_inf))
+        opt = Opt()
+        D.attach_overlap(system.models.values())
+        seq = []
+        real = dist.all_reduce
+
+        def logged(t, *a, **k):                 # every all-reduce this rank issues: (elements, async?)
+            seq.append((int(t.numel()), bool(k.get("async_op", False))))
+            return real(t, *a, **k)
+        dist.all_reduce = torch.distributed.all_reduce = logged
+        rays, target, gt = torch.zeros(8, 8), torch.zeros(8, 3), torch.zeros(8)
+        loss_fn = lambda res, t, g: res["loss"]  # noqa: E731
+        states = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(5):
+                words["now"] = [0, 1] if (step == 1 and rank == 2) else [0, 0]      # rank 2's fine model leaves the range in step 1
+                T.train_step(system, opt, rays, target, gt, loss_fn)
+                states.append([MN.precision_of(m) for m in system.models.values()])
+        q.put((rank, seq, states, list(opt.log)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _pinned_rank_worker(rank, ws, port, q, mode):
+    """rank 0 enters training with its models already pinned (a validation pass tripped its guard)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MNRF_FORCE_COLLECTIVES"] = "0"
+    os.environ["MNRF_GUARD_MODE"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import mirror_nerf_amd as M
+        from mirror_nerf_amd import mirror_nerf as MN, training as T
+        from mirror_nerf_amd.weights import params_of
+        torch.manual_seed(0)
+
+        class System(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.hparams = T.default_hparams()
+                self.nerf_coarse = M.MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+                self.models = {"coarse": self.nerf_coarse}
+
+            def forward(self, rays, extra):
+                return {"loss": _FakeFieldFn.apply(self.nerf_coarse, float(1 + rank), *params_of(self.nerf_coarse)) + rays.sum() * 0.0}
+        system = System()
+
+        def begin(sysm):
+            mods = [m for m in sysm.models.values() if MN.precision_of(m).startswith("split")]
+            if not mods:
+                return None
+            w = torch.zeros(len(mods), dtype=torch.int32)
+            return mods, w.clone(), _FakeEvent(), w
+        MN.guard_async_begin, MN.check_guard = begin, (lambda sysm: False)
+
+        class Opt:
+            mnrf_found_inf = True
+            grad_scale = found_inf = None
+            log = []
+
+            def zero_grad(self, set_to_none=True):
+                for p_ in system.parameters():
+                    p_.grad = None
+
+            def step(self):
+                self.log.append(None if self.found_inf is None else float(self.found_inf))
+        opt = Opt()
+        D.attach_overlap(system.models.values())
+        if rank == 0:
+            MN.pin_fp32(system)                 # outside train_step, on this rank only
+        seq = []
+        real = dist.all_reduce
+
+        def logged(t, *a, **k):
+            seq.append((int(t.numel()), bool(k.get("async_op", False))))
+            return real(t, *a, **k)
+        dist.all_reduce = torch.distributed.all_reduce = logged
+        rays, target, gt = torch.zeros(8, 8), torch.zeros(8, 3), torch.zeros(8)
+        states = []
+        for _ in range(3):
+            T.train_step(system, opt, rays, target, gt, lambda res, t, g: res["loss"])
+            states.append(MN.precision_of(system.nerf_coarse))
+        q.put((rank, seq, states, list(opt.log)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, ws, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, ws, port, q) + args) for r in range(ws)]
+    for p in procs:
+        p.start()
+    out = dict((r[0], r[1:]) for r in (q.get(timeout=240) for _ in procs))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_train_step_collective_sequence_with_four_ranks_and_a_trip_on_rank_two():
+    """training.train_step with four ranks on gloo, kernels replaced by stand-ins (a fake field function whose
+    backward hands out views of one flat buffer, fake guard words).  Rank 2's fine model leaves the range in step 1.  Every rank
+    issues the IDENTICAL sequence of all-reduces in every step (two async buckets, then the three guard flags, blocking); the
+    tripping step's update is skipped on every rank (found_inf = 1 everywhere); from step 2 on every model of every rank is pinned."""
+    for mode in ("skip", "sync"):
+        out = _spawn(_train_step_worker, 4, mode)
+        seqs = [out[r][0] for r in range(4)]
+        assert all(s == seqs[0] for s in seqs), (mode, seqs)
+        n_flat = seqs[0][0][0]                                  # one flat bucket per model (662 152 floats), async, then the flags
+        assert n_flat > 600000 and seqs[0][:3] == [(n_flat, True), (n_flat, True), (3, False)], seqs[0][:6]
+        for r in range(4):
+            _seq, states, log = out[r]
+            assert states[0] == ["split", "split"]
+            assert states[2] == ["fp32", "fp32"] and states[4] == ["fp32", "fp32"], (mode, r, states)
+            if mode == "skip":
+                assert log[0] == 0.0 and log[1] == 1.0, (r, log)      # step 1's update vetoed on EVERY rank
+                assert log[3] in (None, 0.0) and log[4] in (None, 0.0), (r, log)
+
+
+def test_a_rank_pinned_outside_the_step_keeps_the_collectives_matched():
+    """rank 0 has no split model left when training starts.  It used to skip the guard-flag all-reduce
+    that the other ranks issue (the next collective on rank 0 was a bucket of another size: a hang under RCCL)."""
+    for mode in ("skip", "sync"):
+        out = _spawn(_pinned_rank_worker, 2, mode)
+        assert out[0][0] == out[1][0], (mode, out[0][0], out[1][0])
+        assert all(n == 3 and not a for (n, a) in out[0][0][1::2]), out[0][0]      # every step: one bucket, then the three flags
+        for r in (0, 1):
+            assert out[r][1][-1] == "fp32", (mode, r, out[r][1])                   # the ranks converged
+            assert all(v in (None, 0.0) for v in out[r][2]), out[r][2]              # no update was vetoed: nothing tripped

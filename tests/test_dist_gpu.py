@@ -24,7 +24,7 @@ WORKER = textwrap.dedent('''
     from mirror_nerf_amd import dist as D, synthetic as SY, training
 
     rank, ws, dev = D.init_from_env()
-    share = os.environ.get("MNRF_SHARE_GPU") == "1"
+    share = os.environ.get("MNRF_SHARE_GPU") == "1"      # (tests/shared_gpu/sitecustomize.py is loaded then)
     assert dist.is_initialized() and dist.get_backend() == ("gloo" if share else "nccl") and dist.get_world_size() == ws
     assert dev.index == (0 if share else int(os.environ["LOCAL_RANK"])) == torch.cuda.current_device()
 
@@ -148,12 +148,24 @@ def _free_port():
     return p
 
 
+SHIM = os.path.join(ROOT, "tests", "shared_gpu")      # sitecustomize.py: the MNRF_SHARE_GPU transport shim (test aid, not product code)
+
+
+def _share_env(env):
+    """MNRF_SHARE_GPU=1 only means something to processes that load tests/shared_gpu/sitecustomize.py."""
+    if env.get("MNRF_SHARE_GPU") == "1":
+        env["PYTHONPATH"] = SHIM + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        env["MNRF_ROOT"] = ROOT
+    return env
+
+
 def _run(world, worker=None, **extra):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, **extra, MNRF_ROOT=ROOT, MNRF_FORCE_COLLECTIVES="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = _share_env(env)
         procs.append(subprocess.Popen([sys.executable, "-c", worker or WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -193,18 +205,47 @@ def test_guard_trip_on_one_of_two_ranks(mode, opt):
     _run(2, worker=GUARD_WORKER, MNRF_SHARE_GPU="1", MNRF_GUARD_MODE=mode, MNRF_TEST_OPT=opt)
 
 
+PINNED_WORKER = GUARD_WORKER.split("before = [q.detach()")[0] + textwrap.dedent('''
+    # ADVICE r4 (medium): precision pinning OUTSIDE train_step is rank-local -- a validation pass on rank 0 that trips the guard
+    # pins rank 0 only.  Rank 0 then has no split model left; in skip mode it used to skip the guard-flag all-reduce the other
+    # ranks still issued (mismatched collectives).  Now every rank issues it whatever its state, and ranks in different states
+    # converge: every model pinned on every rank from the next step on, identical weights, no hang.
+    if rank == 0:
+        MN.pin_fp32(system)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):
+            training.train_step(system, opt, *batch(False))
+        torch.cuda.synchronize()
+    assert all(MN.precision_of(m) == "fp32" for m in system.models.values()), "ranks in different states must converge"
+    c = checksum()
+    assert all(abs(x - c[0]) <= 1e-9 * max(1.0, abs(c[0])) for x in c), c
+    assert all(bool(torch.isfinite(q).all()) for q in system.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+''')
+
+
+@pytest.mark.parametrize("mode", ["skip", "sync"])
+def test_one_rank_pinned_outside_the_training_step(mode):
+    _run(2, worker=PINNED_WORKER, MNRF_SHARE_GPU="1", MNRF_GUARD_MODE=mode, MNRF_TEST_OPT="flat")
+
+
 def test_bench_with_two_ranks_sharing_the_gpu():
     """`bench.py --gpus 2` end to end (launcher path, weak + strong scaling legs, training step with the all-reduce,
     the hash-grid leg across ranks) on one GPU shared by both ranks; the numbers are void, the line's shape is not."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MNRF_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = _share_env(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     import json
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines                      # rank 0 alone prints
-    line = json.loads(lines[0])
+    assert len(lines) == 2, lines                      # rank 0 alone prints: the headline line at once, the complete one at the end
+    first, line = json.loads(lines[0]), json.loads(lines[1])
+    assert first["line"] == "headline" and line["line"] == "complete" and first["value"] == line["value"] and "train_step" not in first
     assert line["n_gpus"] == 2 and line["config"]["rccl_world_size"] == 2 and line["config"]["collective_backend"].startswith("gloo")
     assert line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line       # rank 0 at N = 1 only
     ss = line["strong_scaling"]

@@ -338,6 +338,23 @@ def test_torch_port_matches_oracle():
             assert np.abs(got[k].numpy() - want[k]).max() <= 2e-6, k
 
 
+def test_torch_port_config1_matches_oracle():
+    """oracle/torch_port.render_train_coarse (what bench.py times as BASELINE config 1 on the host cores) against the pinned
+    numpy oracle's train-semantics recursion (render_train, fixtures G6 / G15): coarse only, GT mirror mask, compacted reflections."""
+    import torch
+    from mirror_nerf_amd import synthetic as SY
+    from oracle import torch_port as TP
+    rays = O.synthetic_rays(40, 40)[::11][:120].copy()
+    gt = (np.arange(rays.shape[0]) % 4 == 1).astype(np.float32)
+    sd = SY.apply_tweaks(SY.make_state_dict(0, 1)[0], SY.STRADDLE)
+    hp = dict(N_samples=64, N_importance=0, use_disp=False, perturb=0, noise_std=0, chunk=32768, trace_secondary_rays=True,
+              only_one_field=False, max_recursive_level=1, only_trace_rays_in_mirrors=True, for_vis=False)
+    want = O.render_train({"coarse": sd}, EMB, rays, hp, {"mirror_mask": gt.copy(), "is_eval": False, "train_geometry_stage": False})
+    got = TP.render_train_coarse({"coarse": {n: torch.from_numpy(v) for n, v in sd.items()}}, torch.from_numpy(rays),
+                                 torch.from_numpy(gt), 64, 32768)
+    assert np.abs(got.numpy() - want["rgb_coarse"]).max() <= 2e-6
+
+
 @pytest.mark.parametrize("name", [n for n in FX.names("g13_") if not n.endswith("_eval")])
 def test_render_rays_without_optional_heads(name):
     """G13: the oracle on models without the normal / mirror-mask heads (models/mirror_nerf.py:80-99)."""
