@@ -13,8 +13,9 @@
  * Conventions
  *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every
  *     buffer and the library never allocates device memory.  A packed weight image is
- *     read-write: its last 17 words are device state of the launches that use it (16
- *     counters of the field kernels' dynamic tile queue, zero between launches, and the
+ *     read-write: its last 19 words are device state of the launches that use it (a
+ *     {value, done} pair of the training backward's single-launch reductions, 16 counters
+ *     of the field kernels' dynamic tile queue -- all zero between launches -- and the
  *     range-guard word below); mnrf_pack_weights zeroes them;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return value 0 = ok, negative = error (see mnrf_last_error()); nothing throws;
@@ -437,7 +438,10 @@ int mnrf_dw_planes2_n(int n_eval, const void* const* x_planes, const void* const
  * [lr, beta1, beta2, eps, weight_decay] (doubles; lr, eps and weight_decay are rounded to float as the namesake's arguments
  * are), *step = the count of calls, this one included -- the caller advances it on the stream with mnrf_add_i64. */
 int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
-                       const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf, void* stream);
+                       const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf,
+                       const uint32_t* const* guard_words /* HOST array of n_guard_words (0..4) device words: a non-zero range-guard
+                                                             word (the last word of a packed image) vetoes the update like found_inf */,
+                       int n_guard_words, void* stream);
 int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream);      /* *counter += delta (device), one thread */
 
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------

@@ -25,10 +25,13 @@ int launch_dwp_n(int n_eval, const void* const* x_planes, const void* const* dy_
                  const int* spr, const unsigned* const* seedmax, const int* kinds, float* ws, float* const* d_params, int accumulate,
                  hipStream_t s);
 // largest |J^| of a second-order pass (float bits) -> *out, as field_split_bwd2_kernel's prologue forms it
+// pair: a {value, done} word pair that is zero between launches (mnrf_layout.h OFF_REDUCE_PAIR of the model's packed image): the
+// reduction is then ONE launch -- the last workgroup out stores the maximum to *out and resets the pair; null: *out is zeroed by
+// a launch of its own first
 void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
-                     const int* n_live = nullptr, int spr = 1);
+                     const int* n_live = nullptr, int spr = 1, unsigned* pair = nullptr);
 // largest seed magnitude of an evaluation (float bits) -> *out; the seeds are those of field_split_bwd_kernel's prologue
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
-                     const int* n_live = nullptr, int spr = 1);
+                     const int* n_live = nullptr, int spr = 1, unsigned* pair = nullptr);
 }  // namespace mnrf

@@ -354,28 +354,47 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
     }
 }
 
+// A 32-bit word of the device-made plan through the SCALAR cache.  The plan is read between the stores of the partial tiles, where
+// hipcc cannot prove it unclobbered and falls back to vector loads -- VMEM operations whose s_waitcnt vmcnt(0) sits in front of
+// every one of a workgroup's ~34 (job, evaluation) pairs: 35 us per launch in the first build of the DEV kernels (rocprofv3: 636 vs
+// 601 us).  The address is wave-uniform by construction (kernel argument + loop counters).
+__device__ __forceinline__ int plan_word(const void* base, int byte_off) {
+    int v;
+    const char* q = (const char*)base + byte_off;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q) : "memory");
+    return v;
+}
+
 // DEV: the plan was made on the device (DwpDevPlan, live row counts); the launch has one workgroup per CU
 template <bool HALF, bool DEV = false>
 __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) {
     const int g = blockIdx.x;
-    const DwpPlan& p = DEV ? A.dev->plan : A.plan;
-    if (DEV && (g >= p.G || p.T == 0)) return;
+    DwpPlan hd;      // n_eval, G, T: what the interval needs (the per-evaluation entries are read where they are used)
+    if (DEV) {
+        hd.n_eval = plan_word(&A.dev->plan.n_eval, 0);
+        hd.G = plan_word(&A.dev->plan.G, 0);
+        hd.T = (long long)(((unsigned long long)(unsigned)plan_word(&A.dev->plan.T, 4) << 32) | (unsigned)plan_word(&A.dev->plan.T, 0));
+        if (g >= hd.G || hd.T == 0) return;
+    } else {
+        hd.n_eval = A.plan.n_eval; hd.G = A.plan.G; hd.T = A.plan.T;
+    }
     long long P = 0, c0, c1;
-    dwp_interval(p, g, c0, c1);
+    dwp_interval(hd, g, c0, c1);
     for (int j = 0; j < DWP_JOBS; ++j) {
         const int w = dwp_weight(j);
-        for (int e = 0; e < p.n_eval; ++e) {
-            const int n = dwp_stages(p, j, e);
+        for (int e = 0; e < hd.n_eval; ++e) {
+            const int kind = DEV ? plan_word(&A.dev->plan.kind[0], 4 * e) : A.plan.kind[e];
+            const int n_sb = DEV ? plan_word(&A.dev->plan.n_sb[0], 4 * e) : A.plan.n_sb[e];
+            const int n = dwp_has(kind, j) ? n_sb : 0;      // dwp_stages()
             int s_lo, s_hi;
             dwp_segment(c0, c1, P, w, n, s_lo, s_hi);
             P += (long long)n * w;
             if (s_hi <= s_lo) continue;
-            const int kind = p.kind[e];
             const DwpJob jb = dwp_job_of(kind, j);
             const long long ysb = dwp_y_stride(kind), xsb = dwp_x_stride(kind);
             const char* Yb = A.ev[e].Y + (long long)jb.ya * PL_FB_BYTES;
             const char* Xb = A.ev[e].X + (long long)jb.xa * PL_FB_BYTES;
-            float* slot = A.part + (long long)(g + j * p.n_eval + e) * DWP_SLOT_FLOATS;
+            float* slot = A.part + (long long)(g + j * hd.n_eval + e) * DWP_SLOT_FLOATS;
             if constexpr (HALF) {
                 switch (jb.shape) {
                 case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
@@ -500,13 +519,35 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
     }
 }
 
+// Tail of a grid-wide maximum of non-negative floats (ordered like their bit patterns).  pair == null: atomicMax into *out (zeroed by
+// a launch in front).  Else `pair` = {value, done}, zero between launches: every wave folds its maximum into pair[0], the last
+// workgroup out stores the result to *out with a plain store and resets both words -- one launch, nothing to zero.
+__device__ __forceinline__ void grid_max_tail(float mx, unsigned* __restrict__ out, unsigned* __restrict__ pair) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (!pair) {
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+        return;
+    }
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(pair, __builtin_bit_cast(unsigned, mx));
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(pair + 1, 1u) == gridDim.x - 1) {
+            __threadfence();
+            *out = atomicExch(pair, 0u);
+            atomicExch(pair + 1, 0u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------- seed maximum
 // The seeds (pre-activation gradients of the four output layers) exactly as field_split_bwd_kernel's prologue forms them --
 // same expressions, same order, -ffp-contract=off in both translation units -- reduced to the largest magnitude.
 __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* __restrict__ g_rgb, const float* __restrict__ g_pn,
                                 const float* __restrict__ g_m, const float* __restrict__ rgb, const float* __restrict__ pn,
                                 const float* __restrict__ is_mirror, const float* __restrict__ save_inv, long long B,
-                                unsigned* __restrict__ out, const int* __restrict__ n_live, int spr) {
+                                unsigned* __restrict__ out, const int* __restrict__ n_live, int spr, unsigned* __restrict__ pair) {
     if (n_live) {      // live row count: B is the capacity
         long long bl = (long long)*n_live * spr;
         bl = bl < 0 ? 0 : bl;
@@ -541,24 +582,22 @@ __global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* 
         }
     }
     // non-negative floats order like their bit patterns; NaN (fmaxf drops it) never gets here, inf gives exponent 255 -> K = 0
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+    grid_max_tail(mx, out, pair);
 }
 
 void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn, const float* g_m, const float* rgb,
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
-                     const int* n_live, int spr) {
-    zero_fill(s, out, sizeof(unsigned));
+                     const int* n_live, int spr, unsigned* pair) {
+    if (!pair) zero_fill(s, out, sizeof(unsigned));
     long long blocks = (B + 1023) / 1024;       // four samples per thread
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
-                       save_inv, B, out, n_live, spr);
+                       save_inv, B, out, n_live, spr, pair);
 }
 
 // largest |J^| (the seed of the second-order pass) exactly as field_split_bwd2_kernel's prologue forms it
 __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float* __restrict__ normal, const float* __restrict__ save_invj,
-                                long long B, unsigned* __restrict__ out, const int* __restrict__ n_live, int spr) {
+                                long long B, unsigned* __restrict__ out, const int* __restrict__ n_live, int spr, unsigned* __restrict__ pair) {
     if (n_live) {      // live row count: B is the capacity
         long long bl = (long long)*n_live * spr;
         bl = bl < 0 ? 0 : bl;
@@ -578,17 +617,15 @@ __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float*
         }
         mx = fmaxf(mx, fmaxf(fabsf(j0), fmaxf(fabsf(j1), fabsf(j2))));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+    grid_max_tail(mx, out, pair);
 }
 
 void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
-                     const int* n_live, int spr) {
-    zero_fill(s, out, sizeof(unsigned));
+                     const int* n_live, int spr, unsigned* pair) {
+    if (!pair) zero_fill(s, out, sizeof(unsigned));
     long long blocks = (B + 1023) / 1024;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out, n_live, spr);
+    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out, n_live, spr, pair);
 }
 
 // ---------------------------------------------------------------------------------------------------------- driver
@@ -628,41 +665,44 @@ struct DwpPlanArgs {
     DwpDevPlan* out;
 };
 __global__ void dwp_plan_kernel(DwpPlanArgs A) {
+    constexpr int NV = DWP_JOBS * DWP_MAX_EVAL;
     __shared__ DwpPlan sp;
-    if (threadIdx.x == 0) {
-        sp.n_eval = A.n_eval;
-        for (int e = 0; e < DWP_MAX_EVAL; ++e) {
-            int n = 0;
-            if (e < A.n_eval) {
-                n = A.cap_sb[e];
-                if (A.n_live[e]) {
-                    long long b = (long long)*A.n_live[e] * A.spr[e];
-                    b = b < 0 ? 0 : b;
-                    const long long live = dwp_sample_blocks(b);
-                    n = live < n ? (int)live : n;
-                }
+    __shared__ long long start[NV + 1];      // cost at which virtual job v starts (job-major), then the total
+    const int v = threadIdx.x;
+    if (v < DWP_MAX_EVAL) {
+        int n = 0;
+        if (v < A.n_eval) {
+            n = A.cap_sb[v];
+            if (A.n_live[v]) {
+                long long b = (long long)*A.n_live[v] * A.spr[v];
+                b = b < 0 ? 0 : b;
+                const long long live = dwp_sample_blocks(b);
+                n = live < n ? (int)live : n;
             }
-            sp.n_sb[e] = n;
-            sp.kind[e] = e < A.n_eval ? A.kind[e] : 0;
         }
-        sp.T = dwp_total(sp);
+        sp.n_sb[v] = n;
+        sp.kind[v] = v < A.n_eval ? A.kind[v] : 0;
+    }
+    if (v == 0) sp.n_eval = A.n_eval;
+    __syncthreads();
+    const bool mine = v < DWP_JOBS * A.n_eval;
+    const int j = mine ? v / A.n_eval : 0, e = mine ? v % A.n_eval : 0;
+    const int n = mine ? dwp_stages(sp, j, e) : 0, w = dwp_weight(j);
+    if (v < NV) start[v + 1] = (long long)n * w;
+    __syncthreads();
+    if (v == 0) {
+        start[0] = 0;
+        for (int k = 1; k <= NV; ++k) start[k] += start[k - 1];
+        sp.T = start[NV];
         sp.G = dwp_pick_G(sp.T, A.cus);
         A.out->plan = sp;
     }
     __syncthreads();
-    const int v = threadIdx.x;
-    if (v >= DWP_JOBS * DWP_MAX_EVAL) return;
+    if (v >= NV) return;
     int lo = 1, hi = 0;
-    if (v < DWP_JOBS * A.n_eval && sp.T > 0) {
-        const int j = v / A.n_eval, e = v % A.n_eval;
-        long long P = 0;      // cost at which virtual job v starts: everything before it on the line (job-major)
-        for (int jj = 0; jj <= j; ++jj)
-            for (int ee = 0; ee < (jj < j ? A.n_eval : e); ++ee) P += (long long)dwp_stages(sp, jj, ee) * dwp_weight(jj);
-        const int n = dwp_stages(sp, j, e);
-        if (n > 0) {
-            lo = dwp_owner(sp, P);
-            hi = dwp_owner(sp, P + (long long)(n - 1) * dwp_weight(j));
-        }
+    if (mine && n > 0 && sp.T > 0) {
+        lo = dwp_owner(sp, start[v]);
+        hi = dwp_owner(sp, start[v] + (long long)(n - 1) * w);
     }
     A.out->g_lo[v] = (short)lo;
     A.out->g_hi[v] = (short)hi;

@@ -51,6 +51,7 @@ struct PackArgs {
 
 __global__ void pack_kernel(PackArgs P, PartTable T) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < DEVICE_STATE_WORDS) P.packed[OFF_REDUCE_PAIR + p] = 0.f;      // device state of the launches that use the image (mnrf_layout.h)
     if (p >= PACKED_F32_FLOATS) return;
     float v = 0.f;
     if (p < OFF_BIAS) {
@@ -141,7 +142,8 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     build_parts(T);
     const int threads = 256;
     const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
-    mnrf::zero_fill((hipStream_t)stream, packed + OFF_TILE_QUEUE, (1 + 2 * TQ_PAIRS) * sizeof(float));   // tile-queue pairs + range-guard word (mnrf.h)
+    // (the device-state words at the image's end -- reduction pair, tile-queue pairs, range-guard word -- are zeroed by pack_kernel
+    // itself: split_pack_kernel, which may raise MNRF_GUARD_WEIGHT, runs behind it on the stream)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
     launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
     if (split32_enabled()) launch_split32_pack(params, packed, (hipStream_t)stream);   // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)
@@ -309,7 +311,8 @@ static int field_backward_planes_impl(const float* packed, int64_t B, const floa
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: need xyz or rays+z_vals");
     hipStream_t s = (hipStream_t)stream;
     if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: bad spr");
-    launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s, n_live, spr);
+    launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s, n_live, spr,
+                    (unsigned*)(const_cast<float*>(packed) + OFF_REDUCE_PAIR));
     FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
                    g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
                    flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
@@ -416,7 +419,7 @@ static int field_backward2_planes_impl(const float* packed, int64_t B, const flo
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: need xyz or rays+z_vals");
     hipStream_t s = (hipStream_t)stream;
     if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: bad spr");
-    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s, n_live, spr);
+    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s, n_live, spr, (unsigned*)(const_cast<float*>(packed) + OFF_REDUCE_PAIR));
     FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
                     (const unsigned long long*)save_mask, nullptr, d_xyz, (char*)x2_planes, (char*)y2_planes, jmax};
     A.n_live = n_live;

@@ -155,6 +155,11 @@ constexpr int64_t PACKED_FLOATS = OFF_SPLIT32_FWD + (int64_t)SPLIT32_FWD_PAIRS *
 // pairs of the dynamic tile queue (mnrf_field_split3.hip).  mnrf_pack_weights zeroes all of them.
 constexpr int TQ_PAIRS = 8;
 constexpr int64_t OFF_TILE_QUEUE = PACKED_FLOATS - 1 - 2 * TQ_PAIRS;
+// ... and before those one {value, done} pair for single-launch grid reductions over an evaluation of this model (round 5: the
+// seed / tangent maxima of the training backward, mnrf_dwp.hip): zero between launches like the tile-queue pairs -- the last
+// workgroup out hands the value over and resets both words -- so a reduction needs no zero-fill launch in front of it
+constexpr int64_t OFF_REDUCE_PAIR = OFF_TILE_QUEUE - 2;
+constexpr int DEVICE_STATE_WORDS = 2 + 2 * TQ_PAIRS + 1;      // what mnrf_pack_weights zeroes, from OFF_REDUCE_PAIR on
 
 // ---- activations saved by the training forward, [section][sample][width], B-form column order
 constexpr int SEC_ENC = 0;            // 64   xyz encoding in (sin,cos)-pair order (enc_col)

@@ -28,29 +28,45 @@ struct AdamArgs {
     // device-resident hyper-parameters and step count (mnrf_adam_step_dev: a step captured in a hipGraph must not freeze them)
     const double* hyper;       // [lr, beta1, beta2, eps, weight_decay] or null
     const long long* step_dev; // the count of step() calls, this one included, or null
+    // range-guard words (mnrf.h MNRF_GUARD_*) that veto the update like found_inf does: a non-zero word = a launch of this step
+    // left the range of the split arithmetic (no torch ops needed to turn the words into a found_inf tensor inside a captured step)
+    const unsigned* guard[4];
+    int n_guard;
 };
 
 __global__ void adam_kernel(AdamArgs A) {
-    if (A.hyper) {
-        A.lr = (float)A.hyper[0]; A.beta1 = A.hyper[1]; A.beta2 = A.hyper[2]; A.eps = (float)A.hyper[3]; A.wd = (float)A.hyper[4];
-        A.step = *A.step_dev;
+    // thread 0 reads every scalar of the step (device-resident ones included) once per block and leaves what the others need in LDS
+    __shared__ float sh[6];      // veto, step_size, sqrt(bias correction 2), beta1, beta2, inv_scale
+    __shared__ float sh_eps_wd[2];
+    if (threadIdx.x == 0) {
+        if (A.hyper) {
+            A.lr = (float)A.hyper[0]; A.beta1 = A.hyper[1]; A.beta2 = A.hyper[2]; A.eps = (float)A.hyper[3]; A.wd = (float)A.hyper[4];
+            A.step = *A.step_dev;
+        }
+        bool veto = A.found_inf && *A.found_inf != 0.f;
+        for (int i = 0; i < A.n_guard; ++i) veto |= *A.guard[i] != 0u;
+        const long long eff = A.step - (long long)*A.skipped;      // >= 1 when the caller counts as documented
+        const double t = (double)(eff < 1 ? 1 : eff);
+        sh[0] = veto ? 1.f : 0.f;
+        sh[1] = A.lr / (float)(1.0 - pow(A.beta1, t));
+        sh[2] = (float)sqrt(1.0 - pow(A.beta2, t));
+        sh[3] = (float)A.beta1;
+        sh[4] = (float)A.beta2;
+        sh[5] = A.grad_scale ? 1.f / *A.grad_scale : 1.f;
+        sh_eps_wd[0] = A.eps;
+        sh_eps_wd[1] = A.wd;
     }
-    if (A.found_inf && *A.found_inf != 0.f) {      // the whole grid leaves; one thread records that this call did not count
+    __syncthreads();
+    if (sh[0] != 0.f) {      // the whole grid leaves; one thread records that this call did not count
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.skipped, 1);
         return;
     }
-    __shared__ float bc[2];
-    if (threadIdx.x == 0) {
-        const long long eff = A.step - (long long)*A.skipped;      // >= 1 when the caller counts as documented
-        const double t = (double)(eff < 1 ? 1 : eff);
-        bc[0] = (float)(1.0 - pow(A.beta1, t));
-        bc[1] = (float)sqrt(1.0 - pow(A.beta2, t));
-    }
-    __syncthreads();
-    const float step_size = A.lr / bc[0];
-    const float bc2_sqrt = bc[1];
-    const float b1 = (float)A.beta1, b2 = (float)A.beta2;
-    const float inv_scale = A.grad_scale ? 1.f / *A.grad_scale : 1.f;
+    const float step_size = sh[1];
+    const float bc2_sqrt = sh[2];
+    const float b1 = sh[3], b2 = sh[4];
+    const float inv_scale = sh[5];
+    A.eps = sh_eps_wd[0];
+    A.wd = sh_eps_wd[1];
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= A.n) return;
     const bool full = i4 + 4 <= A.n;
@@ -98,7 +114,7 @@ extern "C" int mnrf_adam_step(float* param, const float* grad, float* exp_avg, f
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step: tensors must be 16-byte aligned");
     AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, eps, weight_decay, beta1, beta2, (long long)step, skipped, grad_scale, found_inf,
-               nullptr, nullptr};
+               nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}, 0};
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step");
@@ -115,15 +131,22 @@ extern "C" int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream) {
 }
 
 extern "C" int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
-                                  const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf, void* stream) {
+                                  const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf,
+                                  const uint32_t* const* guard_words, int n_guard_words, void* stream) {
     using namespace mnrf;
+    if (n_guard_words < 0 || n_guard_words > 4 || (n_guard_words > 0 && !guard_words))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: 0..4 guard words");
     if (!param || !grad || !exp_avg || !exp_avg_sq || !skipped || !hyper || !step) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null pointer");
     if (n < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: n >= 0");
     if (n == 0) return MNRF_OK;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: tensors must be 16-byte aligned");
     AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, 0.f, 0.f, 0.f, 0.0, 0.0, 1, skipped, grad_scale, found_inf, hyper,
-               (const long long*)step};
+               (const long long*)step, {nullptr, nullptr, nullptr, nullptr}, n_guard_words};
+    for (int i = 0; i < n_guard_words; ++i) {
+        if (!guard_words[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null guard word");
+        A.guard[i] = guard_words[i];
+    }
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step_dev");

@@ -140,10 +140,27 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     # rendering.py:283-300 -- coarse depths
     z_steps = kwargs.get("_z_steps")
     z_steps = _linspace01(N_samples, dev) if z_steps is None else z_steps.float().contiguous()
+    # Training defaults (perturb = noise_std = 1, nothing injected, a coarse and a fine pass): ONE uniform and ONE normal draw per
+    # call -- [stratified offsets | inverse-CDF positions] and [coarse | fine density noise] -- instead of five generator launches
+    # (rendering.py:189, 296-300; 27 draws its u inside sample_pdf).  The draws are i.i.d. either way.
+    S_fine = N_samples + N_importance
+    two_pass = train and N and N_importance > 0 and not kwargs.get("only_one_field", False) and kwargs.get("_z_fine") is None
+    pool_u = pool_n = None
+    if two_pass and perturb > 0 and kwargs.get("_perturb_rand") is None and kwargs.get("_u") is None:
+        pool_u = torch.rand(N * (N_samples + N_importance), device=dev)
+    auto_noise = {}
+    if two_pass and noise_std != 0 and kwargs.get("_noise_coarse") is None and kwargs.get("_noise_fine") is None:
+        pool_n = torch.randn(N * (N_samples + S_fine), device=dev)
+        if noise_std != 1:
+            pool_n = pool_n * noise_std
+        auto_noise = {"_noise_coarse": pool_n[:N * N_samples].view(N, N_samples), "_noise_fine": pool_n[N * N_samples:].view(N, S_fine)}
     prand = None
     if perturb > 0:
         prand = kwargs.get("_perturb_rand")
-        prand = torch.rand(N, N_samples, device=dev) if prand is None else prand.float().contiguous()
+        if prand is None:
+            prand = pool_u[:N * N_samples].view(N, N_samples) if pool_u is not None else torch.rand(N, N_samples, device=dev)
+        else:
+            prand = prand.float().contiguous()
     z_vals = f(N, N_samples)
     if N:
         _lib.check(L.mnrf_sample_coarse_n(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
@@ -274,6 +291,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         noise = kwargs.get(noise_key)
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()
+        elif noise_key in auto_noise and auto_noise[noise_key].shape == (N, S):
+            noise = auto_noise[noise_key]                                 # (already scaled by noise_std)
         elif noise_std != 0:
             noise = torch.randn(N, S, device=dev)
             if noise_std != 1:
@@ -311,6 +330,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             u = kwargs.get("_u")
             if u is None and perturb == 0:
                 u = kwargs.get("_u_det")
+            if u is None and pool_u is not None:
+                u = pool_u[N * N_samples:].view(N, N_importance)
             # weights are detached here, as in the reference (rendering.py:335, 353)
             return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=u, n_live=n_live)
 

@@ -348,6 +348,8 @@ class FlatAdam:
         L, p = _lib.lib(), _lib.ptr
         f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1)  # noqa: E731
         gs, fi = f32(self._gs), f32(self._fi)
+        import ctypes
+        gw = (ctypes.c_void_p * max(1, len(guard_words)))(*[w.data_ptr() for w in guard_words]) if guard_words else None
         _lib.check(L.mnrf_add_i64(self._step_dev.data_ptr(), 1, _lib.stream()), "mnrf_add_i64")
         for i, (m, fp) in enumerate(zip(self.modules, self.flats)):
             flat = D._flat_bucket(m)
@@ -356,7 +358,7 @@ class FlatAdam:
             fp.grad = flat
             _lib.check(L.mnrf_adam_step_dev(p(fp.data), p(flat.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(),
                                             self._hyper.data_ptr(), self._step_dev.data_ptr(), p(self._skipped[i]), p(gs), p(fi),
-                                            _lib.stream()), "mnrf_adam_step_dev")
+                                            gw, len(guard_words), _lib.stream()), "mnrf_adam_step_dev")
         self._gs = self._fi = None
 
     def state_dict(self):
@@ -420,9 +422,10 @@ class GraphedTrainStep:
         loss = fn(res, self.target, self.gt, self.rays) if getattr(fn, "needs_rays", False) else fn(res, self.target, self.gt)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        self._words = torch.cat([m.__dict__["_mnrf_packed"].packed[-1:] for m in models]).view(torch.int32)
-        self.opt.found_inf = (self._words != 0).any().to(torch.float32)       # a saturated step must not reach the weights
-        self.opt.step_dev()
+        # a saturated step must not reach the weights: the guard words of the models' packed images veto the update inside the
+        # Adam kernel (no torch ops to form a found_inf tensor)
+        self._word_views = [m.__dict__["_mnrf_packed"].packed[-1:].view(torch.int32) for m in models]
+        self.opt.step_dev(self._word_views)
         return loss.detach()
 
     def capture(self):
@@ -458,7 +461,8 @@ class GraphedTrainStep:
         self.opt._calls += 1
         from .weights import bump_generation
         bump_generation()                 # host-side caches of the packed images are stale (the replay updated the weights)
-        self._host.copy_(self._words, non_blocking=True)      # this step's guard words, read at the next call
+        for i, w in enumerate(self._word_views):               # this step's guard words, read at the next call
+            self._host[i:i + 1].copy_(w, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._pending = ev
