@@ -87,7 +87,7 @@ extern "C" {
 #define MNRF_GUARD_IN_BACKWARD 256u      /* ... a scaled activation gradient of the training backward (mnrf_field_backward_planes: the
                                             caller may lower the gradient scale instead of leaving the split arithmetic, see its flags) */
 #define MNRF_GUARD_IN_SECOND_ORDER 512u  /* ... a scaled tangent or signal of the second-order pass (mnrf_field_backward2*) */
-#define MNRF_GUARD_ENC_RANGE 4u    /* a position with |x| >= 16: sin/cos arguments beyond 2^13, outside the fast exact reduction */
+#define MNRF_GUARD_ENC_RANGE 4u    /* a position with |x| >= 64: sin/cos arguments beyond 2^15, outside the fast exact reduction */
 /* The fp32 kernels never touch it.  Host policy (mirror_nerf_amd.mirror_nerf.check_guard): read it once per frame /
  * training step; non-zero -> the module is switched to the exact fp32 kernels and the work is repeated. */
 

@@ -56,7 +56,7 @@ def set_precision(mode):
 # ---- range guard of the split arithmetic (include/mnrf.h MNRF_GUARD_*, csrc/mnrf_field_split.inc "range guard")
 # The split kernels raise a sticky flag in the last word of the module's packed weight image when an operand of a Linear
 # reaches the f16 maximum (65504: the hi/lo pair stops carrying fp32 there), a weight is out of range, or a position has
-# |x| >= 16 (sin/cos arguments beyond the fast exact reduction).  The flag costs the kernels one VALU per converted pair;
+# |x| >= 64 (sin/cos arguments beyond the fast exact reduction).  The flag costs the kernels one VALU per converted pair;
 # the HOST reads it at the natural sync points -- the end of a frame (batched_inference), of a training forward
 # (NeRFSystem.forward), of a training step (training.train_step), of a stand-alone render_rays / MirrorNeRF.forward call
 # -- and when it is set the module is switched to the exact fp32 kernels for good and the work is repeated, so a result
@@ -66,7 +66,7 @@ def set_precision(mode):
 # MNRF_GUARD=0 disables the host side.
 GUARD = os.environ.get("MNRF_GUARD", "1") != "0"
 GUARD_NAMES = {1: "an activation reached the f16 maximum (65504)", 2: "a weight is non-finite or >= 65504",
-               4: "a sample position has |x| >= 16 (encoding argument >= 2^13)",
+               4: "a sample position has |x| >= 64 (encoding argument >= 2^15)",
                128: "in a forward evaluation", 256: "in the training backward: a scaled activation gradient",
                512: "in the second-order pass: a scaled tangent or signal"}
 
@@ -79,6 +79,8 @@ def precision_of(module):
 def reset_guard(module):
     """Undo the guard's switch to fp32 (e.g. after loading other weights into the same module)."""
     module.__dict__.pop("_mnrf_precision", None)
+    module.__dict__.pop("_mnrf_transient", None)
+    module.__dict__.pop("_mnrf_range_trips", None)
 
 
 def guard_words(modules):
@@ -110,11 +112,41 @@ def check_guard(modules):
         if w:
             import warnings
             why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
-            warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range ({why}); this model is evaluated with "
-                          "the exact fp32 kernels from now on and the affected work is repeated", RuntimeWarning, stacklevel=2)
+            m.__dict__["_mnrf_guard_trips"] = m.__dict__.get("_mnrf_guard_trips", 0) + 1
+            if _range_only(w) and m.__dict__.get("_mnrf_range_trips", 0) < RANGE_TRIPS_BEFORE_PIN:
+                # positions beyond the fast sin/cos range and nothing else (round 5): a property of THIS call's rays, not of the
+                # model -- the work is repeated on the exact kernels and the model returns to the split arithmetic afterwards
+                # (release_transient, called by the drivers behind the repeated work); a model that keeps meeting such rays is
+                # pinned after RANGE_TRIPS_BEFORE_PIN calls
+                m.__dict__["_mnrf_range_trips"] = m.__dict__.get("_mnrf_range_trips", 0) + 1
+                m.__dict__["_mnrf_transient"] = True
+                m.__dict__["_mnrf_packed"].packed[-1:].zero_()      # the sticky word: the next split launch starts clean
+                warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range ({why}); this call is repeated with the "
+                              "exact fp32 kernels", RuntimeWarning, stacklevel=2)
+            else:
+                warnings.warn(f"mirror_nerf_amd: the split-f16 arithmetic left its range ({why}); this model is evaluated with "
+                              "the exact fp32 kernels from now on and the affected work is repeated", RuntimeWarning, stacklevel=2)
             m.__dict__["_mnrf_precision"] = "fp32"
             tripped = True
     return tripped
+
+
+RANGE_TRIPS_BEFORE_PIN = 3
+
+
+def _range_only(w):
+    """A guard word that says nothing but "a position was beyond the fast sin/cos range" (MNRF_GUARD_ENC_RANGE)."""
+    return bool(w & 4) and not (w & (1 | 2))
+
+
+def release_transient(modules):
+    """Behind the repeated work of a range-only trip: the modules check_guard moved to fp32 for that call only return to the split
+    arithmetic."""
+    if hasattr(modules, "models"):
+        modules = list(modules.models.values())
+    for m in modules:
+        if m.__dict__.pop("_mnrf_transient", None):
+            m.__dict__.pop("_mnrf_precision", None)
 
 
 def guard_async_begin(modules):
@@ -144,6 +176,7 @@ def pin_fp32(modules):
     for m in modules:
         if isinstance(m, MirrorNeRF):
             m.__dict__["_mnrf_precision"] = "fp32"
+            m.__dict__.pop("_mnrf_transient", None)      # (for good: release_transient leaves it alone)
 
 
 GRAD_SCALE_STEP, GRAD_SCALE_MAX = 4, 8       # bits per adaptation / in total (mnrf_field_backward_planes takes r <= 15)
@@ -177,7 +210,16 @@ def guard_async_end(token, adapt=False):
     tripped = False
     for m, w in zip(modules, host.tolist()):
         if w and precision_of(m).startswith("split"):
+            m.__dict__["_mnrf_guard_trips"] = m.__dict__.get("_mnrf_guard_trips", 0) + 1
             if adapt and _lower_gradient_scale(m, w):
+                continue
+            if adapt and _range_only(w) and m.__dict__.get("_mnrf_range_trips", 0) < RANGE_TRIPS_BEFORE_PIN:
+                # one rank, skip mode: the step's update was vetoed on the device; a batch whose rays leave the fast sin/cos range
+                # costs that batch, not the model's arithmetic (a scene that keeps doing it is pinned after a few)
+                m.__dict__["_mnrf_range_trips"] = m.__dict__.get("_mnrf_range_trips", 0) + 1
+                import warnings
+                warnings.warn("mirror_nerf_amd: a training batch held positions beyond the fast sin/cos range (|x| >= 64); its update "
+                              "was skipped, the model stays on the split arithmetic", RuntimeWarning, stacklevel=3)
                 continue
             import warnings
             why = "; ".join(v for k, v in GUARD_NAMES.items() if w & k)
@@ -327,8 +369,11 @@ class MirrorNeRF(nn.Module):
         o = field_forward(self, B, xyz=x, xyz_stride=ld, spr=1,
                           dir_emb=None if sigma_only else x.view(-1)[3:], dir_stride=ld,
                           sigma_only=sigma_only, grad_normal=compute_normal, want_geo=True) if B else None
-        if B and check_guard([self]):      # range guard: the module is on the fp32 kernels now, evaluate again
-            return self.forward(x, compute_normal, sigma_only, embedding_xyz, embedding_dir)
+        if B and check_guard([self]):      # range guard: the module is on the fp32 kernels now (a range-only trip: for this call), evaluate again
+            try:
+                return self.forward(x, compute_normal, sigma_only, embedding_xyz, embedding_dir)
+            finally:
+                release_transient([self])
         out = {}
         dev = x.device
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731

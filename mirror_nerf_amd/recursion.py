@@ -310,10 +310,13 @@ class NeRFSystem(nn.Module):
 
     def forward(self, rays, extra=dict()):
         out = self._forward(rays, extra)
-        from .mirror_nerf import check_guard
+        from .mirror_nerf import check_guard, release_transient
         # (training.train_step passes _guard=False: it reads the sticky flag once, after the backward, for both passes)
         if rays.shape[0] and extra.get("_guard", True) and check_guard(self):   # out of range: the models are on fp32 now
-            out = self._forward(rays, extra)
+            try:
+                out = self._forward(rays, extra)
+            finally:
+                release_transient(self)       # (a range-only trip: for this call only)
         return out
 
     def _forward(self, rays, extra):
@@ -544,8 +547,11 @@ def batched_inference(models, embeddings, rays, N_samples, N_importance, use_dis
     elif to_cpu == "maps" and rays.is_cuda:
         torch.cuda.current_stream().synchronize()
     # range guard of the split arithmetic, once per call (= per frame): a tripped model is on the fp32 kernels now
-    from .mirror_nerf import check_guard
+    from .mirror_nerf import check_guard, release_transient
     if rays.shape[0] and not kwargs.get("_guard_retry") and check_guard([m for m in models.values()]):
-        return batched_inference(models, embeddings, rays, N_samples, N_importance, use_disp, chunk,
-                                 **dict(kwargs, _guard_retry=True))
+        try:
+            return batched_inference(models, embeddings, rays, N_samples, N_importance, use_disp, chunk,
+                                     **dict(kwargs, _guard_retry=True))
+        finally:
+            release_transient(list(models.values()))      # (a range-only trip: this frame on fp32, the next one on split again)
     return {k: torch.cat(v, 0) for k, v in results.items()}

@@ -348,8 +348,11 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     # range guard of the split arithmetic (mirror_nerf.check_guard): a stand-alone call checks its own launches (one
     # 8-byte device->host read); the recursion drivers pass _guard=False and check once per frame / training forward
     if kwargs.get("_guard", True) and N and not hashgrid:
-        from .mirror_nerf import check_guard
+        from .mirror_nerf import check_guard, release_transient
         if check_guard(list(models.values())):
-            return render_rays(models, embeddings, rays, N_samples, use_disp, perturb, noise_std, N_importance, chunk,
-                               white_back, test_time, **kwargs)
+            try:
+                return render_rays(models, embeddings, rays, N_samples, use_disp, perturb, noise_std, N_importance, chunk,
+                                   white_back, test_time, **kwargs)
+            finally:
+                release_transient(list(models.values()))      # (a range-only trip: the models return to the split arithmetic)
     return results

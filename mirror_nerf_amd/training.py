@@ -201,6 +201,8 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
             D.reset_overlap()                  # the first pass's bucket all-reduces (issued from inside backward) are discarded
             loss = fwd_bwd()                   # this step again, exactly
             D.issue_pending()
+            from .mirror_nerf import release_transient
+            release_transient(system)          # (one rank, a range-only trip: the batch's rays, not the model -- back to split)
     else:
         tok = guard_async_begin(system)        # forward + backward flags of THIS step, read at the next (None: no split model here)
         flags_host = flags_ev = found = None

@@ -121,14 +121,49 @@ def test_positions_beyond_the_fast_sincos_range_fall_back():
     from mirror_nerf_amd import synthetic as SY
     models = _models(SY.OPAQUE)
     rays = _rays(64).clone()
-    rays[:, 0] += 30.0                   # origins at x ~ 30: 2^9 * x > 2^13
-    with pytest.warns(RuntimeWarning, match=r"\|x\| >= 16"):
+    rays[:, 0] += 100.0                  # origins at x ~ 100: 2^9 * x > 2^15
+    with pytest.warns(RuntimeWarning, match=r"\|x\| >= 64"):
         got = M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
-    assert _words(models)[0] & 4
+    assert models["coarse"].__dict__["_mnrf_guard_trips"] == 1
     want = _fp32_render(SY.OPAQUE, rays)
     for k in ("rgb_fine", "depth_fine", "opacity_fine"):
         assert torch.equal(got[k], want[k]), k
-    assert MN.precision_of(models["fine"]) == "fp32"
+    # round 5: a range-only trip is a property of the CALL's rays -- the repeated work ran on fp32, the models are back on split
+    assert MN.precision_of(models["fine"]) == "split" and MN.precision_of(models["coarse"]) == "split"
+    assert _words(models) == [0, 0]
+    near = _rays(64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")           # ... and the next call, with rays in range, runs clean on the split arithmetic
+        M.render_rays(models, _emb(), near, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    # a model that keeps meeting such rays is pinned after RANGE_TRIPS_BEFORE_PIN calls
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(MN.RANGE_TRIPS_BEFORE_PIN):
+            M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    assert MN.precision_of(models["coarse"]) == "fp32"
+
+
+def test_far_plane_at_twenty_stays_on_the_split_arithmetic():
+    """A scale_factor-style scene (real_arkit captures, BASELINE config 4: run.sh:14-15, 47-48 set near / far per scene) whose far
+    plane reaches 20: positions up to |x| ~ 24.  Round 4 tripped the encoding-range bit at |x| >= 16 and pinned the model to fp32
+    (3.8x slower) for good; the four-term sin/cos reduction is exact to |x| < 64: no trip, and the split render still matches the
+    exact fp32 one at the parity tolerance."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import synthetic as SY
+    models = _models(SY.OPAQUE)
+    rays = _rays(256).clone()
+    rays[:, 7] = 20.0
+    rays[:, 0:3] *= 1.2
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = M.render_rays(models, _emb(), rays, 64, False, 0, 0, 64, test_time=True, compute_normal=False)
+    assert _words(models) == [0, 0] and MN.precision_of(models["fine"]) == "split"
+    want = _fp32_render(SY.OPAQUE, rays)
+    assert float((got["z_vals_fine"].max())) > 19.0
+    for k in ("rgb_fine", "opacity_fine"):
+        assert float((got[k] - want[k]).abs().max()) <= 1e-4, k
+    assert float((got["depth_fine"] - want["depth_fine"]).abs().max()) <= 1e-4 * 20.0
 
 
 def test_non_finite_weight_is_flagged_at_pack_time():
