@@ -67,6 +67,10 @@ extern "C" {
 #define MNRF_TCNN_F16 256u      /* mnrf_tcnn_forward: single-pass f16 MLPs -- operands rounded to f16, ONE MFMA per product, fp32 accumulation:
                                   "fp16 MLP on CDNA4 MFMA" as BASELINE config 5 words it and as the reference computes under
                                   tinycudann / precision=16 (train.py:586); ~1e-3 relative; sigma-only launches then take the matrix pipe too */
+#define MNRF_TCNN_TABLE_F16 1024u /* mnrf_tcnn_forward / _backward / _encode_flags: `table` points to HALF2 entries (4 B per entry: tinycudann's
+                                  storage, models/gridencoder/grid.py:57-58, mirror_nerf_tcnn.py:39-49; SURVEY 8d prices config 5 at 16 x 8 x 4 =
+                                  512 B of gathers per sample) made from the fp32 master table by mnrf_tcnn_table_half; gradients still go
+                                  to the fp32 d_table (the master the optimizer steps, as tinycudann keeps fp32 master parameters) */
 #define MNRF_TCNN_VALU 8u       /* mnrf_tcnn_forward: evaluate the small MLPs with fp32 FMAs on the VALU, one thread per sample
                                   (the first implementation; default: hi/lo f16 tiles on the matrix pipe, ~1e-6 of it) */
 
@@ -264,6 +268,12 @@ int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64
 int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double log2_per_level_scale, int base_resolution,
                      float bound, int64_t B, const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals,
                      int spr, float* planes, void* stream);
+
+/* ... with flags (0 or MNRF_TCNN_TABLE_F16), and the half2 copy of a table those launches read (entries = offsets[16]). */
+int mnrf_tcnn_encode_flags(const float* table, const int64_t* offsets17_host, double log2_per_level_scale, int base_resolution,
+                           float bound, int64_t B, const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals,
+                           int spr, float* planes, unsigned flags, void* stream);
+int mnrf_tcnn_table_half(const float* table, int64_t entries, void* table_half, void* stream);
 
 /* Measurement aid for the weight-gradient GEMM (mnrf_dw_planes): the rate at which one persistent 8-wave workgroup per CU reads
  * `bytes` of `buf` with the instruction that GEMM streams its operand planes with (global_load_lds_dwordx4, 1 KiB per

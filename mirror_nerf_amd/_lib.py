@@ -29,6 +29,7 @@ MNRF_SPLIT_F16 = 4
 MNRF_TCNN_VALU = 8
 MNRF_TCNN_F16 = 256
 MNRF_TCNN_GRAD_FIXED = 512
+MNRF_TCNN_TABLE_F16 = 1024
 MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128
@@ -87,6 +88,9 @@ SIGNATURES = {
     "mnrf_bench_gather": (_int, [ctypes.c_void_p, _i64, _int, _i64, _int, _c_f, _str]),
     "mnrf_tcnn_encode": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,
                                 _c_f, _str]),
+    "mnrf_tcnn_encode_flags": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _i64, _c_f, _i64, _c_f, _c_f, _int,
+                                      _c_f, _u32, _str]),
+    "mnrf_tcnn_table_half": (_int, [_c_f, _i64, ctypes.c_void_p, _str]),
     "mnrf_tcnn_weight_floats": (_int, []),
     "mnrf_tcnn_pack_weights": (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),
     "mnrf_tcnn_forward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,

@@ -155,6 +155,55 @@ def hash_grid_leg(dev, rays):
     sig32 = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log if (flags & 0x1000) and (flags & 1)]
     for m in models.values():
         m.mlp_f16 = False
+    # round 5: the table in half2 -- 4 B per entry, tinycudann's storage (models/mirror_nerf_tcnn.py:39-49; SURVEY 8d prices config 5
+    # at 16 x 8 x 4 = 512 B of gathers per sample) -- with the default MLP arithmetic and with single-pass f16 MLPs (config 5 as worded)
+    f16_table = {}
+    for m in models.values():
+        m.table_f16 = True
+    for key, mlp16 in (("frame_ms", False), ("frame_ms_f16_mlp", True)):
+        for m in models.values():
+            m.mlp_f16 = mlp16
+        frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame()
+        torch.cuda.synchronize()
+        f16_table[key] = D.max_over_ranks(time.perf_counter() - t0, dev) * 1e3
+    th, tflag = mfine._table()
+    planes = torch.empty(32 * zf.numel(), device=dev)
+    pr16 = lambda: _lib.check(_lib.lib().mnrf_tcnn_encode_flags(  # noqa: E731
+        th.data_ptr(), offs, mfine.cfg["S"], mfine.cfg["H"], float(mfine.bound), zf.numel(), None, 0,
+        _lib.ptr(rchunk), _lib.ptr(zf), zf.shape[1], _lib.ptr(planes), tflag, _lib.stream()), "encode (half2 table)")
+    pr16()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        pr16()
+    e1.record()
+    torch.cuda.synchronize()
+    enc16_ms = e0.elapsed_time(e1) / 5
+    planes = None
+    for m in models.values():
+        m.table_f16 = m.mlp_f16 = False
+    pmc16 = _pmc("mnrf::mf::tcnn_encode_kernel [half2 table]")
+    l2_16 = pmc16.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0 if pmc16 else None
+    n_ = rays.shape[0]
+    f16_table.update({
+        "rays_per_s": world * n_ / (f16_table["frame_ms"] * 1e-3), "rays_per_s_f16_mlp": world * n_ / (f16_table["frame_ms_f16_mlp"] * 1e-3),
+        "encode_ms": enc16_ms, "encode_ms_fp32_table": enc_ms, "table_bytes": int(th.numel() * 2),
+        "gather_roofline": {"bound": "l2", "achieved": (l2_16 / (enc16_ms * 1e-3) / 1e9) if l2_16 else None, "peak": 34500.0, "unit": "GB/s",
+                            "frac": (l2_16 / (enc16_ms * 1e-3) / 1e9 / 34500.0) if l2_16 else None, "l2_read_bytes_per_launch": l2_16,
+                            "l2_hit_rate": (pmc16["TCC_HIT_sum"] / (pmc16["TCC_HIT_sum"] + pmc16["TCC_MISS_sum"])) if pmc16 and "TCC_HIT_sum" in pmc16 else None,
+                            "tcp_hit_rate": (1.0 - pmc16["TCP_TCC_READ_REQ_sum"] / pmc16["TCP_TOTAL_CACHE_ACCESSES_sum"])
+                            if pmc16 and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc16 else None,
+                            "hbm_bytes_per_launch": ((2 * pmc16["FETCH_SIZE"] + pmc16["WRITE_SIZE"]) * 1024) if pmc16 and "FETCH_SIZE" in pmc16 and "WRITE_SIZE" in pmc16 else None,
+                            "counters_source": pmc16.get("source") if pmc16 else None},
+        "algorithmic_bytes_per_sample": 512 + 256,
+        "note": "module.table_f16 / MNRF_TCNN_TABLE_F16: the kernels gather from a half2 copy of the table (2 MB per hashed level against "
+                "the 4 MB L2 of an XCD; the fp32 master stays what the optimizer steps); forward bit-identical to the fp32-table kernels "
+                "on a table rounded to f16 (tests); a level-major gather still pulls a 128-byte line per corner, so the L2->L1 line rate, "
+                "not the entry size, bounds the launch"})
     ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_encode_kernel")
     params = [p for m in models.values() for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # (one multi-tensor launch; the default "foreach" form is ~10 passes over the two 49 MB tables)
@@ -266,6 +315,7 @@ def hash_grid_leg(dev, rays):
                                  "sample) over the time of the two launches; `traffic` = what reached the fabric in the encoding launch "
                                  "(PMC).  The table is cache-resident: gather_roofline (L2) is the ceiling that binds, this fraction "
                                  "is kept for the contract"},
+            "f16_table": f16_table,
             "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
                         "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
                         "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
@@ -329,6 +379,7 @@ def trained_leg(dev):
         if key == "plain":
             w = r.get("weights_fine")
             out["fine_samples_with_zero_weight"] = float((w == 0).float().mean()) if w is not None else None
+    out["guard_trips"] = int(sum(m.__dict__.get("_mnrf_guard_trips", 0) for m in models.values()))      # range-guard trips of the frames above
     out["note"] = ("G11 trained pair, 800x800 view of its analytic scene, eval rules (predicted mask: reflected rays = mirror pixels "
                    "of chunks that hold any); fine_samples_with_zero_weight = the share of samples whose heads exact head skipping "
                    "(models/rendering.py:190-213: w_i = 0) could leave out -- not built, DESIGN.md 8")

@@ -62,7 +62,14 @@ struct TcnnArgs {
     unsigned mode[NL];            // 0: dense level, 1: hashed, power-of-two size (mask), 2: hashed, any size (modulo)
     float* sigma; float* rgb; float* pred_normal; float* is_mirror; float* normal; float* geo_feat;
     float* enc;                   // level-major encoding planes [NL][B] float2 (caller's workspace) or null
+    unsigned table_f16;           // MNRF_TCNN_TABLE_F16: `table` holds half2 entries (4 B: tinycudann's storage) instead of float2
 };
+
+// one table entry (two features) by storage type.  The flag is a kernel argument: a wave-uniform branch next to a gather.
+__device__ __forceinline__ float2 tab_fetch(const float* table, unsigned f16, unsigned long long idx) {
+    if (f16) return __half22float2(((const __half2*)table)[idx]);
+    return ((const float2*)table)[idx];
+}
 
 extern __shared__ __attribute__((aligned(16))) float wlds[];
 
@@ -179,8 +186,8 @@ __device__ __forceinline__ unsigned grid_index(unsigned x, unsigned y, unsigned 
 // one level of the encoding: the two features and (GRAD) their derivatives w.r.t. the [0,1] coordinates
 template <bool GRAD>
 __device__ __forceinline__ void encode_level_p(const float* table, float scale, unsigned res, unsigned off0, unsigned hsize, unsigned mode,
-                                               const float (&u)[3], bool oob, float& a0, float& a1, float (&g0)[3], float (&g1)[3]) {
-    const float2* tab = (const float2*)table + off0;
+                                               const float (&u)[3], bool oob, float& a0, float& a1, float (&g0)[3], float (&g1)[3],
+                                               unsigned f16 = 0u) {
     unsigned pg[3];
     float fr[3];
 #pragma unroll
@@ -200,7 +207,7 @@ __device__ __forceinline__ void encode_level_p(const float* table, float scale, 
         const float wy = (c & 2) ? fr[1] : 1.f - fr[1];
         const float wz = (c & 4) ? fr[2] : 1.f - fr[2];
         // unconditional loads: the eight gathers of a level (and of the next levels, the loop is unrolled) go out together
-        const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, mode)];
+        const float2 v = tab_fetch(table, f16, off0 + grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, mode));
         const float w = wx * wy * wz * in_box;
         a0 += w * v.x; a1 += w * v.y;
         if (GRAD) {
@@ -217,7 +224,7 @@ __device__ __forceinline__ void encode_level_p(const float* table, float scale, 
 template <bool GRAD>
 __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const float (&u)[3], bool oob, float& a0, float& a1,
                                              float (&g0)[3], float (&g1)[3]) {
-    encode_level_p<GRAD>(A.table, A.scale[lv], A.res[lv], A.off[lv], A.off[lv + 1] - A.off[lv], A.mode[lv], u, oob, a0, a1, g0, g1);
+    encode_level_p<GRAD>(A.table, A.scale[lv], A.res[lv], A.off[lv], A.off[lv + 1] - A.off[lv], A.mode[lv], u, oob, a0, a1, g0, g1, A.table_f16);
 }
 
 template <bool SIGMA_ONLY, bool GRAD>
@@ -527,8 +534,7 @@ __device__ __forceinline__ void next_b(const f32x4 (&acc)[NG][2 * NTK], u32x4 (&
 struct LevelP { float scale; unsigned res, off0, hmask; bool dense; };
 template <bool GRAD>
 __device__ __forceinline__ void encode_level_p(const float* table, const LevelP& L, const float (&u)[3], bool oob, float& a0, float& a1,
-                                               float (&g0)[3], float (&g1)[3]) {
-    const float2* tab = (const float2*)table + L.off0;
+                                               float (&g0)[3], float (&g1)[3], unsigned f16 = 0u) {
     unsigned pg[3];
     float fr[3];
 #pragma unroll
@@ -551,7 +557,7 @@ __device__ __forceinline__ void encode_level_p(const float* table, const LevelP&
         const unsigned x = pg[0] + (c & 1), y = pg[1] + ((c >> 1) & 1), z = pg[2] + ((c >> 2) & 1);
         const unsigned lin = x + r1 * (y + r1 * z);
         const unsigned hsh = ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & L.hmask;
-        const float2 v = tab[L.dense ? lin : hsh];
+        const float2 v = tab_fetch(table, f16, L.off0 + (L.dense ? lin : hsh));
         const float w = wx * wy * wz * in_box;
         a0 += w * v.x; a1 += w * v.y;
         if (GRAD) {
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(256) void tcnn_encode_kernel(TcnnArgs A) {
         oob |= u[a] < 0.f || u[a] > 1.f;
     }
     float a0, a1, g0[3], g1[3];
-    encode_level_p<false>(A.table, L, u, oob, a0, a1, g0, g1);
+    encode_level_p<false>(A.table, L, u, oob, a0, a1, g0, g1, A.table_f16);
     __builtin_nontemporal_store(a0, A.enc + 2 * ((long long)lv * A.B + i));
     __builtin_nontemporal_store(a1, A.enc + 2 * ((long long)lv * A.B + i) + 1);
 }
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
                     const float2 v = ((const float2*)A.enc)[(long long)(4 * g + q) * A.B + idx[gi]];
                     f8[2 * q] = v.x; f8[2 * q + 1] = v.y;
                 } else {
-                    encode_level_p<false>(A.table, lvl[q], u[gi], oob[gi], f8[2 * q], f8[2 * q + 1], g0, g1);
+                    encode_level_p<false>(A.table, lvl[q], u[gi], oob[gi], f8[2 * q], f8[2 * q + 1], g0, g1, A.table_f16);
                 }
             }
             to_b<MODE>(f8, eh[gi][0], el[gi][0]);
@@ -1313,7 +1319,6 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
             const float scale = A.scale[lv];
             const unsigned res = A.res[lv];
             const unsigned hsize = A.off[lv + 1] - A.off[lv];
-            const float2* tab = (const float2*)A.table + A.off[lv];
             const bool coarse = P.cp_n[lv] != 0;                          // (wave-uniform)
             float* dtab = coarse ? P.copies + P.cp_off[lv] + 2ll * hsize * (blockIdx.x % (unsigned)P.cp_n[lv])
                                  : P.d_table + 2ll * A.off[lv];
@@ -1336,7 +1341,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
                 v0[c] = w * e0;
                 v1[c] = w * e1;
                 if (P.d_xyz && active) {
-                    const float2 v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
+                    const float2 v = tab_fetch(A.table, A.table_f16, A.off[lv] + grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]));
                     const float ev = e0 * v.x + e1 * v.y;
                     gx[0] += ((c & 1) ? scale : -scale) * wy * wz * ev;
                     gx[1] += ((c & 2) ? scale : -scale) * wx * wz * ev;
@@ -1479,7 +1484,6 @@ __global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
             const float scale = A.scale[lv];
             const unsigned res = A.res[lv];
             const unsigned hsize = A.off[lv + 1] - A.off[lv];
-            const float2* tab = (const float2*)A.table + A.off[lv];
             const bool coarse = P.cp_n[lv] != 0;
             float* dtab = coarse ? P.copies + P.cp_off[lv] + 2ll * hsize * (blockIdx.x % (unsigned)P.cp_n[lv])
                                  : P.d_table + 2ll * A.off[lv];
@@ -1504,7 +1508,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
                 v0[c] = dw * e0;
                 v1[c] = dw * e1;
                 float2 v = float2{0.f, 0.f};
-                if (active) v = tab[grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv])];
+                if (active) v = tab_fetch(A.table, A.table_f16, A.off[lv] + grid_index(pg[0] + (c & 1), pg[1] + ((c >> 1) & 1), pg[2] + ((c >> 2) & 1), hsize, res, A.mode[lv]));
                 df0 += dw * v.x; df1 += dw * v.y;
                 if (P.d_xyz) {
                     const float ev = e0 * v.x + e1 * v.y;
@@ -1765,6 +1769,7 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     level_modes(A);
     A.sigma = sigma; A.rgb = rgb; A.pred_normal = pred_normal; A.is_mirror = is_mirror; A.normal = normal; A.geo_feat = geo_feat;
     A.enc = enc_workspace;
+    A.table_f16 = (flags & MNRF_TCNN_TABLE_F16) ? 1u : 0u;
     hipStream_t s = (hipStream_t)stream;
     // MLPs on the matrix pipe (default); MNRF_TCNN_VALU=1 selects the one-thread-per-sample VALU kernel (A/B measurements)
     static const bool env_valu = [] { const char* e = getenv("MNRF_TCNN_VALU"); return e && e[0] == '1'; }();
@@ -1880,6 +1885,8 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     }
     A.off[NL] = (unsigned)offsets17_host[NL];
     level_modes(A);
+    A.enc = nullptr;
+    A.table_f16 = (flags & MNRF_TCNN_TABLE_F16) ? 1u : 0u;
     A.sigma = A.rgb = A.pred_normal = A.is_mirror = A.normal = A.geo_feat = nullptr;
     P.g_sigma = g_sigma; P.g_rgb = g_rgb; P.g_pn = g_pred_normal; P.g_m = g_is_mirror; P.g_normal = g_normal;
     P.d_table = d_table; P.d_weights = d_weights; P.d_xyz = d_xyz; P.d_dir = d_dir;
@@ -1974,13 +1981,34 @@ __global__ __launch_bounds__(256) void gather_bench_kernel(const T* __restrict__
 // The multiresolution hash encoding alone (tcnn_encode_kernel): planes[level][sample] = the level's two features, for samples
 // given as rows of `xyz` or as rays + z_vals.  This is the first of the two launches of mnrf_tcnn_forward(enc_workspace != null);
 // exposed for measurement (bench.py times it against the L2 roofline) and for callers that want the encoding itself.
+extern "C" int mnrf_tcnn_encode_flags(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                      int base_resolution, float bound, int64_t B, const float* xyz, int64_t xyz_stride,
+                                      const float* rays, const float* z_vals, int spr, float* planes, unsigned flags, void* stream) {
+    if (!planes) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_encode: null output");
+    if (flags & ~MNRF_TCNN_TABLE_F16) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_encode: flags = 0 or MNRF_TCNN_TABLE_F16");
+    return mnrf_tcnn_forward(table, offsets17_host, log2_per_level_scale, base_resolution, bound, table /* unused */,
+                             0x80000000u | MNRF_SIGMA_ONLY | flags,
+                             B, xyz, xyz_stride, rays, z_vals, spr, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             planes, stream);
+}
 extern "C" int mnrf_tcnn_encode(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
                                 int base_resolution, float bound, int64_t B, const float* xyz, int64_t xyz_stride,
                                 const float* rays, const float* z_vals, int spr, float* planes, void* stream) {
-    if (!planes) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_encode: null output");
-    return mnrf_tcnn_forward(table, offsets17_host, log2_per_level_scale, base_resolution, bound, table /* unused */, 0x80000000u | MNRF_SIGMA_ONLY,
-                             B, xyz, xyz_stride, rays, z_vals, spr, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             planes, stream);
+    return mnrf_tcnn_encode_flags(table, offsets17_host, log2_per_level_scale, base_resolution, bound, B, xyz, xyz_stride, rays, z_vals,
+                                  spr, planes, 0u, stream);
+}
+
+// fp32 master table -> the half2 copy the MNRF_TCNN_TABLE_F16 launches read (round to nearest even, like a .half() cast)
+__global__ void tcnn_table_half_kernel(const float2* __restrict__ src, __half2* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __float22half2_rn(src[i]);
+}
+extern "C" int mnrf_tcnn_table_half(const float* table, int64_t entries, void* table_half, void* stream) {
+    if (!table || !table_half || entries < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_table_half: bad argument");
+    if (entries == 0) return MNRF_OK;
+    hipLaunchKernelGGL(tcnn_table_half_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)table, (__half2*)table_half, (long long)entries);
+    return mnrf_check_launch("mnrf_tcnn_table_half");
 }
 
 extern "C" int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gather, int64_t n_threads, int iters,

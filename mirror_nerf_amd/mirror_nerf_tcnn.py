@@ -55,6 +55,9 @@ GRAD_F16 = os.environ.get("MNRF_TCNN_GRAD_F16", "0") == "1"
 # as BASELINE config 5 words it; the sigma-only launches then run on the matrix pipe too.  The backward recomputes in fp32.
 GRAD_FIXED = os.environ.get("MNRF_TCNN_GRAD_FIXED", "1") != "0"
 MLP_F16 = os.environ.get("MNRF_TCNN_F16", "0") == "1"
+# module.table_f16 (env MNRF_TCNN_TABLE_F16=1 sets the default): the kernels gather from a half2 copy of the table (4 B per entry,
+# tinycudann's storage) instead of the fp32 master; see MirrorNeRFTcnn._table
+TABLE_F16 = os.environ.get("MNRF_TCNN_TABLE_F16", "0") == "1"
 # smallest launch (samples) that encodes level by level into scratch planes (module.enc_planes_min overrides; a huge value
 # keeps the one-launch form)
 ENC_PLANES_MIN = int(os.environ.get("MNRF_TCNN_PLANES_MIN", "32768"))
@@ -114,7 +117,8 @@ class TcnnFieldFn(torch.autograd.Function):
     def backward(ctx, g_sigma, g_rgb, g_pn, g_m, g_normal, _g_geo):
         xyz6, rays, z_vals, dirs = ctx.saved_tensors
         m, B, spr = ctx.module, ctx.B, ctx.spr
-        table = m.encoder.embeddings.detach().contiguous()
+        table = m.encoder.embeddings.detach().contiguous()      # the fp32 master: the gradient has its shape
+        read_table, tflag = m._table()                          # what the kernels gather from (the half2 copy with table_f16)
         dev = table.device
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         g_sigma, g_rgb, g_pn, g_m, g_normal = c(g_sigma), c(g_rgb), c(g_pn), c(g_m), c(g_normal)
@@ -144,9 +148,9 @@ class TcnnFieldFn(torch.autograd.Function):
         p = _lib.ptr
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_backward(
-                p(table), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
+                read_table.data_ptr(), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
-                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), flags,
+                p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), flags | tflag,
                 _lib.stream()), "mnrf_tcnn_backward")
         if B and (flags & _lib.MNRF_TCNN_GRAD_F16):
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -234,10 +238,30 @@ class MirrorNeRFTcnn(nn.Module):
             self._blob_key = key
         return self._blob
 
+    def _table(self):
+        """(table pointer tensor, flag): the fp32 table, or -- module.table_f16 (env MNRF_TCNN_TABLE_F16=1 sets the default) -- its
+        half2 copy: 4-byte entries, tinycudann's storage (models/mirror_nerf_tcnn.py:39-49 builds a tcnn HashGrid, whose parameters
+        live in half precision with an fp32 master copy in the optimizer; SURVEY 8d prices config 5 at 512 B of gathers per sample).
+        The fp32 `encoder.embeddings` stays the master the optimizer steps and the gradients land in; the copy is re-made (one launch,
+        73 MB of traffic) whenever the master changed."""
+        table = self.encoder.embeddings.detach()
+        if not getattr(self, "table_f16", TABLE_F16):
+            return table.contiguous(), 0
+        from .weights import _GENERATION
+        key = (_GENERATION[0], table.data_ptr(), self.encoder.embeddings._version)
+        if self.__dict__.get("_table_half_key") != key:
+            half = self.__dict__.get("_table_half")
+            if half is None or half.shape[0] != table.shape[0] or half.device != table.device:
+                half = torch.empty(table.shape[0], 2, dtype=torch.float16, device=table.device)
+            _lib.check(_lib.lib().mnrf_tcnn_table_half(_lib.ptr(table.contiguous()), table.shape[0], half.data_ptr(), _lib.stream()),
+                       "mnrf_tcnn_table_half")
+            self.__dict__["_table_half"], self.__dict__["_table_half_key"] = half, key
+        return self.__dict__["_table_half"], _lib.MNRF_TCNN_TABLE_F16
+
     def field(self, B, *, xyz=None, xyz_stride=6, rays=None, z_vals=None, spr=1, dirs=None, sigma_only=False,
               grad_normal=False, want_geo=False):
         """Run the fused kernel; returns flat per-sample tensors like mirror_nerf.field_forward."""
-        table = self.encoder.embeddings.detach()
+        table, tflag = self._table()
         dev = table.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         out = {"sigma": f(B), "pred_normal": f(B, 3)}
@@ -248,7 +272,7 @@ class MirrorNeRFTcnn(nn.Module):
             out["normal"] = f(B, 3)
         if want_geo:
             out["geo_feat"] = f(B, 15)
-        flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0)
+        flags = (_lib.MNRF_SIGMA_ONLY if sigma_only else 0) | (_lib.MNRF_GRAD_NORMAL if grad_normal else 0) | tflag
         if getattr(self, "mlp_on_valu", False):     # the fp32 VALU kernel instead of hi/lo f16 tiles on the matrix pipe (~1e-6 apart)
             flags |= _lib.MNRF_TCNN_VALU
         elif getattr(self, "mlp_f16", MLP_F16):     # single-pass f16 MLPs: tinycudann's / precision=16's arithmetic (train.py:586)
@@ -268,7 +292,7 @@ class MirrorNeRFTcnn(nn.Module):
             e0.record()
         if B:
             _lib.check(_lib.lib().mnrf_tcnn_forward(
-                p(table.contiguous()), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
+                table.data_ptr(), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
                 p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3,
                 p(out["sigma"]), p(out.get("rgb")), p(out["pred_normal"]), p(out.get("is_mirror")), p(out.get("normal")),
                 p(out.get("geo_feat")), p(enc), _lib.stream()), "mnrf_tcnn_forward")

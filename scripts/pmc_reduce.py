@@ -27,13 +27,20 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
                 continue
             d = per[k][row["Counter_Name"]]
             d[int(row["Dispatch_Id"])] = d.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib.util      # (mirror_nerf_amd/source_hash.py on its own: importing the package would load torch)
+_spec = importlib.util.spec_from_file_location("source_hash", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           "mirror_nerf_amd", "source_hash.py"))
+SH = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(SH)
 out, traffic = {}, {}
 for k, counters in per.items():
     out[k] = {c: v[max(v)] for c, v in counters.items()}
+    out[k]["source_sha1"] = SH.source_sha1(k)      # the sources these counters describe (tests/test_traffic_cpu.py)
     if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
         hbm = (2 * out[k]["FETCH_SIZE"] + out[k]["WRITE_SIZE"]) * 1024
         traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib": out[k]["FETCH_SIZE"], "write_kib": out[k]["WRITE_SIZE"],
-                      "commit": commit}
+                      "commit": commit, "source_sha1": out[k]["source_sha1"]}
     o = out[k]
     if "SQ_WAVE_CYCLES" in o and "SQ_VALU_MFMA_BUSY_CYCLES" in o:
         o["mfma_busy_frac"] = o["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * o["SQ_WAVE_CYCLES"])

@@ -826,3 +826,102 @@ def test_g17_eval_recursion(name):
         assert err <= FX.tolerance(k, m), (k, err, FX.tolerance(k, m))
         n += 1
     assert n >= 12
+
+
+# ----------------------------------------------------------------------------- round 5: the table in half2 (tinycudann's storage)
+def test_tcnn_f16_table_equals_the_fp32_kernels_on_a_rounded_table():
+    """module.table_f16 (MNRF_TCNN_TABLE_F16): the kernels gather from a half2 copy of the table -- 4 B per entry, what tinycudann
+    stores (models/mirror_nerf_tcnn.py:39-49; SURVEY 8d's 512 B per sample) -- made from the fp32 master by mnrf_tcnn_table_half.
+    A half2 -> float2 conversion is exact, so every output AND every gradient must equal, bit for bit, what the fp32-table kernels
+    give on a model whose master table holds the rounded values; against the unrounded master the forward differs by f16 rounding of
+    the entries (2^-11 relative).  Covers the one-launch and the level-major two-launch forward, sigma-only, the VALU kernel with the
+    density-gradient normal, the encoding entry point, and the backward incl. the position gradient."""
+    from mirror_nerf_amd import _lib
+    from mirror_nerf_amd.mirror_nerf_tcnn import TcnnFieldFn, _offsets17
+    m, _w, _cfg = _model(6.0, seed=4, table_scale=0.3)
+    r, _w2, _c2 = _model(6.0, seed=4, table_scale=0.3)
+    with torch.no_grad():
+        r.encoder.embeddings.copy_(m.encoder.embeddings.half().float())       # the rounded twin, fp32 storage
+    rays = torch.from_numpy(O.synthetic_rays(16, 16)).to(DEV)
+    N, S = rays.shape[0], 40
+    z = (torch.linspace(0.3, 7.5, S, device=DEV)[None] + 0.05 * torch.rand(N, S, device=DEV)).contiguous()
+    m.table_f16 = True
+    with torch.no_grad():
+        for kw in (dict(), dict(sigma_only=True), dict(grad_normal=True), dict(want_geo=True)):
+            for planes_min in (1, 1 << 62):
+                m.enc_planes_min = r.enc_planes_min = planes_min
+                a = m.field(N * S, rays=rays, z_vals=z, spr=S, **kw)
+                b = r.field(N * S, rays=rays, z_vals=z, spr=S, **kw)
+                for k in b:
+                    assert torch.equal(a[k], b[k]), (kw, planes_min, k)
+        del m.enc_planes_min, r.enc_planes_min
+        m.table_f16 = False
+        full = m.field(N * S, rays=rays, z_vals=z, spr=S)
+        m.table_f16 = True
+        half = m.field(N * S, rays=rays, z_vals=z, spr=S)
+    d = float((full["sigma"] - half["sigma"]).abs().max())
+    assert 0 < d <= 2e-3 * max(1.0, float(full["sigma"].abs().max())), d            # f16 entries: different, and close
+    # the encoding entry point
+    pa, pb = torch.empty(16, N * S, 2, device=DEV), torch.empty(16, N * S, 2, device=DEV)
+    th, flag = m._table()
+    assert flag == _lib.MNRF_TCNN_TABLE_F16 and th.dtype == torch.float16
+    offs = _offsets17(m.cfg)
+    _lib.check(_lib.lib().mnrf_tcnn_encode_flags(th.data_ptr(), offs, m.cfg["S"], m.cfg["H"], float(m.bound), N * S, None, 0, _lib.ptr(rays),
+                                                 _lib.ptr(z), S, _lib.ptr(pa), flag, _lib.stream()), "encode f16")
+    tr = r.encoder.embeddings.detach().contiguous()
+    _lib.check(_lib.lib().mnrf_tcnn_encode(_lib.ptr(tr), offs, m.cfg["S"], m.cfg["H"], float(m.bound), N * S, None, 0, _lib.ptr(rays),
+                                           _lib.ptr(z), S, _lib.ptr(pb), _lib.stream()), "encode")
+    assert torch.equal(pa, pb)
+    # backward: gradients of the master table, of the MLPs and of the positions
+    x6 = torch.cat([(rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3),
+                    rays[:, None, 3:6].expand(N, S, 3).reshape(-1, 3)], 1).contiguous()
+    grads = []
+    for mod in (m, r):
+        x = x6.clone().requires_grad_(True)
+        for q in mod.parameters():
+            q.grad = None
+        sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(mod, 1, x, None, None, None, True, mod.encoder.embeddings, *mod.mlp_params())
+        (sigma.sum() + (rgb ** 2).sum() + pn[:, 0].sum() + mir.sum() + normal[:, 1].sum()).backward()
+        grads.append([x.grad.clone(), mod.encoder.embeddings.grad.clone()] + [q.grad.clone() for q in mod.mlp_params()])
+    assert torch.equal(grads[0][0], grads[1][0])                     # positions: no atomics, bit for bit
+    for ga, gb in zip(grads[0][1:], grads[1][1:]):                   # table and MLPs: sums of atomics, equal to their rounding
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-30
+    assert float(grads[0][1].abs().max()) > 0
+
+
+def test_tcnn_f16_table_follows_the_master_after_an_optimizer_step():
+    """The half2 copy is re-made when the fp32 master changed (a fused optimizer step bumps the generation the copy is keyed on)."""
+    m, _w, _cfg = _model(6.0, seed=5, table_scale=0.3)
+    m.table_f16 = True
+    rays = torch.from_numpy(O.synthetic_rays(8, 8)).to(DEV)
+    z = torch.linspace(0.3, 7.5, 32, device=DEV)[None].expand(rays.shape[0], 32).contiguous()
+    with torch.no_grad():
+        a = m.field(rays.shape[0] * 32, rays=rays, z_vals=z, spr=32)["sigma"].clone()
+    opt = torch.optim.Adam([m.encoder.embeddings], lr=1e-2, fused=True)
+    m.encoder.embeddings.grad = torch.ones_like(m.encoder.embeddings)
+    opt.step()
+    with torch.no_grad():
+        b = m.field(rays.shape[0] * 32, rays=rays, z_vals=z, spr=32)["sigma"]
+    assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["g17_tcnn_render_test"])
+def test_g17_render_rays_with_f16_table_and_f16_mlps(name):
+    """Config 5 as BASELINE words it -- half2 table, fp16 MLPs -- on the reference's own render (fixture G17) at the tolerances of
+    the single-pass-f16 arithmetic: a few 1e-3 of each output's scale."""
+    import mirror_nerf_amd as M
+    from tests.golden import fixtures as FX
+    fx = FX.Fixture(name)
+    mc, _ = _g17_model(fx, "coarse__", 0)
+    mf, _ = _g17_model(fx, "fine__", 1)
+    for mdl in (mc, mf):
+        mdl.table_f16 = mdl.mlp_f16 = True
+    emb = {"xyz": M.Embedding(0), "dir": M.Embedding(0)}
+    with torch.no_grad():
+        got = M.render_rays({"coarse": mc, "fine": mf}, emb, torch.from_numpy(fx.inputs["rays"]).to(DEV), 64, False, 0, 0, 64,
+                            32768, False, True, compute_normal=False)
+    for k in ("rgb_fine", "opacity_fine", "mirror_mask_fine"):
+        want = fx.outputs[k]
+        assert float(np.max(np.abs(got[k].cpu().numpy() - want))) <= 5e-3 * max(1.0, float(np.abs(want).max())), k
+    far = float(fx.inputs["rays"][:, 7].max())
+    assert float(np.max(np.abs(got["depth_fine"].cpu().numpy() - fx.outputs["depth_fine"]))) <= 5e-3 * far
