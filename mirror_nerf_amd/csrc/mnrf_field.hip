@@ -217,6 +217,10 @@ extern "C" int64_t mnrf_train_save_floats(int64_t B) { return (int64_t)SAVE_FLOA
 extern "C" int64_t mnrf_train_mask_words(int64_t B) { return train_tiles(B) * N_MASKS * s2::S * s2::WG_THREADS; }
 extern "C" int64_t mnrf_train_workspace_floats(int64_t B) { return (int64_t)DY_FLOATS * B + dw_workspace_floats(B); }
 
+#ifdef MNRF_EXP_CYCLES      // experiment builds only (scripts/exp_train_marks.py): where the s_memtime marks of the training forward go
+static void* g_exp_marks = nullptr;
+extern "C" void mnrf_exp_set_marks(void* p) { g_exp_marks = p; }
+#endif
 static int field_forward_train_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                     const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                     int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
@@ -237,6 +241,9 @@ static int field_forward_train_impl(const float* packed, int64_t B, const float*
                 (long long)dir_stride, sigma, rgb, pred_normal, is_mirror, normal, nullptr,
                 planes ? nullptr : save_x, (unsigned long long*)save_mask, save_inv, save_invj, planes ? (char*)save_x : nullptr};
     A.n_live = n_live;
+#ifdef MNRF_EXP_CYCLES
+    A.geo_feat = (float*)g_exp_marks;
+#endif
     // always a 128-sample tiling with the mask-producing (GRAD) body: the backward kernel shares its tile map.
     // MNRF_SPLIT_F16: the split-f16 tuning (same saved quantities, fp32 activations from its fp32 accumulators)
     const int rc = (flags & MNRF_SPLIT_F16) ? launch_split(A, false, true, 0, (hipStream_t)stream)
