@@ -444,15 +444,16 @@ int64_t mnrf_dw_planes2_n_workspace_floats(int n_eval);
 int mnrf_dw_planes2_n(int n_eval, const void* const* x_planes, const void* const* dy_planes, const int64_t* B,
                       const int32_t* const* n_live, const int* spr, const uint32_t* const* seedmax, const int* kinds,
                       float* workspace, float* const* d_params, int accumulate, void* stream);
-/* mnrf_adam_step with its hyper-parameters and step count in DEVICE memory (a captured step must not freeze them): hyper =
- * [lr, beta1, beta2, eps, weight_decay] (doubles; lr, eps and weight_decay are rounded to float as the namesake's arguments
- * are), *step = the count of calls, this one included -- the caller advances it on the stream with mnrf_add_i64. */
-int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
-                       const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf,
-                       const uint32_t* const* guard_words /* HOST array of n_guard_words (0..4) device words: a non-zero range-guard
-                                                             word (the last word of a packed image) vetoes the update like found_inf */,
-                       int n_guard_words, void* stream);
-int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream);      /* *counter += delta (device), one thread */
+/* mnrf_adam_step with every scalar of the step in DEVICE memory (a captured step must not freeze the learning rate or the step
+ * count).  mnrf_adam_prep, one thread: *step += 1 (the count of steps, this one included), then state[0..7] = [veto, lr / bias
+ * correction 1, sqrt(bias correction 2), beta1, beta2, 1 / grad_scale, eps, weight_decay] from hyper = [lr, beta1, beta2, eps,
+ * weight_decay] (doubles; lr, eps and weight_decay are rounded to float as mnrf_adam_step's arguments are) and *skipped (the
+ * first model's counter of vetoed steps); veto = *found_inf != 0 or any of the 0..4 range-guard words (HOST array of device words:
+ * the last word of a packed image) non-zero.  mnrf_adam_step_dev: the update of one flat tensor from `state`. */
+int mnrf_adam_prep(const double* hyper, int64_t* step, const int32_t* skipped, const float* grad_scale, const float* found_inf,
+                   const uint32_t* const* guard_words, int n_guard_words, float* state, void* stream);
+int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* state,
+                       int32_t* skipped, void* stream);
 
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);

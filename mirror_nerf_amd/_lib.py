@@ -134,9 +134,8 @@ SIGNATURES = {
     "mnrf_dw_planes2_n": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                  ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
-    "mnrf_adam_step_dev": (_int, [_c_f, _c_f, _c_f, _c_f, _i64, ctypes.c_void_p, ctypes.c_void_p, _c_i, _c_f, _c_f,
-                                  ctypes.POINTER(ctypes.c_void_p), _int, _str]),
-    "mnrf_add_i64": (_int, [ctypes.c_void_p, _i64, _str]),
+    "mnrf_adam_prep": (_int, [ctypes.c_void_p, ctypes.c_void_p, _c_i, _c_f, _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _c_f, _str]),
+    "mnrf_adam_step_dev": (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _c_f, _c_i, _str]),
 }
 
 _lib = None

@@ -25,36 +25,31 @@ struct AdamArgs {
     int* skipped;              // device: how many of them found_inf has skipped so far
     const float* grad_scale;   // device scalars or null
     const float* found_inf;
-    // device-resident hyper-parameters and step count (mnrf_adam_step_dev: a step captured in a hipGraph must not freeze them)
-    const double* hyper;       // [lr, beta1, beta2, eps, weight_decay] or null
-    const long long* step_dev; // the count of step() calls, this one included, or null
-    // range-guard words (mnrf.h MNRF_GUARD_*) that veto the update like found_inf does: a non-zero word = a launch of this step
-    // left the range of the split arithmetic (no torch ops needed to turn the words into a found_inf tensor inside a captured step)
-    const unsigned* guard[4];
-    int n_guard;
+    // mnrf_adam_step_dev: every scalar of the step comes from a device block written by adam_prep_kernel (a step captured in a hipGraph
+    // must not freeze them): [veto, lr / bias correction 1, sqrt(bias correction 2), beta1, beta2, 1 / grad_scale, eps, weight_decay]
+    const float* state;
 };
 
 __global__ void adam_kernel(AdamArgs A) {
-    // thread 0 reads every scalar of the step (device-resident ones included) once per block and leaves what the others need in LDS
-    __shared__ float sh[6];      // veto, step_size, sqrt(bias correction 2), beta1, beta2, inv_scale
-    __shared__ float sh_eps_wd[2];
+    // thread 0 reads the scalars of the step once per block and leaves what the others need in LDS
+    __shared__ float sh[8];
     if (threadIdx.x == 0) {
-        if (A.hyper) {
-            A.lr = (float)A.hyper[0]; A.beta1 = A.hyper[1]; A.beta2 = A.hyper[2]; A.eps = (float)A.hyper[3]; A.wd = (float)A.hyper[4];
-            A.step = *A.step_dev;
+        if (A.state) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh[i] = A.state[i];
+        } else {
+            const bool veto = A.found_inf && *A.found_inf != 0.f;
+            const long long eff = A.step - (long long)*A.skipped;      // >= 1 when the caller counts as documented
+            const double t = (double)(eff < 1 ? 1 : eff);
+            sh[0] = veto ? 1.f : 0.f;
+            sh[1] = A.lr / (float)(1.0 - pow(A.beta1, t));
+            sh[2] = (float)sqrt(1.0 - pow(A.beta2, t));
+            sh[3] = (float)A.beta1;
+            sh[4] = (float)A.beta2;
+            sh[5] = A.grad_scale ? 1.f / *A.grad_scale : 1.f;
+            sh[6] = A.eps;
+            sh[7] = A.wd;
         }
-        bool veto = A.found_inf && *A.found_inf != 0.f;
-        for (int i = 0; i < A.n_guard; ++i) veto |= *A.guard[i] != 0u;
-        const long long eff = A.step - (long long)*A.skipped;      // >= 1 when the caller counts as documented
-        const double t = (double)(eff < 1 ? 1 : eff);
-        sh[0] = veto ? 1.f : 0.f;
-        sh[1] = A.lr / (float)(1.0 - pow(A.beta1, t));
-        sh[2] = (float)sqrt(1.0 - pow(A.beta2, t));
-        sh[3] = (float)A.beta1;
-        sh[4] = (float)A.beta2;
-        sh[5] = A.grad_scale ? 1.f / *A.grad_scale : 1.f;
-        sh_eps_wd[0] = A.eps;
-        sh_eps_wd[1] = A.wd;
     }
     __syncthreads();
     if (sh[0] != 0.f) {      // the whole grid leaves; one thread records that this call did not count
@@ -65,8 +60,9 @@ __global__ void adam_kernel(AdamArgs A) {
     const float bc2_sqrt = sh[2];
     const float b1 = sh[3], b2 = sh[4];
     const float inv_scale = sh[5];
-    A.eps = sh_eps_wd[0];
-    A.wd = sh_eps_wd[1];
+    const bool scaled = sh[5] != 1.f;
+    A.eps = sh[6];
+    A.wd = sh[7];
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= A.n) return;
     const bool full = i4 + 4 <= A.n;
@@ -84,7 +80,7 @@ __global__ void adam_kernel(AdamArgs A) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float gr = A.grad_scale ? g[c] * inv_scale : g[c];
+        float gr = scaled ? g[c] * inv_scale : g[c];
         if (A.wd != 0.f) gr = gr + A.wd * p[c];
         m[c] = m[c] + (1.f - b1) * (gr - m[c]);                    // lerp(exp_avg, grad, 1 - beta1)
         v[c] = b2 * v[c] + (1.f - b2) * gr * gr;                   // exp_avg_sq * beta2 + (1 - beta2) grad^2
@@ -114,39 +110,63 @@ extern "C" int mnrf_adam_step(float* param, const float* grad, float* exp_avg, f
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step: tensors must be 16-byte aligned");
     AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, eps, weight_decay, beta1, beta2, (long long)step, skipped, grad_scale, found_inf,
-               nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}, 0};
+               nullptr};
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step");
 }
 
-// counter += delta, one thread (the step count of mnrf_adam_step_dev inside a captured step)
+// ---- the same update with every scalar in device memory (a step captured in a hipGraph must not freeze the learning rate or the
+// step count).  mnrf_adam_prep: one thread -- *step += 1, then the scalars of this step -> state[8]; mnrf_adam_step_dev: the update.
 namespace mnrf {
-__global__ void add_i64_kernel(long long* c, long long d) { *c += d; }
+struct AdamPrepArgs {
+    const double* hyper; long long* step; const int* skipped; const float* grad_scale; const float* found_inf;
+    const unsigned* guard[4]; int n_guard; float* state;
+};
+__global__ void adam_prep_kernel(AdamPrepArgs P) {
+    const long long step = *P.step + 1;
+    *P.step = step;
+    bool veto = P.found_inf && *P.found_inf != 0.f;
+    for (int i = 0; i < P.n_guard; ++i) veto |= *P.guard[i] != 0u;      // a range-guard word of this step's launches (mnrf.h MNRF_GUARD_*)
+    const float lr = (float)P.hyper[0], eps = (float)P.hyper[3], wd = (float)P.hyper[4];
+    const double beta1 = P.hyper[1], beta2 = P.hyper[2];
+    const long long eff = step - (long long)*P.skipped;
+    const double t = (double)(eff < 1 ? 1 : eff);
+    P.state[0] = veto ? 1.f : 0.f;
+    P.state[1] = lr / (float)(1.0 - pow(beta1, t));
+    P.state[2] = (float)sqrt(1.0 - pow(beta2, t));
+    P.state[3] = (float)beta1;
+    P.state[4] = (float)beta2;
+    P.state[5] = P.grad_scale ? 1.f / *P.grad_scale : 1.f;
+    P.state[6] = eps;
+    P.state[7] = wd;
+}
 }  // namespace mnrf
-extern "C" int mnrf_add_i64(int64_t* counter, int64_t delta, void* stream) {
-    if (!counter) return mnrf_fail(MNRF_ERR_ARG, "mnrf_add_i64: null pointer");
-    hipLaunchKernelGGL(mnrf::add_i64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)counter, (long long)delta);
-    return mnrf_check_launch("mnrf_add_i64");
+
+extern "C" int mnrf_adam_prep(const double* hyper, int64_t* step, const int32_t* skipped, const float* grad_scale, const float* found_inf,
+                              const uint32_t* const* guard_words, int n_guard_words, float* state, void* stream) {
+    using namespace mnrf;
+    if (!hyper || !step || !skipped || !state) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_prep: null pointer");
+    if (n_guard_words < 0 || n_guard_words > 4 || (n_guard_words > 0 && !guard_words))
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_prep: 0..4 guard words");
+    AdamPrepArgs P{hyper, (long long*)step, skipped, grad_scale, found_inf, {nullptr, nullptr, nullptr, nullptr}, n_guard_words, state};
+    for (int i = 0; i < n_guard_words; ++i) {
+        if (!guard_words[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_prep: null guard word");
+        P.guard[i] = guard_words[i];
+    }
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, P);
+    return mnrf_check_launch("mnrf_adam_prep");
 }
 
-extern "C" int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* hyper,
-                                  const int64_t* step, int32_t* skipped, const float* grad_scale, const float* found_inf,
-                                  const uint32_t* const* guard_words, int n_guard_words, void* stream) {
+extern "C" int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* state,
+                                  int32_t* skipped, void* stream) {
     using namespace mnrf;
-    if (n_guard_words < 0 || n_guard_words > 4 || (n_guard_words > 0 && !guard_words))
-        return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: 0..4 guard words");
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !skipped || !hyper || !step) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null pointer");
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !skipped || !state) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null pointer");
     if (n < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: n >= 0");
     if (n == 0) return MNRF_OK;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: tensors must be 16-byte aligned");
-    AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, 0.f, 0.f, 0.f, 0.0, 0.0, 1, skipped, grad_scale, found_inf, hyper,
-               (const long long*)step, {nullptr, nullptr, nullptr, nullptr}, n_guard_words};
-    for (int i = 0; i < n_guard_words; ++i) {
-        if (!guard_words[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev: null guard word");
-        A.guard[i] = guard_words[i];
-    }
+    AdamArgs A{param, grad, exp_avg, exp_avg_sq, (long long)n, 0.f, 0.f, 0.f, 0.0, 0.0, 1, skipped, nullptr, nullptr, state};
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step_dev");

@@ -893,10 +893,13 @@ __global__ __launch_bounds__(256) void ray_grads_kernel(const float* __restrict_
                                                         const float* __restrict__ d_dir, long long n_rays, int spr,
                                                         float* __restrict__ g_rays, float* __restrict__ g_de,
                                                         const int* __restrict__ n_live) {
+    // one WORKGROUP per ray (round 5; it was one wavefront per ray, 64 dependent 256-byte loads deep for the view-encoding sum:
+    // 23 us per launch for 257 live rays): wave 0 sums the position gradients, all four waves the 32-float rows of d_dir
+    __shared__ float part[8][32];
     const int lane = threadIdx.x & 63;
-    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ray = blockIdx.x;
     if (ray >= live_rows(n_rays, n_live)) return;
-    if (g_rays) {
+    if (g_rays && threadIdx.x < 64) {
         float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int s = lane; s < spr; s += 64) {
             const float* p = d_xyz + (ray * spr + s) * 3;
@@ -912,12 +915,18 @@ __global__ __launch_bounds__(256) void ray_grads_kernel(const float* __restrict_
         if (lane < 8) g_rays[ray * 8 + lane] = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3]
                                                : lane == 4 ? a[4] : lane == 5 ? a[5] : 0.f;      // (near, far: no gradient)
     }
-    if (g_de) {      // d_dir: (B, 32) rows, the 27 channels of Embedding(4) used
-        const int c = lane & 31;
+    if (g_de) {      // d_dir: (B, 32) rows, the 27 channels of Embedding(4) used; fixed summation order
+        const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;      // 8 groups of 32 threads, samples grp, grp + 8, ...
         float acc = 0.f;
-        for (int s = lane >> 5; s < spr; s += 2) acc += d_dir[(ray * spr + s) * 32 + c];
-        acc += __shfl_xor(acc, 32);
-        if (lane < 27) g_de[ray * 27 + lane] = acc;
+        for (int s = grp; s < spr; s += 8) acc += d_dir[(ray * spr + s) * 32 + c];
+        part[grp][c] = acc;
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+            g_de[ray * 27 + threadIdx.x] = t;
+        }
     }
 }
 
@@ -926,7 +935,8 @@ static int ray_grads_impl(const float* d_xyz, const float* z_vals, const float* 
     if (n_rays < 0 || spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: bad size");
     if (n_rays == 0 || (!g_rays && !g_de)) return MNRF_OK;
     if ((g_rays && (!d_xyz || !z_vals)) || (g_de && !d_dir)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: null pointer");
-    hipLaunchKernelGGL(ray_grads_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, d_xyz, z_vals, d_dir,
+    if (n_rays > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_grads: too many rays for one launch");
+    hipLaunchKernelGGL(ray_grads_kernel, dim3((unsigned)n_rays), dim3(256), 0, (hipStream_t)stream, d_xyz, z_vals, d_dir,
                        (long long)n_rays, spr, g_rays, g_de, n_live);
     return mnrf_check_launch("mnrf_ray_grads");
 }

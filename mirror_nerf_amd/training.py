@@ -333,6 +333,7 @@ class FlatAdam:
         self._hyper_host = None
         self._hyper = torch.zeros(5, dtype=torch.float64, device=dev)
         self._step_dev = torch.tensor([self._calls], dtype=torch.int64, device=dev)
+        self._state_dev = torch.zeros(8, dtype=torch.float32, device=dev)      # the scalars of a step (mnrf_adam_prep)
         self.sync_hyper()
 
     def sync_hyper(self):
@@ -352,15 +353,15 @@ class FlatAdam:
         gs, fi = f32(self._gs), f32(self._fi)
         import ctypes
         gw = (ctypes.c_void_p * max(1, len(guard_words)))(*[w.data_ptr() for w in guard_words]) if guard_words else None
-        _lib.check(L.mnrf_add_i64(self._step_dev.data_ptr(), 1, _lib.stream()), "mnrf_add_i64")
+        _lib.check(L.mnrf_adam_prep(self._hyper.data_ptr(), self._step_dev.data_ptr(), p(self._skipped[0]), p(gs), p(fi), gw,
+                                    len(guard_words), p(self._state_dev), _lib.stream()), "mnrf_adam_prep")
         for i, (m, fp) in enumerate(zip(self.modules, self.flats)):
             flat = D._flat_bucket(m)
             if flat is None:
                 flat, _copied = D._module_message(m)
             fp.grad = flat
             _lib.check(L.mnrf_adam_step_dev(p(fp.data), p(flat.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(),
-                                            self._hyper.data_ptr(), self._step_dev.data_ptr(), p(self._skipped[i]), p(gs), p(fi),
-                                            gw, len(guard_words), _lib.stream()), "mnrf_adam_step_dev")
+                                            p(self._state_dev), p(self._skipped[i]), _lib.stream()), "mnrf_adam_step_dev")
         self._gs = self._fi = None
 
     def state_dict(self):

@@ -92,7 +92,9 @@ def main():
         # scratch (9 reloads inside its streams since round 4; it was 161 while dL/dh8 was live through the colour branch, and that
         # cost 12 % of the kernel), the second-order kernel none
         (r"field_split_bwd_kernelILb1", dict(grad16, scratch_inside_max=12, scratch_total_max=40)),
-        (r"field_split_bwd2_kernelILb1", dict(grad16, scratch_inside_max=0, scratch_total_max=0)),
+        # round 5: with its plane stores woven into the GEMMs (6.13-6.18 against 6.26-6.30 ms per TotalLoss step) the store context
+        # costs the second-order kernel 3 reloads inside its streams (scratch operations only make the counted vmcnt waits stricter)
+        (r"field_split_bwd2_kernelILb1", dict(grad16, scratch_inside_max=6, scratch_total_max=100)),
         (r"field_split_bwd2?_kernel", grad16)])
     ok &= o and n2 >= 10
     # 32x32x16 tuning of the forward-only split kernels (same hand-placed scheme; two LDS-read waits per unit of 6 MFMAs)
