@@ -16,7 +16,8 @@
  *     read-write: its last 19 words are device state of the launches that use it (a
  *     {value, done} pair of the training backward's single-launch reductions, 16 counters
  *     of the field kernels' dynamic tile queue -- all zero between launches -- and the
- *     range-guard word below); mnrf_pack_weights zeroes them;
+ *     range-guard word below); mnrf_pack_weights zeroes them.  Hence `float* packed`, not const, in every entry
+ *     point that launches on an image: an image must not live in read-only or IPC-shared memory;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return value 0 = ok, negative = error (see mnrf_last_error()); nothing throws;
  *   - re-entrant; no global stream or global device state (host side: a cached CU count
@@ -119,7 +120,7 @@ int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* 
  * sample/spr (spr = 1 when every sample carries its own row, as in forward(x)).
  * Outputs may be null when not wanted: sigma (B), rgb (B,3), pred_normal (B,3),
  * is_mirror (B), normal (B,3), geo_feat (B,256). */
-int mnrf_field_forward(const float* packed, unsigned flags, int64_t B,
+int mnrf_field_forward(float* packed, unsigned flags, int64_t B,
                        const float* xyz, int64_t xyz_stride,
                        const float* rays, const float* z_vals, int spr,
                        const float* dir_emb, int64_t dir_stride,
@@ -224,7 +225,7 @@ int64_t mnrf_train_workspace_floats(int64_t B);
 
 /* mnrf_field_forward for training: all four heads (+ `normal` when non-null), and keeps in
  * save_x / save_mask / save_inv what mnrf_field_backward needs (no recomputation). */
-int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_forward_train(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                              const float* rays, const float* z_vals, int spr, const float* dir_emb,
                              int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                              float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
@@ -236,7 +237,7 @@ int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, i
  * The gradient flowing into `normal` (the normalised density gradient: a second-order term) is
  * handled by mnrf_field_backward2.
  * Autograd equivalent: loss.backward() through models/mirror_nerf.py:101-212. */
-int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                         const float* rays, const float* z_vals, int spr,
                         const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                         const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -256,7 +257,7 @@ int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_
  * ADDS to d_params (trunk weights and sigma.weight only) and to d_xyz (when non-null): call it after
  * mnrf_field_backward.  workspace: mnrf_train_workspace2_floats(B) floats. */
 int64_t mnrf_train_workspace2_floats(int64_t B);
-int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward2(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                          const float* rays, const float* z_vals, int spr, const float* g_normal,
                          const float* normal, const float* save_invj, const uint64_t* save_mask,
                          float* workspace, float* const* d_params, float* d_xyz, unsigned flags /* 0 or MNRF_SPLIT_F16 */, void* stream);
@@ -302,7 +303,7 @@ int mnrf_bench_gather(const void* table, int64_t table_bytes, int bytes_per_gath
  * noise_std = 0 (test_time), no density-gradient normal.  Null map pointers are skipped; weights (n_rays, 192) optional.
  * Returns MNRF_ERR_UNSUPPORTED when the 48-samples-per-wave tuning is off (MNRF_SPLIT48=0 / MNRF_SPLIT32=1). */
 int mnrf_fused_samples_per_ray(void);
-int mnrf_field_composite_fused(const float* packed, int64_t n_rays, const float* rays, const float* z_vals,
+int mnrf_field_composite_fused(float* packed, int64_t n_rays, const float* rays, const float* z_vals,
                                const float* dir_emb, int64_t dir_stride, int white_back,
                                float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
                                float* surf_normal, float* x_surface, void* stream);
@@ -322,7 +323,7 @@ int64_t mnrf_train_dy_planes_bytes(int64_t B);   /* dY planes of B samples (byte
  * (mnrf_train_dy_planes_bytes(B)) receives dY under one power-of-two scale for the whole call, derived from the largest seed
  * magnitude, whose float bits are left in *seedmax (a device word, overwritten) for mnrf_dw_planes.  A null upstream
  * gradient means zero (no tensor of zeros needed for a head no loss reads). */
-int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward_planes(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                const float* rays, const float* z_vals, int spr,
                                const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -351,7 +352,7 @@ int mnrf_dw_planes(int n_eval, const void* const* x_planes, const void* const* d
  * orders in ONE launch (the reference: one loss.backward() through utils/func.py:10-25 with create_graph=True). */
 int64_t mnrf_train_planes2_bytes(int64_t B);
 int64_t mnrf_train_dy_planes2_bytes(int64_t B);
-int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward2_planes(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                 const float* rays, const float* z_vals, int spr, const float* g_normal,
                                 const float* normal, const float* save_invj, const uint64_t* save_mask,
                                 void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream);
@@ -419,19 +420,19 @@ int mnrf_blend_backward_n(const float* g_out, const float* mask, const int32_t* 
                           float* g_base, float* g_sec, const int32_t* n_sec_live, const int32_t* n_live, void* stream);
 int mnrf_ray_grads_n(const float* d_xyz, const float* z_vals, const float* d_dir, int64_t n_rays, int spr, float* g_rays,
                      float* g_de, const int32_t* n_live, void* stream);
-int mnrf_field_forward_train_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_forward_train_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
                                float* save_inv, float* save_invj, unsigned flags, const int32_t* n_live, void* stream);
-int mnrf_field_backward_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward_planes_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                  const float* rays, const float* z_vals, int spr,
                                  const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                  const float* g_is_mirror, const float* rgb, const float* pred_normal,
                                  const float* is_mirror, const uint64_t* save_mask, const float* save_inv,
                                  void* dy_planes, uint32_t* seedmax, float* d_xyz, float* d_dir, const float* keep_mirror,
                                  unsigned flags, const int32_t* n_live, void* stream);
-int mnrf_field_backward2_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+int mnrf_field_backward2_planes_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                   const float* rays, const float* z_vals, int spr, const float* g_normal,
                                   const float* normal, const float* save_invj, const uint64_t* save_mask,
                                   void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz,

@@ -150,7 +150,7 @@ extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void
     return mnrf_check_launch("mnrf_pack_weights");
 }
 
-extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B, const float* xyz,
+extern "C" int mnrf_field_forward(float* packed, unsigned flags, int64_t B, const float* xyz,
                                   int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
                                   const float* dir_emb, int64_t dir_stride, float* sigma, float* rgb,
                                   float* pred_normal, float* is_mirror, float* normal, float* geo_feat,
@@ -189,7 +189,7 @@ extern "C" int mnrf_field_forward(const float* packed, unsigned flags, int64_t B
 // ---------------------------------------------------------------------- ray-fused fine pass (eval, maps only)
 extern "C" int mnrf_fused_samples_per_ray(void) { return split48_ray_samples(); }
 
-extern "C" int mnrf_field_composite_fused(const float* packed, int64_t n_rays, const float* rays, const float* z_vals,
+extern "C" int mnrf_field_composite_fused(float* packed, int64_t n_rays, const float* rays, const float* z_vals,
                                           const float* dir_emb, int64_t dir_stride, int white_back,
                                           float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
                                           float* surf_normal, float* x_surface, void* stream) {
@@ -221,7 +221,7 @@ extern "C" int64_t mnrf_train_workspace_floats(int64_t B) { return (int64_t)DY_F
 static void* g_exp_marks = nullptr;
 extern "C" void mnrf_exp_set_marks(void* p) { g_exp_marks = p; }
 #endif
-static int field_forward_train_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+static int field_forward_train_impl(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                     const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                     int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                     float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
@@ -252,7 +252,7 @@ static int field_forward_train_impl(const float* packed, int64_t B, const float*
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_forward_train: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_forward_train");
 }
-extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_forward_train(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                         const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                         int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                         float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
@@ -260,7 +260,7 @@ extern "C" int mnrf_field_forward_train(const float* packed, int64_t B, const fl
     return field_forward_train_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, dir_emb, dir_stride, sigma, rgb, pred_normal, is_mirror,
                                     normal, save_x, save_mask, save_inv, save_invj, flags, nullptr, stream);
 }
-extern "C" int mnrf_field_forward_train_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_forward_train_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                           const float* rays, const float* z_vals, int spr, const float* dir_emb,
                                           int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
                                           float* is_mirror, float* normal, float* save_x, uint64_t* save_mask,
@@ -269,7 +269,7 @@ extern "C" int mnrf_field_forward_train_n(const float* packed, int64_t B, const 
                                     normal, save_x, save_mask, save_inv, save_invj, flags, n_live, stream);
 }
 
-extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                    const float* rays, const float* z_vals, int spr,
                                    const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                    const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -304,7 +304,7 @@ extern "C" int mnrf_field_backward(const float* packed, int64_t B, const float* 
 extern "C" int64_t mnrf_train_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLX_SB_BYTES; }
 extern "C" int64_t mnrf_train_dy_planes_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PLY_SB_BYTES; }
 
-static int field_backward_planes_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+static int field_backward_planes_impl(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                       const float* rays, const float* z_vals, int spr,
                                       const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                       const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -319,7 +319,7 @@ static int field_backward_planes_impl(const float* packed, int64_t B, const floa
     hipStream_t s = (hipStream_t)stream;
     if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: bad spr");
     launch_seed_max(g_sigma, g_rgb, g_pred_normal, g_is_mirror, rgb, pred_normal, is_mirror, save_inv, (long long)B, seedmax, s, n_live, spr,
-                    (unsigned*)(const_cast<float*>(packed) + OFF_REDUCE_PAIR));
+                    (unsigned*)(packed + OFF_REDUCE_PAIR));
     FieldBwdArgs A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_sigma, g_rgb, g_pred_normal,
                    g_is_mirror, rgb, pred_normal, is_mirror, (const unsigned long long*)save_mask, save_inv, nullptr, d_xyz, d_dir,
                    flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
@@ -329,7 +329,7 @@ static int field_backward_planes_impl(const float* packed, int64_t B, const floa
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_backward_planes");
 }
-extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward_planes(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                           const float* rays, const float* z_vals, int spr,
                                           const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                           const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -340,7 +340,7 @@ extern "C" int mnrf_field_backward_planes(const float* packed, int64_t B, const 
                                       pred_normal, is_mirror, save_mask, save_inv, dy_planes, seedmax, d_xyz, d_dir, keep_mirror, flags,
                                       nullptr, stream);
 }
-extern "C" int mnrf_field_backward_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward_planes_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                             const float* rays, const float* z_vals, int spr,
                                             const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
                                             const float* g_is_mirror, const float* rgb, const float* pred_normal,
@@ -415,7 +415,7 @@ extern "C" int mnrf_dw_planes2_n(int n_eval, const void* const* x_planes, const 
 extern "C" int64_t mnrf_train_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2X_SB_BYTES; }
 extern "C" int64_t mnrf_train_dy_planes2_bytes(int64_t B) { return B <= 0 ? 0 : dwp_sample_blocks(B) * PL2Y_SB_BYTES; }
 
-static int field_backward2_planes_impl(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+static int field_backward2_planes_impl(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                        const float* rays, const float* z_vals, int spr, const float* g_normal,
                                        const float* normal, const float* save_invj, const uint64_t* save_mask,
                                        void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, const int32_t* n_live,
@@ -426,7 +426,7 @@ static int field_backward2_planes_impl(const float* packed, int64_t B, const flo
     if (!xyz && (!rays || !z_vals)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: need xyz or rays+z_vals");
     hipStream_t s = (hipStream_t)stream;
     if (spr < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: bad spr");
-    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s, n_live, spr, (unsigned*)(const_cast<float*>(packed) + OFF_REDUCE_PAIR));
+    launch_jhat_max(g_normal, normal, save_invj, (long long)B, jmax, s, n_live, spr, (unsigned*)(packed + OFF_REDUCE_PAIR));
     FieldBwd2Args A{packed, (long long)B, xyz, (long long)xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj,
                     (const unsigned long long*)save_mask, nullptr, d_xyz, (char*)x2_planes, (char*)y2_planes, jmax};
     A.n_live = n_live;
@@ -434,14 +434,14 @@ static int field_backward2_planes_impl(const float* packed, int64_t B, const flo
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward2_planes: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_backward2_planes");
 }
-extern "C" int mnrf_field_backward2_planes(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward2_planes(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                            const float* rays, const float* z_vals, int spr, const float* g_normal,
                                            const float* normal, const float* save_invj, const uint64_t* save_mask,
                                            void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz, void* stream) {
     return field_backward2_planes_impl(packed, B, xyz, xyz_stride, rays, z_vals, spr, g_normal, normal, save_invj, save_mask, x2_planes,
                                        y2_planes, jmax, d_xyz, nullptr, stream);
 }
-extern "C" int mnrf_field_backward2_planes_n(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward2_planes_n(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                              const float* rays, const float* z_vals, int spr, const float* g_normal,
                                              const float* normal, const float* save_invj, const uint64_t* save_mask,
                                              void* x2_planes, void* y2_planes, uint32_t* jmax, float* d_xyz,
@@ -452,7 +452,7 @@ extern "C" int mnrf_field_backward2_planes_n(const float* packed, int64_t B, con
 
 extern "C" int64_t mnrf_train_workspace2_floats(int64_t B) { return (int64_t)SO_FLOATS * B + dw2_workspace_floats(B); }
 
-extern "C" int mnrf_field_backward2(const float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
+extern "C" int mnrf_field_backward2(float* packed, int64_t B, const float* xyz, int64_t xyz_stride,
                                     const float* rays, const float* z_vals, int spr, const float* g_normal,
                                     const float* normal, const float* save_invj, const uint64_t* save_mask,
                                     float* workspace, float* const* d_params, float* d_xyz, unsigned flags, void* stream) {

@@ -35,6 +35,7 @@ def color_mask_loss_torch(res, target, gt_mask):
 
 
 _COLOR_MASK = []
+_COLOR_MASK_RAYS = {}      # (n, device) -> the (n, 8) zero tensor the fused loss takes as `rays` (read by the absent normal terms only)
 
 
 def color_mask_loss(res, target, gt_mask):
@@ -45,12 +46,11 @@ def color_mask_loss(res, target, gt_mask):
         from .losses import get_loss
         _COLOR_MASK.append(get_loss(SimpleNamespace()))
     inputs = {k: res[k] for k in ("rgb_coarse", "rgb_fine", "mirror_mask_coarse", "mirror_mask_fine") if k in res}
-    n = target.shape[0]
-    if len(_COLOR_MASK) < 2 or _COLOR_MASK[1].shape[0] != n or _COLOR_MASK[1].device != target.device:
-        del _COLOR_MASK[1:]
-        _COLOR_MASK.append(torch.zeros(n, 8, device=target.device))      # (`rays` is only read by the normal terms, which are absent)
-    return _COLOR_MASK[0](inputs, {"rgbs": target, "mirror_mask": gt_mask, "rays": _COLOR_MASK[1]}, train_geometry_stage=False,
-                          epoch=5)[0]
+    key = (target.shape[0], str(target.device))
+    zr = _COLOR_MASK_RAYS.get(key)
+    if zr is None:
+        zr = _COLOR_MASK_RAYS[key] = torch.zeros(target.shape[0], 8, device=target.device)
+    return _COLOR_MASK[0](inputs, {"rgbs": target, "mirror_mask": gt_mask, "rays": zr}, train_geometry_stage=False, epoch=5)[0]
 
 
 def total_loss_fn(hparams=None, epoch=5):
@@ -252,7 +252,9 @@ class FlatAdam:
     copied.  The update is torch.optim.Adam's (same arithmetic, same `found_inf` contract: train_step's range guard) from
     `mnrf_adam_step`, one thread per four elements: torch's fused multi-tensor kernel deals 65 536-element chunks to blocks, TEN
     blocks for a model, 46 us per model and step against 6 (round 4).  `kernel=False` (or MNRF_FLAT_ADAM_KERNEL=0) keeps torch's
-    fused Adam over the flat tensors.  Build it AFTER moving the models to their device."""
+    fused Adam over the flat tensors.  Build it AFTER moving the models to their device (step() raises when a parameter no longer
+    aliases its flat tensor).  Not a torch.optim.Optimizer: lr_scheduler constructors reject it -- schedule by writing
+    `param_groups[0]["lr"]` (read at every step; GraphedTrainStep copies it to the device between replays)."""
 
     def __init__(self, modules, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, kernel=None):
         from .weights import param_refs
@@ -300,9 +302,31 @@ class FlatAdam:
             for q in params_of(m):
                 q.grad = None
 
+    def _check_aliasing(self):
+        """The parameters must still BE views of the flat tensors: `system.to()`, `.float()`, `load_state_dict(assign=True)` replace a
+        parameter's storage, and step() would then update an orphaned flat tensor while training stood still without any error
+        (ADVICE r4).  Checked on the first and last parameter of every module, two pointer compares per step."""
+        from .weights import param_refs
+        # (every parameter on the first call and every 16th, the first and the last one -- what a move or a cast changes -- always)
+        n_chk = self.__dict__["_alias_checks"] = self.__dict__.get("_alias_checks", 0) + 1
+        for m, fp in zip(self.modules, self.flats):
+            lay, _total = D._field_layout(m)
+            refs = param_refs(m)
+            for sub, pn, full in (refs if n_chk % 16 == 1 else (refs[0], refs[-1])):
+                q = sub._parameters[pn]
+                if q.data_ptr() != fp.data_ptr() + 4 * lay[full][0]:
+                    raise RuntimeError(f"FlatAdam: parameter {full} no longer aliases its flat tensor (the module was moved, cast or "
+                                       "re-assigned after the optimizer was built): build FlatAdam again")
+
     def step(self):
+        self._check_aliasing()
+        from .weights import params_of
         grads = []
         for m, fp in zip(self.modules, self.flats):
+            if all(q.grad is None for q in params_of(m)):
+                grads.append(None)                   # no backward pass reached this module: torch.optim.Adam skips such parameters
+                fp.grad = None                       # (an update from a zero gradient would still move them by momentum)
+                continue
             flat = D._flat_bucket(m)                 # the backward pass's buffer when every .grad still is a view of it ...
             if flat is None:
                 flat, _copied = D._module_message(m)   # ... else a flat copy in the same layout (zeros where there is no gradient)
@@ -318,6 +342,8 @@ class FlatAdam:
         f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1)  # noqa: E731
         gs, fi = f32(self._gs), f32(self._fi)
         for i, (fp, g) in enumerate(zip(self.flats, grads)):
+            if g is None:
+                continue
             grp = self.param_groups[0]
             _lib.check(L.mnrf_adam_step(p(fp.data), p(g.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(), float(grp["lr"]),
                                         float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
@@ -348,6 +374,7 @@ class FlatAdam:
         """step() with every scalar read from device memory: capturable; the host's call count is NOT advanced (replays do not
         pass through here): GraphedTrainStep keeps it in step with the device count."""
         from . import _lib
+        self._check_aliasing()
         L, p = _lib.lib(), _lib.ptr
         f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1)  # noqa: E731
         gs, fi = f32(self._gs), f32(self._fi)

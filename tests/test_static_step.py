@@ -241,3 +241,25 @@ def test_device_made_gemm_plan_gives_the_host_plan_gradients():
     _cmp_grads(got, ref, 2e-5)
     none = run(torch.tensor([0], dtype=torch.int32, device=DEV), N)
     assert all(float(g.abs().max()) == 0.0 for g in none)
+
+
+def test_flat_adam_refuses_orphaned_parameters_and_skips_modules_without_gradients():
+    """FlatAdam re-points every parameter at a view of its flat tensor.  A parameter whose storage is replaced later
+    (`.to()`, `.float()`, load_state_dict(assign=True)) would leave step() updating an orphaned tensor: step() raises instead.  A
+    module no backward pass reached is skipped like torch.optim.Adam skips parameters without .grad (no momentum-only update)."""
+    from mirror_nerf_amd import training as T
+    a = _system(perturb=0.0, noise_std=0.0)
+    opt = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    rays, target, gt = _batch(n=64)
+    T.train_step(a, opt, rays, target, gt)                      # builds momentum
+    torch.cuda.synchronize()
+    w = [fp.detach().clone() for fp in opt.flats]
+    m = [t.clone() for t in opt._m]
+    opt.zero_grad()
+    opt.step()                                                   # no gradients anywhere: nothing moves, the moments do not decay
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, fp.detach()) for x, fp in zip(w, opt.flats)) and all(torch.equal(x, y) for x, y in zip(m, opt._m))
+    q = a.nerf_fine.is_mirror_net[2].bias
+    q.data = q.data.clone()                                      # what a cast / move / re-assignment does to the aliasing
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        opt.step()
