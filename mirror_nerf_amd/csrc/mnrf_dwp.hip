@@ -589,8 +589,10 @@ void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
                      const int* n_live, int spr, unsigned* pair) {
     if (!pair) zero_fill(s, out, sizeof(unsigned));
-    long long blocks = (B + 255) / 256;         // one sample per thread up to 2048 workgroups (it was four: 12 us per launch, latency-bound)
-    if (blocks > 2048) blocks = 2048;
+    // four samples per thread, at most 256 workgroups: every workgroup ends in two same-address atomics (the maximum and the ticket
+    // of grid_max_tail), which serialise at ~10 ns each -- 2048 workgroups measured 31 us per launch against 12.6 with 128
+    long long blocks = (B + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
                        save_inv, B, out, n_live, spr, pair);
 }
@@ -623,8 +625,8 @@ __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float*
 void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
                      const int* n_live, int spr, unsigned* pair) {
     if (!pair) zero_fill(s, out, sizeof(unsigned));
-    long long blocks = (B + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    long long blocks = (B + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out, n_live, spr, pair);
 }
 
