@@ -577,9 +577,30 @@ __device__ __forceinline__ void encode_level_p(const float* table, const LevelP&
 // encoding) the 4 MB L2 of an XCD sees 48 MB of table at once, misses on 54 % of the lines and the kernel streams 20.7 GB per
 // 6.29 M samples over the fabric (3.2x the 1 KiB of table entries a sample needs, at 7.5 TB/s: profiles/r04b_pmc_tcnn).
 // Level by level the working set is one level.  Costs 128 B per sample written and read once (the planes).
+// Thread -> sample map of a workgroup (ray mode).  ENC_PATCH_RAYS = 1: 256 consecutive samples of the flat (ray-major) order -- one or
+// two rays, 256 depths.  ENC_PATCH_RAYS = R > 1: a PATCH of R consecutive rays x 256 / R consecutive depths: neighbouring rays of a
+// chunk are neighbouring pixels, whose samples at equal depth share grid cells up to the middle levels, so the lanes of a wave
+// instruction fall on fewer distinct cache lines (the launch is bound by the vector L1's requests to the L2, not by bytes: 4.3).
+// Measured on one 32768-ray chunk of the bench frame, fine pass (scripts/exp_tcnn_encode.py, alternating libraries, identical
+// outputs): 1.68 ms per launch flat, 1.55 with 4 rays x 64 depths, 1.32 with 8 x 32, 1.28 with 16 x 16, **1.27 with 32 x 8** (a wave = 8
+// rays x 8 depths), 1.45 with 64 x 4.  Falls back to the flat map when the shape does not tile (spr % 8, rays % 32) or with xyz input.
+#ifndef MNRF_EXP_ENC_PATCH_RAYS
+#define MNRF_EXP_ENC_PATCH_RAYS 32
+#endif
+constexpr int ENC_PATCH_RAYS = MNRF_EXP_ENC_PATCH_RAYS;
 __global__ __launch_bounds__(256) void tcnn_encode_kernel(TcnnArgs A) {
     const int lv = blockIdx.y;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (ENC_PATCH_RAYS > 1 && !A.xyz && A.spr % (256 / ENC_PATCH_RAYS) == 0 && (A.B / A.spr) % ENC_PATCH_RAYS == 0) {
+        constexpr int PS = 256 / ENC_PATCH_RAYS;                  // depths per patch
+        const int groups = A.spr / PS;                            // patches along a ray
+        const long long patch = blockIdx.x;
+        const long long ray0 = patch / groups * ENC_PATCH_RAYS;
+        const int s0 = (int)(patch % groups) * PS;
+        // lanes: depth fastest within PS, then ray -- a wave of 64 covers 64 / PS rays x PS depths (PS < 64) or one ray (PS >= 64)
+        const int r = threadIdx.x / PS, sidx = threadIdx.x % PS;
+        i = (ray0 + r) * A.spr + s0 + sidx;
+    }
     if (i >= A.B) return;
     LevelP L{0.f, 0u, 0u, 0u, true};
 #pragma unroll
