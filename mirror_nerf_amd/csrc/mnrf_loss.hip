@@ -293,18 +293,32 @@ struct FinishArgs {
     float* out;
 };
 
-__global__ void finish_kernel(FinishArgs F) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One workgroup, a FIXED summation order (thread t sums entries t, t + 256, ...; then a fixed tree over the 256 partial sums): the
+// same bits run to run.  (It was one thread walking ~800 partials one dependent load after the other: 37 us per TotalLoss step.)
+__device__ __forceinline__ float fixed_sum(const float* p, int n, int stride, int off, float* sh) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < n; b += TPB) v += p[b * stride + off];
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+__global__ __launch_bounds__(TPB) void finish_kernel(FinishArgs F) {
+    __shared__ float sh[TPB];
     float t[N_TERMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < F.ray_blocks; ++b) {
-        t[T_COLOR] += F.ray_partials[b * 3 + 0];
-        t[T_MASK] += F.ray_partials[b * 3 + 1];
-        t[T_NORMAL] += F.ray_partials[b * 3 + 2];
-    }
+    t[T_COLOR] = fixed_sum(F.ray_partials, F.ray_blocks, 3, 0, sh);
+    t[T_MASK] = fixed_sum(F.ray_partials, F.ray_blocks, 3, 1, sh);
+    t[T_NORMAL] = fixed_sum(F.ray_partials, F.ray_blocks, 3, 2, sh);
     for (int typ = 0; typ < 2; ++typ) {
-        for (int b = 0; b < F.reg_blocks[typ]; ++b) t[T_REG] += F.reg_partials[typ][b];
-        for (int b = 0; b < F.plane_blocks[typ]; ++b) t[T_PLANE] += F.plane_partials[typ][b];
+        if (F.reg_blocks[typ] > 0) t[T_REG] += fixed_sum(F.reg_partials[typ], F.reg_blocks[typ], 1, 0, sh);
+        if (F.plane_blocks[typ] > 0) t[T_PLANE] += fixed_sum(F.plane_partials[typ], F.plane_blocks[typ], 1, 0, sh);
     }
+    if (threadIdx.x != 0) return;
     // TotalLoss.forward: sum(list(loss_dict.values())) in insertion order, absent terms skipped (losses.py:226-253)
     const bool use[N_TERMS] = {true, (F.flags & MNRF_LOSS_USE_MASK) != 0, (F.flags & MNRF_LOSS_USE_PLANE) != 0,
                                (F.flags & MNRF_LOSS_USE_NORMAL) != 0, (F.flags & MNRF_LOSS_USE_NORMAL) != 0};
@@ -421,7 +435,7 @@ extern "C" int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void*
     F.w[T_COLOR] = A.w_color; F.w[T_MASK] = A.w_mask; F.w[T_PLANE] = A.w_plane; F.w[T_NORMAL] = A.w_normal; F.w[T_REG] = A.w_normal_reg;
     F.flags = A.flags;
     F.out = A.out;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, s, F);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(TPB), 0, s, F);
     return mnrf_check_launch("mnrf_total_loss");
 }
 
