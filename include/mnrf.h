@@ -408,7 +408,18 @@ int mnrf_threshold_mask_n(float* mask, int64_t n, int32_t* any, const int32_t* n
 int mnrf_reflect_compact_n(const float* rays, const float* x_surface, const float* normal,
                            const float* normal_noise, float noise_std, const float* mask,
                            int64_t n_rays, int compact, float near2, float* sec_rays, int32_t* index,
-                           int32_t* count, float* reflect_dir, const int32_t* n_live, void* stream);
+                           int32_t* count, float* reflect_dir, const int32_t* n_live,
+                           int32_t* slot /* (n_rays) or null: the inverse of `index` -- the row of sec_rays ray i went to, -1 where it
+                                            was not selected: what the gather-form blend below reads */,
+                           void* stream);
+/* Both blends of a recursion level (rgb_coarse and rgb_fine, train.py:263-296) in one launch, gather form through `slot`:
+ * out = m * part + (1 - m) * base, part = sec[slot[i]] where ray i was reflected and base[i] where not -- mnrf_blend_scatter's
+ * expressions, bit-identical values.  Tensor b (or a) may be null.  Backward: g_base = (1 - m) g_out for every live row, g_sec[slot[i]]
+ * = m g_out where slot[i] >= 0 (rows of g_sec past the reflection's count are not written). */
+int mnrf_blend2_n(const float* base_a, const float* sec_a, const float* base_b, const float* sec_b, const int32_t* slot,
+                  const float* mask, int64_t n, int c, float* out_a, float* out_b, const int32_t* n_live, void* stream);
+int mnrf_blend2_backward_n(const float* g_out_a, const float* g_out_b, const int32_t* slot, const float* mask, int64_t n, int c,
+                           float* g_base_a, float* g_sec_a, float* g_base_b, float* g_sec_b, const int32_t* n_live, void* stream);
 /* n_sec_live: live rows of sec / index / g_sec (the reflection's count); n_live: live rows of base / mask / out */
 int mnrf_blend_scatter_n(const float* base, const float* sec, const int32_t* index, int64_t n_sec,
                          const float* mask, int64_t n, int c, float* out, float* reflect_out,

@@ -120,7 +120,9 @@ SIGNATURES = {
     "mnrf_composite_backward_n": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_int, _c_f, _c_i, _str]),
     "mnrf_sample_fine_n": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _c_i, _str]),
     "mnrf_threshold_mask_n": (_int, [_c_f, _i64, _c_i, _c_i, _str]),
-    "mnrf_reflect_compact_n": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i, _c_i, _c_f, _c_i, _str]),
+    "mnrf_reflect_compact_n": (_int, [_c_f, _c_f, _c_f, _c_f, _flt, _c_f, _i64, _int, _flt, _c_f, _c_i, _c_i, _c_f, _c_i, _c_i, _str]),
+    "mnrf_blend2_n": (_int, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _i64, _int, _c_f, _c_f, _c_i, _str]),
+    "mnrf_blend2_backward_n": (_int, [_c_f, _c_f, _c_i, _c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_blend_scatter_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),
     "mnrf_reflect_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_blend_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),

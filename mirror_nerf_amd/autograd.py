@@ -419,13 +419,16 @@ class ReflectFn(torch.autograd.Function):
         index = torch.empty(N, dtype=torch.int32, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)      # (always written by the kernel)
         rdir = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        slot = torch.empty(N, dtype=torch.int32, device=dev) if static else None      # inverse of `index` (the gather-form blend)
         p = _lib.ptr
         _lib.check(_lib.lib().mnrf_reflect_compact_n(
             p(rays), p(x_surface), p(normal), None, 0.0, p(_c(mask.float())) if mask is not None else None, N,
-            int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), p(n_live), _lib.stream()), "mnrf_reflect_compact")
+            int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), p(n_live), p(slot), _lib.stream()), "mnrf_reflect_compact")
         ctx.static = bool(static)
         if static:
             ctx.count = count
+            ctx.slot = slot      # (not an autograd output: recursion._static_level picks it up from the count tensor)
+            count._mnrf_slot = slot
         else:
             M = int(count.item()) if compact else N     # the one host sync per level (train.py:175 does the same)
             sec, index = sec[:M].contiguous(), index[:M].contiguous()
@@ -449,6 +452,51 @@ class ReflectFn(torch.autograd.Function):
             p(rays), p(normal), p(index) if ctx.compact else None, M, p(g_sec.contiguous().float()), N, p(g_xs), p(g_n),
             p(g_rays), p(ctx.count), _lib.stream()), "mnrf_reflect_backward")
         return g_rays, g_xs, g_n, None, None, None, None
+
+
+class Blend2Fn(torch.autograd.Function):
+    """Both blends of a recursion level (rgb_coarse and rgb_fine, train.py:263-296) as ONE launch forward and ONE backward
+    (mnrf_blend2_n / mnrf_blend2_backward_n, gather form through the compaction's inverse index `slot`): the static training route's
+    blend.  apply(base_a, sec_a, base_b, sec_b, slot, mask, detach_sec, n_live) -> (out_a, out_b); tensor b may be None."""
+
+    @staticmethod
+    def forward(ctx, base_a, sec_a, base_b, sec_b, slot, mask, detach_sec=False, n_live=None):
+        base_a, sec_a, mask = _c(base_a.float()), _c(sec_a.float()), _c(mask.float())
+        base_b = None if base_b is None else _c(base_b.float())
+        sec_b = None if sec_b is None else _c(sec_b.float())
+        N = base_a.shape[0]
+        c = base_a.shape[1] if base_a.dim() == 2 else 1
+        out_a = torch.empty_like(base_a)
+        out_b = None if base_b is None else torch.empty_like(base_b)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mnrf_blend2_n(p(base_a), p(sec_a), p(base_b), p(sec_b), p(slot), p(mask), N, c, p(out_a), p(out_b), p(n_live),
+                                            _lib.stream()), "mnrf_blend2_n")
+        ctx.save_for_backward(mask, slot)
+        ctx.c, ctx.detach_sec, ctx.n_live = c, bool(detach_sec), n_live
+        ctx.sec_shapes = (tuple(sec_a.shape), None if sec_b is None else tuple(sec_b.shape))
+        ctx.set_materialize_grads(False)
+        if out_b is None:
+            out_b = torch.empty(0, device=base_a.device)
+            ctx.mark_non_differentiable(out_b)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        mask, slot = ctx.saved_tensors
+        N = mask.shape[0]
+        dev = mask.device
+        g_a = None if g_a is None else g_a.contiguous().float()
+        g_b = None if (g_b is None or ctx.sec_shapes[1] is None) else g_b.contiguous().float()
+        gb_a = None if g_a is None else torch.empty_like(g_a)
+        gb_b = None if g_b is None else torch.empty_like(g_b)
+        want_sec = not ctx.detach_sec
+        gs_a = torch.empty(ctx.sec_shapes[0], dtype=torch.float32, device=dev) if (want_sec and g_a is not None) else None
+        gs_b = torch.empty(ctx.sec_shapes[1], dtype=torch.float32, device=dev) if (want_sec and g_b is not None) else None
+        p = _lib.ptr
+        if g_a is not None or g_b is not None:
+            _lib.check(_lib.lib().mnrf_blend2_backward_n(p(g_a), p(g_b), p(slot), p(mask), N, ctx.c, p(gb_a), p(gs_a), p(gb_b), p(gs_b),
+                                                         p(ctx.n_live), _lib.stream()), "mnrf_blend2_backward_n")
+        return gb_a, gs_a, gb_b, gs_b, None, None, None, None
 
 
 class BlendFn(torch.autograd.Function):

@@ -407,6 +407,7 @@ struct ReflArgs {
     const float* mask; long long n; int compact; float near2;
     float* sec; int* index; int* count; float* reflect_dir;
     const int* n_live;
+    int* slot;      // (n) or null: row of sec that ray i went to, -1 for a ray that was not selected (the inverse of `index`)
 };
 
 __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
@@ -455,6 +456,9 @@ __global__ __launch_bounds__(1024) void reflect_compact_kernel(ReflArgs A) {
             o[6] = A.near2;                    // ray_forward_offset, absolute (train.py:232, eval.py:529)
             o[7] = A.rays[i * 8 + 7];
             A.index[p] = (int)i;
+            if (A.slot) A.slot[i] = (int)p;
+        } else if (in && A.slot) {
+            A.slot[i] = -1;
         }
         __syncthreads();
         if (tid == 0) s_base = base + tot;
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(256) void reflect_all_kernel(ReflArgs A) {
     o[6] = A.near2;
     o[7] = A.rays[i * 8 + 7];
     A.index[i] = (int)i;
+    if (A.slot) A.slot[i] = (int)i;
 }
 
 // ------------------------------------------------------------------ blend / scatter
@@ -519,6 +524,52 @@ __global__ void blend_scatter_kernel(const float* __restrict__ base, const float
     const float v = sec[j];
     out[row * c + ch] = m * v + (1.f - m) * base[row * c + ch];
     if (refl) refl[row * c + ch] = v;
+}
+
+// Both blends of a level (rgb_coarse and rgb_fine, train.py:263-296) in ONE launch, in gather form through `slot` (the inverse of the
+// compaction's index): out = m * part + (1 - m) * base with part = sec[slot] where the ray was reflected, base where it was not -- the
+// very expressions of blend_all_kernel / blend_scatter_kernel, so the values are identical bit for bit.  (Round 5: the scatter form
+// took two launches per tensor and two more backward.)
+__global__ void blend2_kernel(const float* __restrict__ base_a, const float* __restrict__ sec_a, const float* __restrict__ base_b,
+                              const float* __restrict__ sec_b, const int* __restrict__ slot, const float* __restrict__ mask, long long n,
+                              int c, float* __restrict__ out_a, float* __restrict__ out_b, const int* __restrict__ n_live) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= live_rows(n, n_live) * c) return;
+    const long long row = i / c;
+    const int ch = (int)(i % c);
+    const float m = mask[row];
+    const int sl = slot[row];
+    if (base_a) {
+        const float b = base_a[i];
+        const float part = sl >= 0 ? sec_a[(long long)sl * c + ch] : b;
+        out_a[i] = m * part + (1.f - m) * b;
+    }
+    if (base_b) {
+        const float b = base_b[i];
+        const float part = sl >= 0 ? sec_b[(long long)sl * c + ch] : b;
+        out_b[i] = m * part + (1.f - m) * b;
+    }
+}
+__global__ void blend2_backward_kernel(const float* __restrict__ g_out_a, const float* __restrict__ g_out_b, const int* __restrict__ slot,
+                                       const float* __restrict__ mask, long long n, int c, float* __restrict__ g_base_a,
+                                       float* __restrict__ g_sec_a, float* __restrict__ g_base_b, float* __restrict__ g_sec_b,
+                                       const int* __restrict__ n_live) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= live_rows(n, n_live) * c) return;
+    const long long row = i / c;
+    const int ch = (int)(i % c);
+    const float m = mask[row];
+    const int sl = slot[row];
+    if (g_out_a) {
+        const float g = g_out_a[i];
+        if (g_base_a) g_base_a[i] = (1.f - m) * g;
+        if (g_sec_a && sl >= 0) g_sec_a[(long long)sl * c + ch] = m * g;
+    }
+    if (g_out_b) {
+        const float g = g_out_b[i];
+        if (g_base_b) g_base_b[i] = (1.f - m) * g;
+        if (g_sec_b && sl >= 0) g_sec_b[(long long)sl * c + ch] = m * g;
+    }
 }
 
 // ------------------------------------------------------------------ pin-hole rays
@@ -782,14 +833,14 @@ extern "C" int mnrf_threshold_mask_n(float* mask, int64_t n, int32_t* any, const
 static int reflect_compact_impl(const float* rays, const float* x_surface, const float* normal,
                                 const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
                                 int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
-                                float* reflect_dir, const int32_t* n_live, void* stream) {
+                                float* reflect_dir, const int32_t* n_live, int32_t* slot, void* stream) {
     if (n_rays < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: bad size");
     if (!count) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: count is null");
     if (n_rays > 0 && (!rays || !x_surface || !normal || !sec_rays || !index))
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: null pointer");
     if (compact && n_rays > 0 && !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_compact: compaction needs the mask");
     ReflArgs A{rays, x_surface, normal, normal_noise, noise_std, mask, (long long)n_rays, compact, near2,
-               sec_rays, index, count, reflect_dir, n_live};
+               sec_rays, index, count, reflect_dir, n_live, slot};
     if (!compact && n_rays > 0)
         hipLaunchKernelGGL(reflect_all_kernel, dim3(blocks_for(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, A);
     else
@@ -801,14 +852,34 @@ extern "C" int mnrf_reflect_compact(const float* rays, const float* x_surface, c
                                     int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
                                     float* reflect_dir, void* stream) {
     return reflect_compact_impl(rays, x_surface, normal, normal_noise, noise_std, mask, n_rays, compact, near2, sec_rays, index, count,
-                                reflect_dir, nullptr, stream);
+                                reflect_dir, nullptr, nullptr, stream);
 }
 extern "C" int mnrf_reflect_compact_n(const float* rays, const float* x_surface, const float* normal,
                                       const float* normal_noise, float noise_std, const float* mask, int64_t n_rays,
                                       int compact, float near2, float* sec_rays, int32_t* index, int32_t* count,
-                                      float* reflect_dir, const int32_t* n_live, void* stream) {
+                                      float* reflect_dir, const int32_t* n_live, int32_t* slot, void* stream) {
     return reflect_compact_impl(rays, x_surface, normal, normal_noise, noise_std, mask, n_rays, compact, near2, sec_rays, index, count,
-                                reflect_dir, n_live, stream);
+                                reflect_dir, n_live, slot, stream);
+}
+
+extern "C" int mnrf_blend2_n(const float* base_a, const float* sec_a, const float* base_b, const float* sec_b, const int32_t* slot,
+                             const float* mask, int64_t n, int c, float* out_a, float* out_b, const int32_t* n_live, void* stream) {
+    if (n < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend2_n: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!slot || !mask || (!base_a && !base_b)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend2_n: null pointer");
+    if ((base_a && (!sec_a || !out_a)) || (base_b && (!sec_b || !out_b))) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend2_n: a tensor needs base, sec and out");
+    hipLaunchKernelGGL(blend2_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, base_a, sec_a, base_b, sec_b, slot, mask,
+                       (long long)n, c, out_a, out_b, n_live);
+    return mnrf_check_launch("mnrf_blend2_n");
+}
+extern "C" int mnrf_blend2_backward_n(const float* g_out_a, const float* g_out_b, const int32_t* slot, const float* mask, int64_t n, int c,
+                                      float* g_base_a, float* g_sec_a, float* g_base_b, float* g_sec_b, const int32_t* n_live, void* stream) {
+    if (n < 0 || c < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend2_backward_n: bad size");
+    if (n == 0) return MNRF_OK;
+    if (!slot || !mask) return mnrf_fail(MNRF_ERR_ARG, "mnrf_blend2_backward_n: null pointer");
+    hipLaunchKernelGGL(blend2_backward_kernel, dim3(blocks_for(n * c, 256)), dim3(256), 0, (hipStream_t)stream, g_out_a, g_out_b, slot, mask,
+                       (long long)n, c, g_base_a, g_sec_a, g_base_b, g_sec_b, n_live);
+    return mnrf_check_launch("mnrf_blend2_backward_n");
 }
 
 // n_live: live rows of base / mask / out (null: n); n_sec_live: live rows of sec / index (null: n_sec)

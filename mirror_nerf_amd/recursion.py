@@ -243,6 +243,9 @@ def _static_level(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_le
     gt_valid = extra_chunk.get("_gt_valid")
     if gt_valid is None:
         raise RuntimeError("static step: extra['_gt_valid'] must say whether the batch's mirror masks are all valid (train.py:153)")
+    if recur_level > 0 and not can_trace:
+        return r      # (the reference thresholds this level's predicted mask in place, train.py:165-166, in a dict whose masks nobody reads:
+                      #  the caller keeps rgb_* only, train.py:263-296 -- one launch less per step)
     if recur_level > 0 or not gt_valid:                           # train.py:155-166: predicted mask, thresholded in place
         if "mirror_mask_fine" in r:
             mask = r["mirror_mask_fine"]
@@ -270,11 +273,18 @@ def _static_level(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_le
     sec, index, _rdir, count = ReflectFn.apply(rays_chunk, r[f"x_surface_{sel}"], nrm, mask, bool(only_in), True, n_live)
     r2 = render_rays_chunk_recursively(models, embeddings, hp, sec, mask, recur_level + 1, dict(extra_chunk, _n_live=count),
                                        white_back, train_geometry_stage)
-    for typ in ("coarse", "fine"):                                # train.py:263-296
-        if f"rgb_{typ}" in r and f"rgb_{typ}" in r2:
-            r[f"rgb_{typ}_direct"] = r[f"rgb_{typ}"]
-            r[f"rgb_{typ}"], _ = _blend_autograd(r[f"rgb_{typ}"], r2[f"rgb_{typ}"], index if only_in else None, mask, False,
-                                                 detach_sec=detach_sec, n_sec_live=count, n_live=n_live)
+    # train.py:263-296 for both typs in one launch (gather form through the compaction's inverse index: autograd.Blend2Fn)
+    from .autograd import Blend2Fn
+    typs = [t for t in ("coarse", "fine") if f"rgb_{t}" in r and f"rgb_{t}" in r2]
+    if typs:
+        a = typs[0]
+        b = typs[1] if len(typs) > 1 else None
+        out_a, out_b = Blend2Fn.apply(r[f"rgb_{a}"], r2[f"rgb_{a}"], r[f"rgb_{b}"] if b else None, r2[f"rgb_{b}"] if b else None,
+                                      count._mnrf_slot, mask, detach_sec, n_live)
+        for t, o in ((a, out_a), (b, out_b)):
+            if t:
+                r[f"rgb_{t}_direct"] = r[f"rgb_{t}"]
+                r[f"rgb_{t}"] = o
     return r
 
 
