@@ -108,6 +108,9 @@ int64_t mnrf_packed_floats(void);
  * order (nn.Linear layout (out,in) row-major, models/mirror_nerf.py:59-99).
  * Replaces: the implicit weight reads of nn.Linear at call time. */
 int mnrf_pack_weights(const float* const* params, float* packed, void* stream);
+/* The same for n_models models at once (a training step re-packs its coarse and its fine model behind every optimizer step: one
+ * launch pair instead of one per model): params = n_models x 32 pointers, model after model; packed = n_models images. */
+int mnrf_pack_weights_n(int n_models, const float* const* params, float* const* packed, void* stream);
 
 /* Embedding.forward (models/mirror_nerf.py:20-38): x (n, c) -> out (n, c*(2*n_freqs+1)). */
 int mnrf_embed(const float* x, int64_t n, int c, int n_freqs, float* out, void* stream);
@@ -385,6 +388,18 @@ int mnrf_embed_n(const float* x, int64_t n, int c, int n_freqs, float* out, cons
 int mnrf_embed_backward_n(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x, const int32_t* n_live, void* stream);
 int mnrf_sample_coarse_n(const float* rays, int64_t n_rays, const float* z_steps, int n_samples, int use_disp, float perturb,
                          const float* perturb_rand, float* z_vals, const int32_t* n_live, void* stream);
+/* What render_rays does with a ray before the first field evaluation (models/rendering.py:275-300: `embedding_dir(rays_d)`, the
+ * coarse depths) as one launch: dir_emb (n_rays, 3 (2 n_freqs_dir + 1)) = mnrf_embed of columns 3..5 of the rays read in place,
+ * z_vals = mnrf_sample_coarse; both bit for bit.  n_samples >= 3. */
+int mnrf_ray_prologue_n(const float* rays, int64_t n_rays, int n_freqs_dir, const float* z_steps, int n_samples, int use_disp,
+                        float perturb, const float* perturb_rand, float* dir_emb, float* z_vals, const int32_t* n_live, void* stream);
+/* The gradient of reflected rays that went into several consumers (train.py:205: the reflected rays carry gradient back to the
+ * surface) in one launch instead of autograd's pairwise adds:
+ * g_rays = ((((g0 + g1) + g2) + g3) + pad(mnrf_embed_backward(rays[:, 3:6], g_dir_a + g_dir_b))), sums in this order; g0..g3
+ * (n_rays, 8) and g_dir_a / g_dir_b (n_rays, 3 (2 n_freqs_dir + 1)) may each be null (at least one is not). */
+int mnrf_ray_fan_backward_n(const float* g0, const float* g1, const float* g2, const float* g3, const float* rays,
+                            const float* g_dir_a, const float* g_dir_b, int64_t n_rays, int n_freqs_dir, float* g_rays,
+                            const int32_t* n_live, void* stream);
 int mnrf_composite_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
                      const float* noise, const float* rgb, const float* is_mirror,
                      const float* pred_normal, const float* normal, int white_back,

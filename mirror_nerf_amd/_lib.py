@@ -45,6 +45,7 @@ SIGNATURES = {
     "mnrf_version": (_int, []),
     "mnrf_packed_floats": (_i64, []),
     "mnrf_pack_weights": (_int, [ctypes.POINTER(ctypes.c_void_p), _c_f, _str]),
+    "mnrf_pack_weights_n": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _str]),
     "mnrf_embed": (_int, [_c_f, _i64, _int, _int, _c_f, _str]),
     "mnrf_field_forward": (_int, [_c_f, _u32, _i64, _c_f, _i64, _c_f, _c_f, _int, _c_f, _i64,
                                   _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "mnrf_embed_n": (_int, [_c_f, _i64, _int, _int, _c_f, _c_i, _str]),
     "mnrf_embed_backward_n": (_int, [_c_f, _c_f, _i64, _int, _int, _c_f, _c_i, _str]),
     "mnrf_sample_coarse_n": (_int, [_c_f, _i64, _c_f, _int, _int, _flt, _c_f, _c_f, _c_i, _str]),
+    "mnrf_ray_prologue_n": (_int, [_c_f, _i64, _int, _c_f, _int, _int, _flt, _c_f, _c_f, _c_f, _c_i, _str]),
+    "mnrf_ray_fan_backward_n": (_int, [_c_f] * 7 + [_i64, _int, _c_f, _c_i, _str]),
     "mnrf_composite_n": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
                                 _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_composite_backward_n": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_int, _c_f, _c_i, _str]),

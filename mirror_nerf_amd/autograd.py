@@ -402,6 +402,44 @@ class EmbedFn(torch.autograd.Function):
         return gx, None, None
 
 
+class RayFanFn(torch.autograd.Function):
+    """The head of a training render_rays call (models/rendering.py:275-300) and the tail of its backward, one launch each:
+    apply(rays, n_freqs_dir, z_steps, N_samples, use_disp, perturb, prand, n_live) ->
+        (rays_a, rays_b, rays_c, rays_d, dir_emb_a, dir_emb_b, z_vals)
+    rays_* are `rays` itself (views: one per consumer -- two field evaluations, two compositing passes), dir_emb_a / _b ONE view
+    encoding of the directions (one per field evaluation), z_vals the coarse depths (mnrf_ray_prologue_n).  The backward takes the
+    gradient every consumer sends and returns their sum in one launch (mnrf_ray_fan_backward_n) where autograd would add the pieces
+    pairwise, run the encoding's backward, pad it to eight columns and add again (eight launches per level of reflected rays,
+    train.py:205 "not detach() to jointly optimize")."""
+
+    @staticmethod
+    def forward(ctx, rays, n_freqs, z_steps, n_samples, use_disp, perturb, prand, n_live=None):
+        N = rays.shape[0]
+        dev = rays.device
+        dir_emb = torch.empty(N, 3 * (2 * n_freqs + 1), dtype=torch.float32, device=dev)
+        z_vals = torch.empty(N, n_samples, dtype=torch.float32, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mnrf_ray_prologue_n(p(rays), N, n_freqs, p(z_steps), n_samples, int(bool(use_disp)), float(perturb), p(prand),
+                                                  p(dir_emb), p(z_vals), p(n_live), _lib.stream()), "mnrf_ray_prologue_n")
+        ctx.save_for_backward(rays)
+        ctx.n_freqs, ctx.n_live = n_freqs, n_live
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(z_vals)
+        return (rays.view_as(rays), rays.view_as(rays), rays.view_as(rays), rays.view_as(rays), dir_emb, dir_emb.view_as(dir_emb), z_vals)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3, ga, gb, _gz):
+        (rays,) = ctx.saved_tensors
+        g = [None if t is None else t.contiguous().float() for t in (g0, g1, g2, g3, ga, gb)]
+        if all(t is None for t in g):
+            return (None,) * 8
+        out = torch.empty_like(rays)
+        p = _lib.ptr
+        _lib.check(_lib.lib().mnrf_ray_fan_backward_n(p(g[0]), p(g[1]), p(g[2]), p(g[3]), p(rays), p(g[4]), p(g[5]), rays.shape[0],
+                                                      ctx.n_freqs, p(out), p(ctx.n_live), _lib.stream()), "mnrf_ray_fan_backward_n")
+        return (out,) + (None,) * 7
+
+
 class ReflectFn(torch.autograd.Function):
     """mnrf_reflect_compact / mnrf_reflect_backward (train.py:192-252): reflected-ray construction and
     order-preserving compaction.  apply(rays, x_surface, normal, mask, compact) -> (sec (M,8), index (M) int32
@@ -435,6 +473,7 @@ class ReflectFn(torch.autograd.Function):
             ctx.count = None
         ctx.save_for_backward(rays, normal, index)
         ctx.compact = bool(compact)
+        ctx.set_materialize_grads(False)     # (index / reflect_dir / count carry no gradient: no tensors of zeros made for them)
         ctx.mark_non_differentiable(index, rdir, count)
         return sec, index, rdir, count
 

@@ -48,8 +48,15 @@ struct PackArgs {
     const float* params[32];
     float* packed;
 };
+// up to PACK_BATCH models per launch (blockIdx.y = model): a training step re-packs its coarse and its fine model behind
+// every optimizer step -- one launch instead of one per model (mnrf_pack_weights_n)
+constexpr int PACK_BATCH = 4;
+struct PackBatch {
+    PackArgs m[PACK_BATCH];
+};
 
-__global__ void pack_kernel(PackArgs P, PartTable T) {
+__global__ void pack_kernel(PackBatch PB, PartTable T) {
+    const PackArgs& P = PB.m[blockIdx.y];
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < DEVICE_STATE_WORDS) P.packed[OFF_REDUCE_PAIR + p] = 0.f;      // device state of the launches that use the image (mnrf_layout.h)
     if (p >= PACKED_F32_FLOATS) return;
@@ -130,24 +137,39 @@ using namespace mnrf;
 
 extern "C" int64_t mnrf_packed_floats(void) { return PACKED_FLOATS; }
 
-extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void* stream) {
+extern "C" int mnrf_pack_weights_n(int n_models, const float* const* params, float* const* packed, void* stream) {
+    if (n_models < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_pack_weights_n: negative model count");
+    if (n_models == 0) return MNRF_OK;
     if (!params || !packed) return mnrf_fail(MNRF_ERR_ARG, "mnrf_pack_weights: null pointer");
-    PackArgs P;
-    for (int i = 0; i < MNRF_N_PARAMS; ++i) {
+    for (int i = 0; i < n_models * MNRF_N_PARAMS; ++i)
         if (!params[i]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_pack_weights: null parameter pointer");
-        P.params[i] = params[i];
-    }
-    P.packed = packed;
+    for (int m = 0; m < n_models; ++m)
+        if (!packed[m]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_pack_weights: null image pointer");
     PartTable T;
     build_parts(T);
     const int threads = 256;
     const int blocks = (int)((PACKED_F32_FLOATS + threads - 1) / threads);
-    // (the device-state words at the image's end -- reduction pair, tile-queue pairs, range-guard word -- are zeroed by pack_kernel
-    // itself: split_pack_kernel, which may raise MNRF_GUARD_WEIGHT, runs behind it on the stream)
-    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, T);
-    launch_split_pack(packed, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
-    if (split32_enabled()) launch_split32_pack(params, packed, (hipStream_t)stream);   // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)
+    for (int m0 = 0; m0 < n_models; m0 += PACK_BATCH) {
+        const int nb = n_models - m0 < PACK_BATCH ? n_models - m0 : PACK_BATCH;
+        PackBatch PB{};
+        float* images[PACK_BATCH] = {};
+        for (int m = 0; m < nb; ++m) {
+            for (int i = 0; i < MNRF_N_PARAMS; ++i) PB.m[m].params[i] = params[(m0 + m) * MNRF_N_PARAMS + i];
+            PB.m[m].packed = images[m] = packed[m0 + m];
+        }
+        // (the device-state words at the image's end -- reduction pair, tile-queue pairs, range-guard word -- are zeroed by pack_kernel
+        // itself: split_pack_kernel, which may raise MNRF_GUARD_WEIGHT, runs behind it on the stream)
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks, nb), dim3(threads), 0, (hipStream_t)stream, PB, T);
+        launch_split_pack(images, nb, (hipStream_t)stream);   // hi/lo f16 streams of the split tunings, from the fp32 tiles
+        if (split32_enabled())      // stream of the 32x32x16 tuning (MNRF_SPLIT32=1 only)
+            for (int m = 0; m < nb; ++m) launch_split32_pack(params + (m0 + m) * MNRF_N_PARAMS, images[m], (hipStream_t)stream);
+    }
     return mnrf_check_launch("mnrf_pack_weights");
+}
+
+extern "C" int mnrf_pack_weights(const float* const* params, float* packed, void* stream) {
+    if (!params || !packed) return mnrf_fail(MNRF_ERR_ARG, "mnrf_pack_weights: null pointer");
+    return mnrf_pack_weights_n(1, params, &packed, stream);
 }
 
 extern "C" int mnrf_field_forward(float* packed, unsigned flags, int64_t B, const float* xyz,

@@ -104,7 +104,7 @@ struct FieldBwd2Args {
 // split-f16 tunings (mnrf_field_split.hip).  variant: 0 = default.
 int launch_split(const FieldArgs& A, bool sigma_only, bool grad, int variant, hipStream_t s);
 // builds the split streams of a packed image from its fp32 streams (same stream, after pack_kernel)
-void launch_split_pack(float* packed, hipStream_t s);
+void launch_split_pack(float* const* packed, int n_images, hipStream_t s);      // up to 4 images per launch
 int launch_split_bwd(const FieldBwdArgs& A, hipStream_t s);
 // 32x32x16 tuning of the forward-only split kernels (mnrf_field_split32.hip) and the packer of its stream (from the
 // state_dict-ordered parameter pointers)

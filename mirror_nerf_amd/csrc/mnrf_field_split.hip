@@ -71,7 +71,11 @@ int launch_split_bwd2(const FieldBwd2Args& A, hipStream_t s) { return h2x::launc
 // kernel took 30 us per model and step).  Half j of lane l of pair (T, nb) of a part is float (j&3) of lane l of the part's
 // fp32 tile (2T + (j>>2), nb); hi = f16(w) (round to nearest), lo = f16(w - hi): the thread reads two float4 and writes the 8 hi
 // halves (16 B at pair * 2048 + 16 l) and the 8 lo halves (1 KiB further).
-__global__ void split_pack_kernel(float* packed, PartTable T) {
+struct SplitPackImages {
+    float* packed[4];
+};
+__global__ void split_pack_kernel(SplitPackImages I, PartTable T) {
+    float* packed = I.packed[blockIdx.y];
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr long long FWD_LANES = (long long)SPLIT_FWD_PAIRS * 64;
     constexpr long long BWD_LANES = (long long)SPLIT_BWD_PAIRS * 64;
@@ -135,11 +139,13 @@ __global__ void split_pack_kernel(float* packed, PartTable T) {
     *(h8v*)(dst + PAIR_BYTES / 2) = lo;
 }
 
-void launch_split_pack(float* packed, hipStream_t s) {
+void launch_split_pack(float* const* packed, int n_images, hipStream_t s) {      // n_images <= 4
     PartTable T;
     build_parts(T);
+    SplitPackImages I{};
+    for (int m = 0; m < n_images; ++m) I.packed[m] = packed[m];
     const long long n = (long long)(SPLIT_FWD_PAIRS + SPLIT_BWD_PAIRS + SPLIT_HBWD_PAIRS) * 64;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, packed, T);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, I, T);
 }
 
 }  // namespace mnrf

@@ -662,6 +662,86 @@ __global__ void embed_backward_kernel(const float* __restrict__ x, const float* 
     gx[i] = a;
 }
 
+// ------------------------------------------------------------------ ray prologue / ray gradient fan-in (training)
+// What render_rays does with a ray before the first field evaluation (models/rendering.py:275-300) as ONE launch: the view
+// encoding of the direction (columns 3..5 of the ray, read in place: no contiguous copy) and the coarse depths.  The arithmetic
+// is embed_kernel's and sample_coarse_kernel's: the outputs are theirs bit for bit.  Needs ns >= 3 (thread s < 3 of a ray also
+// writes encoding channel s).
+__global__ void ray_prologue_kernel(const float* __restrict__ rays, long long n_rays, int n_freqs,
+                                    const float* __restrict__ z_steps, int ns, int use_disp, float perturb,
+                                    const float* __restrict__ prand, float* __restrict__ dir_emb, float* __restrict__ z_out,
+                                    const int* __restrict__ n_live) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= live_rows(n_rays, n_live) * ns) return;
+    const long long r = i / ns;
+    const int s = (int)(i % ns);
+    const float near = rays[r * 8 + 6], far = rays[r * 8 + 7];
+    auto zat = [&](int k) -> float {
+        const float t = z_steps[k];
+        if (!use_disp) return near * (1.f - t) + far * t;
+        return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);
+    };
+    float z = zat(s);
+    if (perturb > 0.f) {
+        const float lower = s == 0 ? z : 0.5f * (zat(s - 1) + z);
+        const float upper = s == ns - 1 ? z : 0.5f * (z + zat(s + 1));
+        z = lower + (upper - lower) * (perturb * prand[i]);
+    }
+    z_out[i] = z;
+    if (s < 3) {
+        const int ld = 3 * (2 * n_freqs + 1);
+        const float v = rays[r * 8 + 3 + s];
+        float* o = dir_emb + r * ld;
+        o[s] = v;
+        for (int f = 0; f < n_freqs; ++f) {
+            float sn, co;
+            sincosf(ldexpf(v, f), &sn, &co);
+            o[3 * (1 + 2 * f) + s] = sn;
+            o[3 * (2 + 2 * f) + s] = co;
+        }
+    }
+}
+
+// The gradient of a ray that went into several consumers (two field evaluations, two compositing passes, the view encoding):
+// autograd would add the (N,8) pieces pairwise (four launches), run the encoding's backward on the sum of its two gradients
+// (one add, one launch), pad that to eight columns (a fill and a strided copy) and add it (one more).  Here: one launch,
+// out = ((((g0 + g1) + g2) + g3) + [0 0 0 dview 0 0]) with dview = embed_backward(rays[:, 3:6], ga + gb) -- the same sums in
+// the same order.  Any g may be null (a consumer that sent nothing).
+struct RayFanArgs {
+    const float* g[4]; const float* rays; const float* ga; const float* gb; long long n; int n_freqs; float* out; const int* n_live;
+};
+__global__ void ray_fan_backward_kernel(RayFanArgs A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= live_rows(A.n, A.n_live) * 8) return;
+    const long long row = i >> 3;
+    const int col = (int)(i & 7);
+    float acc = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (A.g[k]) {
+            const float t = A.g[k][i];
+            acc = any ? acc + t : t;
+            any = true;
+        }
+    if (col >= 3 && col < 6 && (A.ga || A.gb)) {
+        const int ch = col - 3;
+        const int ld = 3 * (2 * A.n_freqs + 1);
+        const float v = A.rays[i];
+        const float* ra = A.ga ? A.ga + row * ld : nullptr;
+        const float* rb = A.gb ? A.gb + row * ld : nullptr;
+        auto gat = [&](int k) -> float { return ra ? (rb ? ra[k] + rb[k] : ra[k]) : rb[k]; };
+        float a = gat(ch);
+        for (int f = 0; f < A.n_freqs; ++f) {
+            float sn, co;
+            sincosf(ldexpf(v, f), &sn, &co);
+            a += ldexpf(gat(3 * (1 + 2 * f) + ch) * co - gat(3 * (2 + 2 * f) + ch) * sn, f);
+        }
+        acc = any ? acc + a : a;
+    }
+    A.out[i] = acc;
+}
+
 inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
@@ -1035,6 +1115,31 @@ extern "C" int mnrf_embed_backward(const float* x, const float* g_out, int64_t n
 extern "C" int mnrf_embed_backward_n(const float* x, const float* g_out, int64_t n, int c, int n_freqs, float* g_x,
                                      const int32_t* n_live, void* stream) {
     return embed_backward_impl(x, g_out, n, c, n_freqs, g_x, n_live, stream);
+}
+
+extern "C" int mnrf_ray_prologue_n(const float* rays, int64_t n_rays, int n_freqs_dir, const float* z_steps, int n_samples, int use_disp,
+                                   float perturb, const float* perturb_rand, float* dir_emb, float* z_vals, const int32_t* n_live,
+                                   void* stream) {
+    if (n_rays < 0 || n_samples < 3 || n_freqs_dir < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_prologue_n: bad size (n_samples >= 3)");
+    if (n_rays == 0) return MNRF_OK;
+    if (!rays || !z_steps || !z_vals || !dir_emb) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_prologue_n: null pointer");
+    if (perturb > 0.f && !perturb_rand) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_prologue_n: perturb > 0 needs perturb_rand");
+    hipLaunchKernelGGL(ray_prologue_kernel, dim3(blocks_for(n_rays * n_samples, 256)), dim3(256), 0, (hipStream_t)stream, rays,
+                       (long long)n_rays, n_freqs_dir, z_steps, n_samples, use_disp, perturb, perturb_rand, dir_emb, z_vals, n_live);
+    return mnrf_check_launch("mnrf_ray_prologue_n");
+}
+
+extern "C" int mnrf_ray_fan_backward_n(const float* g0, const float* g1, const float* g2, const float* g3, const float* rays,
+                                       const float* g_dir_a, const float* g_dir_b, int64_t n_rays, int n_freqs_dir, float* g_rays,
+                                       const int32_t* n_live, void* stream) {
+    if (n_rays < 0 || n_freqs_dir < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_fan_backward_n: bad size");
+    if (n_rays == 0) return MNRF_OK;
+    if (!g_rays || ((g_dir_a || g_dir_b) && !rays)) return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_fan_backward_n: null pointer");
+    if (!g0 && !g1 && !g2 && !g3 && !g_dir_a && !g_dir_b)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_ray_fan_backward_n: no gradient at all (the caller returns None instead)");
+    RayFanArgs A{{g0, g1, g2, g3}, rays, g_dir_a, g_dir_b, (long long)n_rays, n_freqs_dir, g_rays, n_live};
+    hipLaunchKernelGGL(ray_fan_backward_kernel, dim3(blocks_for(n_rays * 8, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    return mnrf_check_launch("mnrf_ray_fan_backward_n");
 }
 
 extern "C" int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far, float* rays,

@@ -107,7 +107,8 @@ class _TotalLossFn(torch.autograd.Function):
         a.w_color, a.w_normal, a.w_normal_reg = cfg["w_color"], cfg["w_normal"], cfg["w_normal_reg"]
         a.w_mask, a.w_plane = cfg["w_mask"], cfg["w_plane"]
         a.flags = cfg["flags"]
-        out = torch.empty(6, dtype=torch.float32, device=dev)
+        buf = torch.empty(6, dtype=torch.float32, device=dev)
+        out = buf[:6]             # (the six terms and the returned sum are two views of `buf`, not of each other: no clone launch)
         a.out = _ptr(out)
 
         times = [0, 0]
@@ -128,12 +129,15 @@ class _TotalLossFn(torch.autograd.Function):
         ctx.grads = [grads.get(k) for k in keys]
         ctx.shapes = [t.shape for t in tensors]
         ctx.mark_non_differentiable(out)
-        return out[5:6].clone().reshape(()), out
+        ctx.set_materialize_grads(False)
+        return buf[5], out
 
     @staticmethod
     def backward(ctx, g_sum, _g_out):
         # one multi-tensor launch for all inputs (four separate multiplies sat at the very start of the backward pass, where the
         # device has nothing else queued)
+        if g_sum is None:
+            return (None, None, None) + (None,) * len(ctx.grads)
         have = [g for g in ctx.grads if g is not None]
         scaled = iter(torch._foreach_mul(have, g_sum) if have else [])
         outs = [None if g is None else next(scaled).reshape(shape) for g, shape in zip(ctx.grads, ctx.shapes)]

@@ -138,6 +138,10 @@ def render_rays_chunk_recursively(models, embeddings, hp, rays_chunk, mirror_mas
     the ground-truth mask is valid (train.py:153 `(mask >= 0).all()`) is the caller's statement extra_chunk["_gt_valid"]."""
     static = bool(extra_chunk.get("_static")) and not extra_chunk.get("is_eval", False) and torch.is_grad_enabled()
     n_live = extra_chunk.get("_n_live")
+    if static and recur_level == 0 and "_rng_share" not in extra_chunk and hp.trace_secondary_rays and not train_geometry_stage:
+        # every level of a static step renders the same capacity of rays: the first one draws the random numbers of all of them
+        # (two generator launches per step instead of two per level)
+        extra_chunk = dict(extra_chunk, _rng_share=(1 + max(0, hp.max_recursive_level), {}))
     r = render_rays(models, embeddings, rays_chunk, hp.N_samples, hp.use_disp, hp.perturb, hp.noise_std,
                     hp.N_importance, hp.chunk, white_back, compute_normal=hp.trace_secondary_rays,
                     **dict(extra_chunk, _guard=False))        # the range guard is read once, in NeRFSystem.forward
@@ -340,8 +344,9 @@ class NeRFSystem(nn.Module):
         for i in range(0, rays.shape[0], hp.chunk):
             ex = {k: (v[i:i + hp.chunk] if isinstance(v, torch.Tensor) else v) for k, v in extra.items() if k != "_guard"}
             rc = rays[i:i + hp.chunk].contiguous()
-            first = torch.ones(rc.shape[0], dtype=torch.bool, device=rc.device)
-            out = render_rays_chunk_recursively(self.models, self.embeddings, hp, rc, first, 0, ex,
+            # (train.py:115-119 hands an all-ones "previous mirror mask" to level 0, where nothing reads it: train.py:167-168 multiplies by it
+            #  at recur_level > 0 only -- no tensor made for it)
+            out = render_rays_chunk_recursively(self.models, self.embeddings, hp, rc, None, 0, ex,
                                                 self.white_back, self.train_geometry_stage)
             for k, v in out.items():
                 results[k] += [v]

@@ -131,8 +131,12 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             cut_heads |= _lib.MNRF_CUT_NORMAL_HEAD
 
     # rendering.py:275-277 -- view encoding once per ray
+    # (training, the MirrorNeRF field: encoding and coarse depths come from ONE launch further down, autograd.RayFanFn)
+    fan = bool(train and not test_time and not hashgrid and N and N_samples >= 3 and "view_dir" not in kwargs and rays.shape[1] == 8)
     view = kwargs.get("view_dir", rays[:, 3:6])
-    if hashgrid:
+    if fan:
+        dir_emb = None
+    elif hashgrid:
         dir_emb = view.float().contiguous()          # Embedding(0): the raw direction (train.py:69-70)
     else:
         dir_emb = EmbedFn.apply(view, n_fd, n_live) if (train and view.requires_grad) else _embed(view.detach(), n_fd, n_live)
@@ -145,12 +149,23 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     # (rendering.py:189, 296-300; 27 draws its u inside sample_pdf).  The draws are i.i.d. either way.
     S_fine = N_samples + N_importance
     two_pass = train and N and N_importance > 0 and not kwargs.get("only_one_field", False) and kwargs.get("_z_fine") is None
+    # `_rng_share` = (k, box): this call is the first of k calls of this shape in one step (the recursion levels of a static
+    # training step); it draws for all of them at once and leaves the rest in box["u"] / box["n"], which the later calls take.
     pool_u = pool_n = None
+    share, box = kwargs.get("_rng_share") or (1, None)
+
+    def pooled(kind, need, make):
+        have = box.get(kind) if box is not None else None
+        if have is None or have.numel() < need:
+            have = make(need * (share if box is not None else 1))
+        if box is not None:
+            box[kind] = have[need:]
+        return have[:need]
     if two_pass and perturb > 0 and kwargs.get("_perturb_rand") is None and kwargs.get("_u") is None:
-        pool_u = torch.rand(N * (N_samples + N_importance), device=dev)
+        pool_u = pooled("u", N * (N_samples + N_importance), lambda k: torch.rand(k, device=dev))
     auto_noise = {}
     if two_pass and noise_std != 0 and kwargs.get("_noise_coarse") is None and kwargs.get("_noise_fine") is None:
-        pool_n = torch.randn(N * (N_samples + S_fine), device=dev)
+        pool_n = pooled("n", N * (N_samples + S_fine), lambda k: torch.randn(k, device=dev))
         if noise_std != 1:
             pool_n = pool_n * noise_std
         auto_noise = {"_noise_coarse": pool_n[:N * N_samples].view(N, N_samples), "_noise_fine": pool_n[N * N_samples:].view(N, S_fine)}
@@ -161,10 +176,20 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             prand = pool_u[:N * N_samples].view(N, N_samples) if pool_u is not None else torch.rand(N, N_samples, device=dev)
         else:
             prand = prand.float().contiguous()
-    z_vals = f(N, N_samples)
-    if N:
-        _lib.check(L.mnrf_sample_coarse_n(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
-                                          p(prand), p(z_vals), p(n_live), _lib.stream()), "mnrf_sample_coarse")
+    # which tensors a pass reads: (rays of the field evaluation, rays of the compositing, view encoding); with the fan, every
+    # consumer gets its own view of the rays so that their gradients come back as separate arguments of ONE summing launch
+    per_pass = {}
+    if fan:
+        from .autograd import RayFanFn
+        r_cf, r_ff, r_cc, r_fc, de_c, de_f, z_vals = RayFanFn.apply(rays, n_fd, z_steps, N_samples, bool(use_disp), float(perturb),
+                                                                   prand, n_live)
+        # (argument order of the sum = the order autograd adds in: fine compositing, fine field, coarse compositing, coarse field)
+        per_pass = {"_noise_coarse": (r_fc, r_cc, de_c), "_noise_fine": (r_ff, r_cf, de_f)}
+    else:
+        z_vals = f(N, N_samples)
+        if N:
+            _lib.check(L.mnrf_sample_coarse_n(p(rays), N, p(z_steps), N_samples, int(bool(use_disp)), float(perturb),
+                                              p(prand), p(z_vals), p(n_live), _lib.stream()), "mnrf_sample_coarse")
 
     has_fine = "fine" in models
     results = {}
@@ -276,6 +301,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     def inference_train(model, typ, z, noise_key):
         """The same pass with autograd-aware kernels (training)."""
         S = z.shape[1]
+        rays_f, rays_c, dir_emb_p = per_pass.get(noise_key, (rays, rays, dir_emb))
         if hashgrid:
             from .mirror_nerf_tcnn import TcnnFieldFn
             want = bool(compute_normal)
@@ -287,7 +313,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             want = bool(compute_normal)
             if cut_heads or keep_mirror is not None or n_live is not None:
                 want = (want, cut_heads, keep_mirror, n_live)
-            sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays, z, dir_emb, want, *params_of(model))
+            sigma, rgb, pn, mir, normal = FieldFn.apply(model, S, None, rays_f, z, dir_emb_p, want, *params_of(model))
         noise = kwargs.get(noise_key)
         if noise is not None:
             noise = (noise.float() * noise_std).contiguous()
@@ -303,7 +329,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if not getattr(model, "predict_normal", True):
             pn = None
         weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
-            rays, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live)
+            rays_c, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live)
         results[f"weights_{typ}"] = weights
         results[f"opacity_{typ}"] = opacity
         results[f"z_vals_{typ}"] = z

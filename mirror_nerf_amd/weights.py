@@ -76,17 +76,13 @@ def decanonical(name, g, shape):
     return g[:, :shape[1]]
 
 
-def pack_state(tensors, out=None):
-    """tensors: dict name -> fp32 CUDA tensor.  Returns the packed image (1-D fp32 CUDA tensor).
-    The parameters of an absent optional head (predict_normal=False / predict_mirror_mask=False) are packed as zeros."""
-    L = _lib.lib()
+def _param_pointers(tensors, arr, base, keep):
+    """Fill arr[base : base + 32] with the addresses of one model's parameters in PARAM_NAMES order; returns the device."""
     missing = [n for n in PARAM_NAMES if n not in tensors and not n.startswith(OPTIONAL_HEADS)]
     if missing:
         raise RuntimeError(
             "the HIP field kernel implements the reference's D=8, W=256 trunk with the colour head "
             f"(train.py:44-66); missing parameters: {missing}")
-    keep = []
-    arr = (ctypes.c_void_p * _lib.N_PARAMS)()
     dev = next(iter(tensors.values())).device
     for i, n in enumerate(PARAM_NAMES):
         t = canonical(n, tensors[n].detach()) if n in tensors else _zeros(n, dev)
@@ -96,12 +92,33 @@ def pack_state(tensors, out=None):
             raise RuntimeError(f"{n}: need a float32 CUDA tensor")
         t = t.contiguous()
         keep.append(t)
-        arr[i] = t.data_ptr()
+        arr[base + i] = t.data_ptr()
         dev = t.device
-    if out is None:
-        out = torch.empty(L.mnrf_packed_floats(), dtype=torch.float32, device=dev)
-    _lib.check(L.mnrf_pack_weights(arr, _lib.ptr(out), _lib.stream()), "mnrf_pack_weights")
-    return out
+    return dev
+
+
+def pack_states(states, outs=None):
+    """states: list of dicts name -> fp32 CUDA tensor (one per model, all on one device); outs: list of images to overwrite (entries
+    may be None).  ONE mnrf_pack_weights_n call for all of them.  Returns the packed images (1-D fp32 CUDA tensors).
+    The parameters of an absent optional head (predict_normal=False / predict_mirror_mask=False) are packed as zeros."""
+    L = _lib.lib()
+    n = len(states)
+    outs = list(outs) if outs is not None else [None] * n
+    keep = []
+    arr = (ctypes.c_void_p * (_lib.N_PARAMS * n))()
+    img = (ctypes.c_void_p * n)()
+    for m, tensors in enumerate(states):
+        dev = _param_pointers(tensors, arr, m * _lib.N_PARAMS, keep)
+        if outs[m] is None:
+            outs[m] = torch.empty(L.mnrf_packed_floats(), dtype=torch.float32, device=dev)
+        img[m] = outs[m].data_ptr()
+    _lib.check(L.mnrf_pack_weights_n(n, arr, img, _lib.stream()), "mnrf_pack_weights")
+    return outs
+
+
+def pack_state(tensors, out=None):
+    """One model (see pack_states)."""
+    return pack_states([tensors], [out])[0]
 
 
 def param_refs(module):
@@ -152,7 +169,8 @@ class PackedCache:
         self.key = None
         self.packed = None
 
-    def get(self, module):
+    def stale(self, module):
+        """-> the key the image should have, or None when the image is current."""
         # (the look-up runs eight times per training step, four of them with nothing else queued on the device: one pass over
         # the parameters, no dict unless the image has to be rebuilt)
         refs = param_refs(module)
@@ -163,10 +181,35 @@ class PackedCache:
             key.append(q._version)
         if _reg_hook is None and any(sub._parameters[pname].requires_grad for sub, pname, _ in refs):
             self.key = None
-        if key != self.key or self.packed is None:
-            self.packed = pack_state({full: sub._parameters[pname] for sub, pname, full in refs}, self.packed)
+        return key if (key != self.key or self.packed is None) else None
+
+    def get(self, module):
+        key = self.stale(module)
+        if key is not None:
+            self.packed = pack_state({full: sub._parameters[pname] for sub, pname, full in param_refs(module)}, self.packed)
             self.key = key
         return self.packed
+
+
+def packed_of_many(modules):
+    """packed_of for several MirrorNeRF modules; the stale images among them are rebuilt by ONE batched launch pair."""
+    caches, todo = [], []
+    for m in modules:
+        cache = m.__dict__.get("_mnrf_packed")
+        if cache is None:
+            cache = m.__dict__["_mnrf_packed"] = PackedCache()
+        caches.append(cache)
+        key = cache.stale(m)
+        if key is not None:
+            todo.append((m, cache, key))
+    if len({next(iter(m.parameters())).device for m, _, _ in todo}) > 1:      # (images on several devices: one call each)
+        return [c.get(m) for m, c in zip(modules, caches)]
+    if todo:
+        outs = pack_states([{full: sub._parameters[pname] for sub, pname, full in param_refs(m)} for m, _, _ in todo],
+                           [c.packed for _, c, _ in todo])
+        for (m, c, key), out in zip(todo, outs):
+            c.packed, c.key = out, key
+    return [c.packed for c in caches]
 
 
 def invalidate_packed(module):
@@ -192,10 +235,10 @@ class validated:
 
     def __enter__(self):
         self.added = []
-        for m in self.modules:
-            if id(m) not in _VALIDATED and m.__class__.__name__ == "MirrorNeRF":
-                _VALIDATED[id(m)] = packed_of(m)
-                self.added.append(id(m))
+        fresh = [m for m in self.modules if id(m) not in _VALIDATED and m.__class__.__name__ == "MirrorNeRF"]
+        for m, image in zip(fresh, packed_of_many(fresh) if fresh else []):
+            _VALIDATED[id(m)] = image
+            self.added.append(id(m))
         return self
 
     def __exit__(self, *exc):
