@@ -31,6 +31,17 @@ def _pmc(kernel):
         return {}
 
 
+def _l1_rate(pmc, ms):
+    """Vector-L1 (TCP) line accesses of a launch per clock and CU at the nominal 2.4 GHz.  Reported as context for the level-major
+    gather launch (round 5, 32-ray x 8-depth patches per workgroup: most gathers hit the L1 and the L2 line rate is no longer what
+    binds); the guide gives no peak for it and an experiment that removed a quarter of these accesses (the two x-neighbours of a
+    corner as one 16-byte gather where they are adjacent, bit-identical planes) left the time unchanged, so it is not the bound either."""
+    if not pmc or "TCP_TOTAL_CACHE_ACCESSES_sum" not in pmc or not ms:
+        return None
+    return {"l1_line_accesses_per_launch": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
+            "per_clock_per_cu_at_2400MHz": pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * ms * 2.4e6)}
+
+
 def _traffic(kernel):
     try:
         with open(TRAFFIC_JSON) as f:
@@ -198,12 +209,14 @@ def hash_grid_leg(dev, rays):
                             "tcp_hit_rate": (1.0 - pmc16["TCP_TCC_READ_REQ_sum"] / pmc16["TCP_TOTAL_CACHE_ACCESSES_sum"])
                             if pmc16 and "TCP_TOTAL_CACHE_ACCESSES_sum" in pmc16 else None,
                             "hbm_bytes_per_launch": ((2 * pmc16["FETCH_SIZE"] + pmc16["WRITE_SIZE"]) * 1024) if pmc16 and "FETCH_SIZE" in pmc16 and "WRITE_SIZE" in pmc16 else None,
+                            "l1_access_rate": _l1_rate(pmc16, enc16_ms),
                             "counters_source": pmc16.get("source") if pmc16 else None},
         "algorithmic_bytes_per_sample": 512 + 256,
         "note": "module.table_f16 / MNRF_TCNN_TABLE_F16: the kernels gather from a half2 copy of the table (2 MB per hashed level against "
                 "the 4 MB L2 of an XCD; the fp32 master stays what the optimizer steps); forward bit-identical to the fp32-table kernels "
-                "on a table rounded to f16 (tests); a level-major gather still pulls a 128-byte line per corner, so the L2->L1 line rate, "
-                "not the entry size, bounds the launch"})
+                "on a table rounded to f16 (tests).  With 32-ray x 8-depth patches per workgroup most gathers hit the vector L1 and the "
+                "launch takes the same time with either entry size (`l1_access_rate`: 0.8-0.9 L1 line accesses per clock and CU): the half2 "
+                "table halves the footprint and the fabric traffic, not the time"})
     ttr, tsrc, tcommit = _traffic("mnrf::mf::tcnn_encode_kernel")
     params = [p for m in models.values() for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=5e-4, fused=True)      # (one multi-tensor launch; the default "foreach" form is ~10 passes over the two 49 MB tables)
@@ -300,12 +313,18 @@ def hash_grid_leg(dev, rays):
                                 "one_launch_form_ms": one_launch_ms, "G_gathers_per_s": zf.numel() * 128 / (enc_ms * 1e-3) / 1e9,
                                 "context": {"independent_random_8B_gathers_in_a_2MiB_window": ceil["l2_resident_8B"],
                                             "uniformly_random_over_the_49MB_table": {"8_byte": ceil["random_8B"], "4_byte": ceil["random_4B"]}},
+                                "l1_access_rate": _l1_rate(pmc, enc_ms),
                                 "counters_source": "static profile: profiles/traffic.json \"pmc\" (scripts/pmc_tcnn.sh), per launch of one 32768-ray chunk",
                                 "note": "every gather that misses the 32 KB vector L1 pulls a 128-byte line out of the L2 for 8 useful bytes; "
                                         "achieved = those lines (PMC: TCP_TCC_READ_REQ x 128 B per launch) over the live launch time, against "
                                         "the L2's ~34.5 TB/s (MI355X_MICROARCH.md).  Round 3's one-launch kernel walked all 16 levels per wave: "
                                         "54 % of its lines missed the L2 too and 20.7 GB per launch crossed the fabric at 7.5 TB/s "
-                                        "(profiles/r04b_pmc_tcnn); level by level the L2 holds the level (hit rate above)."},
+                                        "(profiles/r04b_pmc_tcnn); round 4 went level by level (L2 hit rate 0.95, 0.64 of this roofline); "
+                                        "round 5 gives a workgroup a patch of 32 neighbouring rays x 8 depths: the L1 hit rate rises "
+                                        "0.57 -> 0.83 and the lines asked of the L2 fall 2.5x -- this L2 fraction is lower than round 4's "
+                                        "because the kernel needs less of the L2, not because it got slower (1.62 -> 1.24 ms).  What binds "
+                                        "now is inside the CU's gather path (`l1_access_rate`: 0.9 L1 line accesses per clock and CU; "
+                                        "removing a quarter of them did not shorten the launch, DESIGN 9)."},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": ttr,
                          "traffic_source": (f"static profile: profiles/traffic.json, commit {tcommit or 'unrecorded'}, {tsrc}") if ttr else None,
                          "kernel": "mnrf::mf::tcnn_encode_kernel + mnrf::mf::tcnn_mfma_kernel<0,true> (full evaluation, fine pass)",

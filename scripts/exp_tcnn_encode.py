@@ -40,4 +40,27 @@ for _ in range(10):
     pr()
 e1.record()
 torch.cuda.synchronize()
+bits = int(planes.view(torch.int32).to(torch.int64).sum())      # exact: equal for bit-identical planes
+# the same launch from the half2 copy of the table
+th, tflag = m._table() if hasattr(m, "_table") else (None, 0)
+m.table_f16 = True
+th, tflag = m._table()
+m.table_f16 = False
+
+
+def pr16():
+    _lib.check(_lib.lib().mnrf_tcnn_encode_flags(th.data_ptr(), offs, m.cfg["S"], m.cfg["H"], float(m.bound), zf.numel(), None, 0, _lib.ptr(rays),
+                                                 _lib.ptr(zf), zf.shape[1], _lib.ptr(planes), tflag, _lib.stream()), "encode (half2)")
+
+
+pr16()
+torch.cuda.synchronize()
+bits16 = int(planes.view(torch.int32).to(torch.int64).sum())
+h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+h0.record()
+for _ in range(10):
+    pr16()
+h1.record()
+torch.cuda.synchronize()
+print(f"half2 table: {h0.elapsed_time(h1) / 10:.3f} ms per launch, bits {bits16}; fp32 table bits {bits}")
 print(f"encode {e0.elapsed_time(e1) / 10:.3f} ms per launch ({zf.numel()} samples), checksum {chk[0]:.6e} {chk[1]:.6e}  (lib {os.environ.get('MNRF_LIB', 'default')})")
