@@ -263,3 +263,91 @@ def test_flat_adam_refuses_orphaned_parameters_and_skips_modules_without_gradien
     q.data = q.data.clone()                                      # what a cast / move / re-assignment does to the aliasing
     with pytest.raises(RuntimeError, match="no longer aliases"):
         opt.step()
+
+
+# ---------------------------------------------------------------- launches merged in the second half of round 5
+def test_ray_prologue_equals_embed_and_sample_coarse():
+    """mnrf_ray_prologue_n = mnrf_embed_n of the direction columns + mnrf_sample_coarse_n, bit for bit, with and without a live
+    row count (rows past it are not written)."""
+    from mirror_nerf_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    n, ns, nf = 200, 64, 4
+    rays = torch.randn(n, 8, device=DEV, generator=g)
+    rays[:, 6], rays[:, 7] = 0.3, 5.0
+    steps = torch.linspace(0, 1, ns, device=DEV)
+    prand = torch.rand(n, ns, device=DEV, generator=g)
+    for use_disp, perturb in ((0, 0.0), (0, 1.0), (1, 1.0)):
+        for live in (None, 77):
+            nl = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+            want_e, want_z = torch.full((n, 27), -7.0, device=DEV), torch.full((n, ns), -7.0, device=DEV)
+            got_e, got_z = want_e.clone(), want_z.clone()
+            dirs = rays[:, 3:6].contiguous()
+            _lib.check(L.mnrf_embed_n(p(dirs), n, 3, nf, p(want_e), p(nl), _lib.stream()), "embed")
+            _lib.check(L.mnrf_sample_coarse_n(p(rays), n, p(steps), ns, use_disp, perturb, p(prand), p(want_z), p(nl), _lib.stream()), "coarse")
+            _lib.check(L.mnrf_ray_prologue_n(p(rays), n, nf, p(steps), ns, use_disp, perturb, p(prand), p(got_e), p(got_z), p(nl),
+                                             _lib.stream()), "prologue")
+            assert torch.equal(got_e, want_e) and torch.equal(got_z, want_z)
+    assert L.mnrf_ray_prologue_n(p(rays), n, nf, p(steps), 2, 0, 0.0, None, p(got_e), p(got_z), None, _lib.stream()) < 0     # n_samples >= 3
+
+
+@pytest.mark.parametrize("absent", [(), (1,), (0, 2, 3), (4,), (0, 1, 2, 3)])
+def test_ray_fan_backward_is_autograds_sum(absent):
+    """mnrf_ray_fan_backward_n against the torch ops it replaces, in autograd's order: pairwise adds of the four ray gradients, the
+    encoding's backward on the sum of its two gradients, padded to eight columns, added last.  Bit for bit; any piece may be absent."""
+    from mirror_nerf_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    n, nf = 300, 4
+    rays = torch.randn(n, 8, device=DEV, generator=g)
+    gs = [torch.randn(n, 8, device=DEV, generator=g) for _ in range(4)]
+    ga, gb = torch.randn(n, 27, device=DEV, generator=g), torch.randn(n, 27, device=DEV, generator=g)
+    pieces = [None if k in absent else t for k, t in enumerate(gs)]
+    da = None if 4 in absent else ga
+    db = None if 5 in absent else gb
+    want = None
+    for t in pieces:
+        if t is not None:
+            want = t.clone() if want is None else want + t
+    if da is not None or db is not None:
+        gsum = da if db is None else (db if da is None else da + db)
+        gx = torch.empty(n, 3, device=DEV)
+        _lib.check(L.mnrf_embed_backward_n(p(rays[:, 3:6].contiguous()), p(gsum.contiguous()), n, 3, nf, p(gx), None, _lib.stream()), "embed bwd")
+        pad = torch.zeros(n, 8, device=DEV)
+        pad[:, 3:6] = gx
+        want = pad if want is None else want + pad
+    got = torch.empty(n, 8, device=DEV)
+    _lib.check(L.mnrf_ray_fan_backward_n(p(pieces[0]), p(pieces[1]), p(pieces[2]), p(pieces[3]), p(rays), p(da), p(db), n, nf, p(got), None,
+                                         _lib.stream()), "fan")
+    assert torch.equal(got, want)
+    nl = torch.tensor([123], dtype=torch.int32, device=DEV)
+    got2 = torch.full((n, 8), -3.0, device=DEV)
+    _lib.check(L.mnrf_ray_fan_backward_n(p(pieces[0]), p(pieces[1]), p(pieces[2]), p(pieces[3]), p(rays), p(da), p(db), n, nf, p(got2), p(nl),
+                                         _lib.stream()), "fan (live rows)")
+    assert torch.equal(got2[:123], want[:123]) and bool((got2[123:] == -3.0).all())
+
+
+def test_ray_fan_backward_refuses_nothing():
+    from mirror_nerf_amd import _lib
+    out = torch.empty(4, 8, device=DEV)
+    assert _lib.lib().mnrf_ray_fan_backward_n(None, None, None, None, None, None, None, 4, 4, _lib.ptr(out), None, _lib.stream()) < 0
+
+
+def test_pack_weights_n_equals_one_by_one():
+    """mnrf_pack_weights_n (both models of a step in one launch pair) writes the images mnrf_pack_weights writes."""
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd.weights import pack_state, pack_states, param_refs
+    torch.manual_seed(3)
+    models = [M.MirrorNeRF().to(DEV) for _ in range(5)]          # five: more than one batch of four
+    states = [{full: sub._parameters[pname] for sub, pname, full in param_refs(m)} for m in models]
+    one = [pack_state(s) for s in states]
+    many = pack_states(states)
+    for a, b in zip(one, many):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    with torch.no_grad():
+        models[1].sigma.weight[0, 0] = float("inf")             # the weight bit of the range guard belongs to ITS image only
+    many = pack_states(states, many)
+    words = [int(t[-1:].view(torch.int32).item()) for t in many]
+    assert words[1] != 0 and all(w == 0 for k, w in enumerate(words) if k != 1)
