@@ -342,8 +342,10 @@ def test_pack_weights_n_equals_one_by_one():
     torch.manual_seed(3)
     models = [M.MirrorNeRF().to(DEV) for _ in range(5)]          # five: more than one batch of four
     states = [{full: sub._parameters[pname] for sub, pname, full in param_refs(m)} for m in models]
-    one = [pack_state(s) for s in states]
-    many = pack_states(states)
+    from mirror_nerf_amd import _lib
+    blank = lambda: torch.zeros(_lib.lib().mnrf_packed_floats(), device=DEV)  # noqa: E731  (regions no tuning writes stay as they were)
+    one = [pack_state(s, blank()) for s in states]
+    many = pack_states(states, [blank() for _ in states])
     for a, b in zip(one, many):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     with torch.no_grad():
