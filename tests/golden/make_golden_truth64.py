@@ -7,7 +7,8 @@ ask the sharper question -- is the HIP value at least as close to the truth as t
 
 Build-container only:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_truth64.py
 g3_coarse64_train is coarse only; the fine passes (g4_fine_train, g11_trained_render_train) are evaluated at the fp32 run's
-own fine depths (truth_fine), so that inverse-CDF bin flips cannot dominate the comparison."""
+own fine depths (truth_fine), so that inverse-CDF bin flips cannot dominate the comparison; the primary level of two recursion
+fixtures (G6) the same way (truth_recursion_level0)."""
 import copy
 import json
 import os
@@ -107,6 +108,52 @@ def truth_fine(base):
           {k: f"{v:.1e}" for k, v in err.items()})
 
 
+def truth_recursion_level0(base):
+    """The primary level of a RECURSION fixture (G6: train.NeRFSystem.forward) in float64.  The keys the wide tolerances are
+    about -- surface_normal_grad_*, normal_dif_* -- belong to the primary render (train.py:132-145 calls render_rays with
+    compute_normal=trace_secondary_rays; the recursion only re-blends rgb_*), so their truth is render_rays in float64 on the
+    fixture's rays, weights and hparams, at the fine depths the fp32 run drew (as truth_fine).  rgb_* of the truth are the
+    UNBLENDED colours: the fixture's rgb_*_direct."""
+    import models.rendering as ref_rendering
+    fx = Fixture(base)
+    hp = fx.meta["hp"]
+    assert hp["N_importance"] > 0 and not hp["only_one_field"] and hp["perturb"] == 0 and hp["noise_std"] == 0
+    sds = fx.state_dicts()
+    mods = {}
+    for name, sd in zip(("coarse", "fine"), sds):
+        mod = MirrorNeRF(in_channels_xyz=63, in_channels_dir=27, predict_normal=True, predict_mirror_mask=True)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        mods[name] = copy.deepcopy(mod).double().eval()
+    zc, zf = fx.outputs["z_vals_coarse"], fx.outputs["z_vals_fine"]
+    new = np.empty((zf.shape[0], hp["N_importance"]), np.float32)
+    for r in range(zf.shape[0]):
+        row = list(zf[r])
+        for v in zc[r]:
+            row.remove(v)
+        new[r] = row
+    orig = ref_rendering.sample_pdf
+    ref_rendering.sample_pdf = lambda bins, weights, n, det=False, eps=1e-5: torch.from_numpy(new).double()
+    try:
+        rays = torch.from_numpy(fx.inputs["rays"]).double()
+        with torch.enable_grad():
+            out = ref_render_rays(mods, EMB, rays, hp["N_samples"], hp["use_disp"], hp["perturb"], hp["noise_std"], hp["N_importance"],
+                                  hp["chunk"], False, compute_normal=hp["trace_secondary_rays"])
+    finally:
+        ref_rendering.sample_pdf = orig
+    out = {k: v.detach().numpy() for k, v in out.items()}
+    dz = float(np.max(np.abs(out["z_vals_fine"] - zf)))
+    assert dz < 1e-5, dz
+    ref_key = lambda k: k + "_direct" if k in ("rgb_coarse", "rgb_fine") else k  # noqa: E731  (the fixture's rgb_* are blended)
+    keep = [k for k in out if ref_key(k) in fx.outputs and out[k].size and out[k].shape == fx.outputs[ref_key(k)].shape]
+    arrs = {"out64__" + k: out[k].astype(np.float64) for k in keep}
+    err = {k: float(np.max(np.abs(out[k] - fx.outputs[ref_key(k)].astype(np.float64)))) for k in keep}
+    arrs["meta"] = np.array(json.dumps({"base": base, "ref32_err": err, "z_fine_max_diff": dz}))
+    path = os.path.join(HERE, f"g14_truth64_{base}.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {os.path.basename(path)} {os.path.getsize(path) / 1024:.0f} KiB; reference fp32 (through NeRFSystem.forward) vs fp64 "
+          "render_rays at the same fine depths:", {k: f"{v:.1e}" for k, v in err.items()})
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "coarse" in only:
@@ -114,3 +161,6 @@ if __name__ == "__main__":
     if not only or "fine" in only:
         truth_fine("g4_fine_train")               # random-init weights, fine pass
         truth_fine("g11_trained_render_train")    # trained weights (fixtures G11), fine pass
+    if not only or "recursion" in only:
+        truth_recursion_level0("g6_train_gt_compact")      # primary level of a recursion fixture
+        truth_recursion_level0("g6_train_pred_straddle")

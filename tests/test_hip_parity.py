@@ -229,6 +229,45 @@ def test_fine_pass_as_close_to_the_fp64_truth_as_the_reference(base, precision):
           {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
 
 
+@pytest.mark.parametrize("base", ["g6_train_gt_compact", "g6_train_pred_straddle"])
+def test_recursion_primary_level_as_close_to_the_fp64_truth_as_the_reference(base, precision):
+    """Fixtures G14 for the RECURSION fixtures (tests/golden/make_golden_truth64.py truth_recursion_level0; VERDICT r4 weak #2: the
+    G6 comparisons of surface_normal_grad_* / normal_dif_* ride on the 2e-2 allowance of the noise-dominated keys).  Those keys are
+    the primary render's (train.py:132-145; the recursion only re-blends rgb_*), so their truth is the reference's render_rays in
+    float64 on the fixture's rays and weights at the fine depths its fp32 run drew.  The HIP render of the same call has to be as
+    close to that truth as the reference's fp32 values in the fixture are: max-abs error within twice the reference's plus
+    roundoff (2e-6 fp32 chain, 1e-5 split arithmetic).  The reference's own fp32 error on these keys is 1e-3 .. 7e-3."""
+    fx = FX.Fixture(base)
+    hp = fx.meta["hp"]
+    sds = fx.state_dicts()
+    models = {"coarse": _module(sds[0]), "fine": _module(sds[1])}
+    rays = torch.from_numpy(fx.inputs["rays"]).to(DEV)
+    got = _np(_M().render_rays(models, _emb(), rays, hp["N_samples"], hp["use_disp"], hp["perturb"], hp["noise_std"], hp["N_importance"],
+                               hp["chunk"], False, compute_normal=hp["trace_secondary_rays"],
+                               _z_fine=torch.from_numpy(fx.outputs["z_vals_fine"]).to(DEV)))
+    z = np.load(os.path.join(os.path.dirname(FX.__file__), f"g14_truth64_{base}.npz"))
+    slack = 2e-6 if precision == "fp32" else 1e-5
+    thresholded = fx.meta.get("gt_mode") == "invalid"      # train.py:155-166: the fixture's predicted masks are the hard ones
+    checked, report = 0, {}
+    for f in z.files:
+        if not f.startswith("out64__"):
+            continue
+        k = f[7:]
+        if thresholded and k.startswith("mirror_mask"):
+            continue
+        truth = z[f]
+        ref32 = fx.outputs[k + "_direct" if k in ("rgb_coarse", "rgb_fine") else k].astype(np.float64)
+        hip = got[k].astype(np.float64)
+        scale = 8.0 if k.startswith(("depth", "x_surface", "z_vals")) else 1.0
+        e_ref, e_hip = np.abs(ref32 - truth), np.abs(hip - truth)
+        report[k] = (float(e_hip.max()), float(e_ref.max()))
+        assert e_hip.max() <= 2.0 * e_ref.max() + slack * scale, (k, e_hip.max(), e_ref.max())
+        checked += 1
+    assert checked >= 18
+    print(f"G14 recursion primary level {base} [{precision}] max |err| vs fp64 truth (hip, reference fp32):",
+          {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
+
+
 # --------------------------------------------------------------------------- G14: against the reference in float64
 def test_as_close_to_the_fp64_truth_as_the_reference(precision):
     """Fixture G14 (tests/golden/make_golden_truth64.py): the reference evaluated in float64 on the inputs of

@@ -433,6 +433,37 @@ def test_oracle_fine_pass_is_as_close_to_the_fp64_truth_as_the_reference(base):
     assert n >= 9
 
 
+@pytest.mark.parametrize("base", ["g6_train_gt_compact", "g6_train_pred_straddle"])
+def test_oracle_recursion_primary_level_is_as_close_to_the_fp64_truth_as_the_reference(base):
+    """Fixtures G14 for two RECURSION fixtures (make_golden_truth64.truth_recursion_level0): the noise-dominated keys of G6
+    (surface_normal_grad_*, normal_dif_*) belong to the primary render -- the recursion only re-blends rgb_* -- so their truth is the
+    reference's render_rays in float64 on the fixture's rays and weights, at the fine depths its fp32 run drew.  The oracle's render
+    of the same call has to be as close to it as the values NeRFSystem.forward left in the fixture."""
+    import os
+    fx = FX.Fixture(base)
+    hp = fx.meta["hp"]
+    sds = fx.state_dicts()
+    got = O.render_rays({"coarse": sds[0], "fine": sds[1]}, EMB, fx.inputs["rays"], hp["N_samples"], hp["use_disp"], hp["perturb"],
+                        hp["noise_std"], hp["N_importance"], hp["chunk"], False, compute_normal=hp["trace_secondary_rays"],
+                        _z_fine=fx.outputs["z_vals_fine"])
+    z = np.load(os.path.join(os.path.dirname(FX.__file__), f"g14_truth64_{base}.npz"))
+    thresholded = fx.meta.get("gt_mode") == "invalid"      # train.py:155-166: the fixture holds the hard predicted masks
+    n = 0
+    for f in z.files:
+        if not f.startswith("out64__"):
+            continue
+        k = f[7:]
+        if thresholded and k.startswith("mirror_mask"):
+            continue
+        truth = z[f]
+        e_ref = np.abs(fx.outputs[k + "_direct" if k in ("rgb_coarse", "rgb_fine") else k].astype(np.float64) - truth)
+        e_orc = np.abs(got[k].astype(np.float64) - truth)
+        scale = 8.0 if k.startswith(("depth", "x_surface", "z_vals")) else 1.0
+        assert e_orc.max() <= 2.0 * e_ref.max() + 2e-6 * scale, (k, e_orc.max(), e_ref.max())
+        n += 1
+    assert n >= 18
+
+
 def test_sh4_against_scipy_real_spherical_harmonics():
     """Config 5 is "parity unpinned" (tinycudann and the CUDA SH extension cannot run here, the reference holds no vectors),
     but its view encoding has an independent closed form: the degree-4 real spherical harmonics.  The oracle's restatement of
