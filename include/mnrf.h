@@ -406,6 +406,16 @@ int mnrf_composite_n(const float* rays, int64_t n_rays, int S, const float* sigm
                      float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
                      float* surf_normal, float* surf_normal_grad, float* normal_dif, float* x_surface,
                      const int32_t* n_live, void* stream);
+/* mnrf_composite_n and the mnrf_sample_fine_n that follows it in a coarse pass (models/rendering.py:181-264, then 312-326) as one
+ * launch: z_fine (n_rays, S + n_importance) from these weights; u / u_per_ray / n_importance as in mnrf_sample_fine.  weights must
+ * not be null.  Same maps, weights and depths bit for bit. */
+int mnrf_composite_sample_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                            const float* noise, const float* rgb, const float* is_mirror,
+                            const float* pred_normal, const float* normal, int white_back,
+                            float* weights, float* opacity, float* rgb_map, float* depth, float* mirror_mask,
+                            float* surf_normal, float* surf_normal_grad, float* normal_dif, float* x_surface,
+                            const float* u, int u_per_ray, int n_importance, float* z_fine,
+                            const int32_t* n_live, void* stream);
 int mnrf_composite_backward_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
                               const float* noise, const float* rgb, const float* is_mirror,
                               const float* pred_normal, const float* normal, int white_back,
@@ -427,6 +437,10 @@ int mnrf_reflect_compact_n(const float* rays, const float* x_surface, const floa
                            int32_t* slot /* (n_rays) or null: the inverse of `index` -- the row of sec_rays ray i went to, -1 where it
                                             was not selected: what the gather-form blend below reads */,
                            void* stream);
+/* mnrf_reflect_backward in gather form through `slot` (the static route): every live ray's row of the three outputs is written -- zeros
+ * where the ray was not reflected -- so nothing is zero-filled in front; same values.  n_live: the live rows of the INPUT rays. */
+int mnrf_reflect_backward_gather_n(const float* rays, const float* normal, const int32_t* slot, const float* g_sec, int64_t n_rays,
+                                   float* g_x_surface, float* g_normal, float* g_rays, const int32_t* n_live, void* stream);
 /* Both blends of a recursion level (rgb_coarse and rgb_fine, train.py:263-296) in one launch, gather form through `slot`:
  * out = m * part + (1 - m) * base, part = sec[slot[i]] where ray i was reflected and base[i] where not -- mnrf_blend_scatter's
  * expressions, bit-identical values.  Tensor b (or a) may be null.  Backward: g_base = (1 - m) g_out for every live row, g_sec[slot[i]]
@@ -481,6 +495,9 @@ int mnrf_adam_prep(const double* hyper, int64_t* step, const int32_t* skipped, c
                    const uint32_t* const* guard_words, int n_guard_words, float* state, void* stream);
 int mnrf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* state,
                        int32_t* skipped, void* stream);
+/* mnrf_adam_step_dev for up to 4 flat tensors in ONE launch (a step's coarse and fine model): arrays of n_tensors entries each. */
+int mnrf_adam_step_dev_n(int n_tensors, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                         const int64_t* n, const float* state, int32_t* const* skipped, void* stream);
 
 /* ---- hash-grid field, BASELINE config 5 (models/mirror_nerf_tcnn.py:151-259) ---------------------
  * table: (entries, 2) fp32 hash-grid features; offsets17_host: 17 level offsets in entries (HOST);

@@ -120,6 +120,8 @@ SIGNATURES = {
     "mnrf_ray_fan_backward_n": (_int, [_c_f] * 7 + [_i64, _int, _c_f, _c_i, _str]),
     "mnrf_composite_n": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
                                 _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
+    "mnrf_composite_sample_n": (_int, [_c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int,
+                                       _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _int, _int, _c_f, _c_i, _str]),
     "mnrf_composite_backward_n": (_int, [_c_f, _i64, _int] + [_c_f] * 7 + [_int] + [_c_f] * 17 + [_int, _c_f, _c_i, _str]),
     "mnrf_sample_fine_n": (_int, [_c_f, _c_f, _i64, _int, _c_f, _int, _int, _c_f, _c_i, _str]),
     "mnrf_threshold_mask_n": (_int, [_c_f, _i64, _c_i, _c_i, _str]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "mnrf_blend2_n": (_int, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _i64, _int, _c_f, _c_f, _c_i, _str]),
     "mnrf_blend2_backward_n": (_int, [_c_f, _c_f, _c_i, _c_f, _i64, _int, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_blend_scatter_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),
+    "mnrf_reflect_backward_gather_n": (_int, [_c_f, _c_f, _c_i, _c_f, _i64, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_reflect_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _c_f, _i64, _c_f, _c_f, _c_f, _c_i, _str]),
     "mnrf_blend_backward_n": (_int, [_c_f, _c_f, _c_i, _i64, _i64, _int, _c_f, _c_f, _c_i, _c_i, _str]),
     "mnrf_ray_grads_n": (_int, [_c_f, _c_f, _c_f, _i64, _int, _c_f, _c_f, _c_i, _str]),
@@ -141,6 +144,7 @@ SIGNATURES = {
                                  ctypes.POINTER(ctypes.c_int), _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _str]),
     "mnrf_adam_prep": (_int, [ctypes.c_void_p, ctypes.c_void_p, _c_i, _c_f, _c_f, ctypes.POINTER(ctypes.c_void_p), _int, _c_f, _str]),
     "mnrf_adam_step_dev": (_int, [_c_f, _c_f, _c_f, _c_f, _i64, _c_f, _c_i, _str]),
+    "mnrf_adam_step_dev_n": (_int, [_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _c_f, ctypes.POINTER(ctypes.c_void_p), _str]),
 }
 
 _lib = None

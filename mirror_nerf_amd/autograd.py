@@ -25,10 +25,13 @@ class CompositeFn(torch.autograd.Function):
     Differentiable inputs: rays (through x_surface), sigma, rgb, is_mirror, pred_normal, normal."""
 
     @staticmethod
-    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back, detach=0, keep_mirror=None, n_live=None):
+    def forward(ctx, rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, white_back, detach=0, keep_mirror=None, n_live=None,
+                resample=None):
         """detach: MNRF_DETACH_W_MASK | MNRF_DETACH_W_NORMAL; keep_mirror: (N,) float, 0 = that ray's mirror mask sees
         weights.detach() (models/rendering.py:223-247: the --detach_density_* options; values are unaffected).
-        n_live: device int32 (1,) or None -- the rays that exist, N being the capacity (include/mnrf.h "live row counts")."""
+        n_live: device int32 (1,) or None -- the rays that exist, N being the capacity (include/mnrf.h "live row counts").
+        resample: None, or (u, n_importance) -- the resampling that follows a coarse pass in the same launch (mnrf_composite_sample_n):
+        a tenth output, z_fine (N, S + n_importance), not differentiable (the reference detaches the weights there, rendering.py:335)."""
         N, S = z.shape
         dev = z.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -44,7 +47,16 @@ class CompositeFn(torch.autograd.Function):
         nd = f(N) if (sn is not None and sng is not None) else None
         xs = f(N, 3) if full else None
         p = _lib.ptr
-        if N:
+        z_fine = None
+        if N and resample is not None:
+            u, n_imp = resample
+            u = u.float().contiguous()
+            z_fine = f(N, S + n_imp)
+            _lib.check(_lib.lib().mnrf_composite_sample_n(
+                p(rays), N, S, p(sigma), p(z), p(noise), p(rgb), p(is_mirror), p(pred_normal), p(normal),
+                int(bool(white_back)), p(weights), p(opacity), p(rgb_map), p(depth), p(mask), p(sn), p(sng), p(nd),
+                p(xs), p(u), 1 if u.dim() == 2 else 0, int(n_imp), p(z_fine), p(n_live), _lib.stream()), "mnrf_composite_sample_n")
+        elif N:
             _lib.check(_lib.lib().mnrf_composite_n(
                 p(rays), N, S, p(sigma), p(z), p(noise), p(rgb), p(is_mirror), p(pred_normal), p(normal),
                 int(bool(white_back)), p(weights), p(opacity), p(rgb_map), p(depth), p(mask), p(sn), p(sng), p(nd),
@@ -57,11 +69,15 @@ class CompositeFn(torch.autograd.Function):
         ctx.present = (rgb_map is not None, depth is not None, mask is not None, sn is not None, sng is not None,
                        nd is not None, xs is not None)
         outs = (weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs)
-        ctx.mark_non_differentiable(*[o for o in () if o is not None])
+        if resample is not None:
+            if z_fine is None:
+                z_fine = f(N, S + resample[1])
+            ctx.mark_non_differentiable(z_fine)
+            return outs + (z_fine,)
         return outs
 
     @staticmethod
-    def backward(ctx, g_w, g_op, g_rgb, g_depth, g_mask, g_sn, g_sng, g_nd, g_xs):
+    def backward(ctx, g_w, g_op, g_rgb, g_depth, g_mask, g_sn, g_sng, g_nd, g_xs, _g_zf=None):
         rays, sigma, z, noise, rgb, is_mirror, pred_normal, normal, depth = ctx.saved_tensors
         N, S = z.shape
         dev = z.device
@@ -89,7 +105,7 @@ class CompositeFn(torch.autograd.Function):
         return (d_rays, like(d_sigma, sigma), None, None, like(d_rgb, rgb) if rgb is not None else None,
                 like(d_m, is_mirror) if is_mirror is not None else None,
                 like(d_pn, pred_normal) if pred_normal is not None else None,
-                like(d_n, normal) if normal is not None else None, None, None, None, None)
+                like(d_n, normal) if normal is not None else None, None, None, None, None, None)
 
 
 class FieldFn(torch.autograd.Function):
@@ -463,6 +479,7 @@ class ReflectFn(torch.autograd.Function):
             p(rays), p(x_surface), p(normal), None, 0.0, p(_c(mask.float())) if mask is not None else None, N,
             int(bool(compact)), 0.1, p(sec), p(index), p(count), p(rdir), p(n_live), p(slot), _lib.stream()), "mnrf_reflect_compact")
         ctx.static = bool(static)
+        ctx.n_live = n_live
         if static:
             ctx.count = count
             ctx.slot = slot      # (not an autograd output: recursion._static_level picks it up from the count tensor)
@@ -487,9 +504,14 @@ class ReflectFn(torch.autograd.Function):
         p = _lib.ptr
         if g_sec is None:
             return torch.zeros_like(rays), torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev), None, None, None, None
-        _lib.check(_lib.lib().mnrf_reflect_backward_n(
-            p(rays), p(normal), p(index) if ctx.compact else None, M, p(g_sec.contiguous().float()), N, p(g_xs), p(g_n),
-            p(g_rays), p(ctx.count), _lib.stream()), "mnrf_reflect_backward")
+        if ctx.static:     # gather form through the inverse index (identity when not compacted): one launch, nothing zero-filled in front
+            _lib.check(_lib.lib().mnrf_reflect_backward_gather_n(
+                p(rays), p(normal), p(ctx.slot), p(g_sec.contiguous().float()), N, p(g_xs), p(g_n), p(g_rays), p(ctx.n_live),
+                _lib.stream()), "mnrf_reflect_backward_gather_n")
+        else:
+            _lib.check(_lib.lib().mnrf_reflect_backward_n(
+                p(rays), p(normal), p(index) if ctx.compact else None, M, p(g_sec.contiguous().float()), N, p(g_xs), p(g_n),
+                p(g_rays), p(ctx.count), _lib.stream()), "mnrf_reflect_backward")
         return g_rays, g_xs, g_n, None, None, None, None
 
 

@@ -519,32 +519,37 @@ __global__ void dwp_finish_kernel(DwpFinishArgs F) {
     }
 }
 
-// Tail of a grid-wide maximum of non-negative floats (ordered like their bit patterns).  pair == null: atomicMax into *out (zeroed by
-// a launch in front).  Else `pair` = {value, done}, zero between launches: every wave folds its maximum into pair[0], the last
-// workgroup out stores the result to *out with a plain store and resets both words -- one launch, nothing to zero.
+// Tail of a grid-wide maximum of non-negative floats (ordered like their bit patterns).  The workgroup folds its waves' maxima in
+// LDS first (every atomic of the grid goes to the same two words and they serialise at ~10 ns each: one per workgroup, not one per
+// wave).  pair == null: atomicMax into *out (zeroed by a launch in front).  Else `pair` = {value, done}, zero between launches: the
+// last workgroup out stores the result to *out with a plain store and resets both words -- one launch, nothing to zero.
+constexpr int MAX_THREADS = 1024;      // workgroup size of the two maximum kernels: one sample per thread up to 256 K samples
 __device__ __forceinline__ void grid_max_tail(float mx, unsigned* __restrict__ out, unsigned* __restrict__ pair) {
+    __shared__ float wave_max[MAX_THREADS / 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int waves = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < waves; ++w) mx = fmaxf(mx, wave_max[w]);
     if (!pair) {
-        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
+        if (mx > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, mx));
         return;
     }
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(pair, __builtin_bit_cast(unsigned, mx));
+    if (mx > 0.f) atomicMax(pair, __builtin_bit_cast(unsigned, mx));
     __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (atomicAdd(pair + 1, 1u) == gridDim.x - 1) {
-            __threadfence();
-            *out = atomicExch(pair, 0u);
-            atomicExch(pair + 1, 0u);
-        }
+    if (atomicAdd(pair + 1, 1u) == gridDim.x - 1) {
+        __threadfence();
+        *out = atomicExch(pair, 0u);
+        atomicExch(pair + 1, 0u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------- seed maximum
 // The seeds (pre-activation gradients of the four output layers) exactly as field_split_bwd_kernel's prologue forms them --
 // same expressions, same order, -ffp-contract=off in both translation units -- reduced to the largest magnitude.
-__global__ void seed_max_kernel(const float* __restrict__ g_sigma, const float* __restrict__ g_rgb, const float* __restrict__ g_pn,
+__global__ __launch_bounds__(MAX_THREADS) void seed_max_kernel(const float* __restrict__ g_sigma, const float* __restrict__ g_rgb, const float* __restrict__ g_pn,
                                 const float* __restrict__ g_m, const float* __restrict__ rgb, const float* __restrict__ pn,
                                 const float* __restrict__ is_mirror, const float* __restrict__ save_inv, long long B,
                                 unsigned* __restrict__ out, const int* __restrict__ n_live, int spr, unsigned* __restrict__ pair) {
@@ -589,16 +594,18 @@ void launch_seed_max(const float* g_sigma, const float* g_rgb, const float* g_pn
                      const float* pn, const float* is_mirror, const float* save_inv, long long B, unsigned* out, hipStream_t s,
                      const int* n_live, int spr, unsigned* pair) {
     if (!pair) zero_fill(s, out, sizeof(unsigned));
-    // four samples per thread, at most 256 workgroups: every workgroup ends in two same-address atomics (the maximum and the ticket
-    // of grid_max_tail), which serialise at ~10 ns each -- 2048 workgroups measured 31 us per launch against 12.6 with 128
-    long long blocks = (B + 1023) / 1024;
+    // 1024-thread workgroups, at most 256 of them (one sample per thread up to 256 K samples: the launch is latency-bound, sixteen
+    // dependent loads per sample).  Every workgroup ends in two same-address atomics (the maximum and the ticket of grid_max_tail),
+    // which serialise at ~10 ns each: 2048 small workgroups measured 31 us per launch against 12.6 with 128 -- and with one atomic per
+    // WAVE (as it was through round 4) 14-18 us against 7-9 now.
+    long long blocks = (B + MAX_THREADS - 1) / MAX_THREADS;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
+    hipLaunchKernelGGL(seed_max_kernel, dim3((unsigned)blocks), dim3(MAX_THREADS), 0, s, g_sigma, g_rgb, g_pn, g_m, rgb, pn, is_mirror,
                        save_inv, B, out, n_live, spr, pair);
 }
 
 // largest |J^| (the seed of the second-order pass) exactly as field_split_bwd2_kernel's prologue forms it
-__global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float* __restrict__ normal, const float* __restrict__ save_invj,
+__global__ __launch_bounds__(MAX_THREADS) void jhat_max_kernel(const float* __restrict__ g_normal, const float* __restrict__ normal, const float* __restrict__ save_invj,
                                 long long B, unsigned* __restrict__ out, const int* __restrict__ n_live, int spr, unsigned* __restrict__ pair) {
     if (n_live) {      // live row count: B is the capacity
         long long bl = (long long)*n_live * spr;
@@ -625,9 +632,9 @@ __global__ void jhat_max_kernel(const float* __restrict__ g_normal, const float*
 void launch_jhat_max(const float* g_normal, const float* normal, const float* save_invj, long long B, unsigned* out, hipStream_t s,
                      const int* n_live, int spr, unsigned* pair) {
     if (!pair) zero_fill(s, out, sizeof(unsigned));
-    long long blocks = (B + 1023) / 1024;
+    long long blocks = (B + MAX_THREADS - 1) / MAX_THREADS;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_normal, normal, save_invj, B, out, n_live, spr, pair);
+    hipLaunchKernelGGL(jhat_max_kernel, dim3((unsigned)blocks), dim3(MAX_THREADS), 0, s, g_normal, normal, save_invj, B, out, n_live, spr, pair);
 }
 
 // ---------------------------------------------------------------------------------------------------------- driver

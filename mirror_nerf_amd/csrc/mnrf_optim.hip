@@ -30,7 +30,7 @@ struct AdamArgs {
     const float* state;
 };
 
-__global__ void adam_kernel(AdamArgs A) {
+__device__ __forceinline__ void adam_body(AdamArgs A) {
     // thread 0 reads the scalars of the step once per block and leaves what the others need in LDS
     __shared__ float sh[8];
     if (threadIdx.x == 0) {
@@ -97,6 +97,17 @@ __global__ void adam_kernel(AdamArgs A) {
             if (i4 + c < A.n) { A.p[i4 + c] = p[c]; A.m[i4 + c] = m[c]; A.v[i4 + c] = v[c]; }
     }
 }
+
+
+__global__ void adam_kernel(AdamArgs A) { adam_body(A); }
+
+// the same for up to ADAM_BATCH flat tensors in one launch (blockIdx.y = tensor): a training step updates its coarse and its fine
+// model behind ONE prep launch (mnrf_adam_step_dev_n)
+constexpr int ADAM_BATCH = 4;
+struct AdamBatch {
+    AdamArgs a[ADAM_BATCH];
+};
+__global__ void adam_batch_kernel(AdamBatch B) { adam_body(B.a[blockIdx.y]); }
 
 }  // namespace mnrf
 
@@ -170,4 +181,26 @@ extern "C" int mnrf_adam_step_dev(float* param, const float* grad, float* exp_av
     const long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_adam_step_dev");
+}
+
+extern "C" int mnrf_adam_step_dev_n(int n_tensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                                    float* const* exp_avg_sq, const int64_t* n, const float* state, int32_t* const* skipped, void* stream) {
+    using namespace mnrf;
+    if (n_tensors < 0 || n_tensors > ADAM_BATCH) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev_n: 0..4 tensors per call");
+    if (n_tensors == 0) return MNRF_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !n || !skipped || !state) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev_n: null pointer");
+    AdamBatch B{};
+    long long most = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (!param[t] || !grad[t] || !exp_avg[t] || !exp_avg_sq[t] || !skipped[t]) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev_n: null pointer");
+        if (n[t] < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev_n: n >= 0");
+        if (((uintptr_t)param[t] | (uintptr_t)grad[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) & 15)
+            return mnrf_fail(MNRF_ERR_ARG, "mnrf_adam_step_dev_n: tensors must be 16-byte aligned");
+        B.a[t] = AdamArgs{param[t], grad[t], exp_avg[t], exp_avg_sq[t], (long long)n[t], 0.f, 0.f, 0.f, 0.0, 0.0, 1, skipped[t], nullptr, nullptr, state};
+        most = n[t] > most ? n[t] : most;
+    }
+    if (most == 0) return MNRF_OK;
+    const long long threads = (most + 3) / 4;
+    hipLaunchKernelGGL(adam_batch_kernel, dim3((unsigned)((threads + 255) / 256), n_tensors), dim3(256), 0, (hipStream_t)stream, B);
+    return mnrf_check_launch("mnrf_adam_step_dev_n");
 }

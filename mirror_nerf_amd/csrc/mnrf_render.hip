@@ -310,19 +310,16 @@ __device__ __forceinline__ void sort_store(const float* srt, int lane, float* ou
     }
 }
 
-__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
-                                                          long long n_rays, int S, const float* __restrict__ u, int u_per_ray,
-                                                          int n_imp, float* __restrict__ z_fine, const int* __restrict__ n_live) {
+// body of the resampling for the ray of this wavefront (`ray` < n_rays; live = false: a wave past the last ray, which runs along on
+// the last ray for the barriers and stores nothing).  All four waves of the workgroup must call it.
+__device__ __forceinline__ void sample_fine_ray(const float* __restrict__ z_coarse, const float* __restrict__ weights, long long ray,
+                                                bool live, int S, const float* __restrict__ u, int u_per_ray, int n_imp,
+                                                float* __restrict__ z_fine) {
     __shared__ float s_cdf[4][256];
     __shared__ float s_bin[4][256];
     __shared__ float s_sort[4][SF_MAX];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    long long ray = (long long)blockIdx.x * 4 + wv;
-    n_rays = live_rows(n_rays, n_live);
-    if ((long long)blockIdx.x * 4 >= n_rays) return;      // (the whole workgroup: the barriers below stay uniform)
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
     const float* zc = z_coarse + ray * S;
     const float* wc = weights + ray * S;
     const int nw = S - 2;          // weights[:, 1:-1]
@@ -382,6 +379,39 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     else if (P2 == 128) sort_store<2>(srt, lane, live ? z_fine + ray * T : nullptr, T);
     else if (P2 == 256) sort_store<4>(srt, lane, live ? z_fine + ray * T : nullptr, T);
     else sort_store<8>(srt, lane, live ? z_fine + ray * T : nullptr, T);
+}
+
+__global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
+                                                          long long n_rays, int S, const float* __restrict__ u, int u_per_ray,
+                                                          int n_imp, float* __restrict__ z_fine, const int* __restrict__ n_live) {
+    long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    n_rays = live_rows(n_rays, n_live);
+    if ((long long)blockIdx.x * 4 >= n_rays) return;      // (the whole workgroup: the barriers of the body stay uniform)
+    const bool live = ray < n_rays;
+    if (!live) ray = n_rays - 1;
+    sample_fine_ray(z_coarse, weights, ray, live, S, u, u_per_ray, n_imp, z_fine);
+}
+
+// Compositing of a pass and the resampling that follows it (models/rendering.py:181-264, then 312-326) in ONE launch: both are
+// "one wavefront per ray, four rays per workgroup", and the resampling reads nothing but the weights the same wavefront has just
+// written (made visible to the workgroup by the fence + barrier).  Same bodies: the same maps, weights and depths bit for bit.
+__global__ __launch_bounds__(256) void composite_sample_kernel(CompArgs A, const float* __restrict__ u, int u_per_ray, int n_imp,
+                                                               float* __restrict__ z_fine) {
+    const int lane = threadIdx.x & 63;
+    long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_rays = live_rows(A.n_rays, A.n_live);
+    if ((long long)blockIdx.x * 4 >= n_rays) return;
+    const bool live = ray < n_rays;
+    if (live) {
+        const CompGlobalSrc src{A, ray};
+        const CompMaps out{A.weights + ray * A.S, A.opacity, A.rgb_map, A.depth, A.mirror_mask, A.surf_normal,
+                           A.surf_normal_grad, A.normal_dif, A.x_surface, A.rays, A.white_back};
+        composite_ray(src, A.S, lane, ray, out);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (!live) ray = n_rays - 1;
+    sample_fine_ray(A.z, A.weights, ray, live, A.S, u, u_per_ray, n_imp, z_fine);
 }
 
 // ------------------------------------------------------------------ mask threshold
@@ -627,6 +657,53 @@ __global__ void reflect_backward_kernel(const float* __restrict__ rays, const fl
     g_rays[i * 8 + 7] = g_sec[j * 8 + 7];                           // far is passed through
 }
 
+// The same in GATHER form through the compaction's inverse index (slot[i] = row of sec_rays ray i went to, -1: not reflected): one
+// thread per ray writes its row of all three outputs -- zeros where nothing was reflected -- so nothing has to be zero-filled in front
+// (the scatter form above: a zeroing launch + this one).  Same expressions: bit-identical values.
+__global__ void reflect_backward_gather_kernel(const float* __restrict__ rays, const float* __restrict__ normal,
+                                               const int* __restrict__ slot, const float* __restrict__ g_sec, long long n_rays,
+                                               float* __restrict__ g_xs, float* __restrict__ g_normal, float* __restrict__ g_rays,
+                                               const int* __restrict__ n_live) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= live_rows(n_rays, n_live)) return;
+    const long long j = slot[i];
+    float* gx = g_xs + i * 3;
+    float* gn = g_normal + i * 3;
+    float* gy = g_rays + i * 8;
+    if (j < 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gx[k] = 0.f; gn[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gy[k] = 0.f;
+        return;
+    }
+    float nv[3], wv[3], gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nv[k] = normal[i * 3 + k]; wv[k] = -rays[i * 8 + 3 + k]; gr[k] = g_sec[j * 8 + 3 + k]; }
+    const float nsq = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2];
+    const float wsq = wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2];
+    const float ninv = 1.f / sqrtf(fmaxf(nsq, EPS32)), winv = 1.f / sqrtf(fmaxf(wsq, EPS32));
+    float nh[3], wh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nh[k] = nv[k] * ninv; wh[k] = wv[k] * winv; }
+    const float c = wh[0] * nh[0] + wh[1] * nh[1] + wh[2] * nh[2];
+    const float grn = gr[0] * nh[0] + gr[1] * nh[1] + gr[2] * nh[2];
+    float gnh[3], gwh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gnh[k] = 2.f * grn * wh[k] + 2.f * c * gr[k]; gwh[k] = 2.f * grn * nh[k] - gr[k]; }
+    const float pn = nsq > EPS32 ? nh[0] * gnh[0] + nh[1] * gnh[1] + nh[2] * gnh[2] : 0.f;
+    const float pw = wsq > EPS32 ? wh[0] * gwh[0] + wh[1] * gwh[1] + wh[2] * gwh[2] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gx[k] = g_sec[j * 8 + k];
+        gn[k] = (gnh[k] - nh[k] * pn) * ninv;
+        gy[k] = 0.f;
+        gy[3 + k] = -(gwh[k] - wh[k] * pw) * winv;
+    }
+    gy[6] = 0.f;
+    gy[7] = g_sec[j * 8 + 7];
+}
+
 // blend: out = m*part + (1-m)*base, part = sec scattered by index (rows without a source: base.detach())
 __global__ void blend_backward_kernel(const float* __restrict__ g_out, const float* __restrict__ mask, long long n, int c,
                                       float* __restrict__ g_base, const int* __restrict__ n_live) {
@@ -787,7 +864,8 @@ static int composite_impl(const float* rays, int64_t n_rays, int S, const float*
                           const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
                           const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
                           float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
-                          float* normal_dif, float* x_surface, const int32_t* n_live, void* stream) {
+                          float* normal_dif, float* x_surface, const int32_t* n_live, void* stream,
+                          const float* u = nullptr, int u_per_ray = 0, int n_importance = 0, float* z_fine = nullptr) {
     if (n_rays < 0 || S < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: bad size");
     if (n_rays == 0) return MNRF_OK;
     if (!sigma || !z_vals) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: sigma and z_vals are required");
@@ -799,6 +877,15 @@ static int composite_impl(const float* rays, int64_t n_rays, int S, const float*
     if (x_surface && !rays) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite: x_surface needs rays");
     CompArgs A{rays, (long long)n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back,
                weights, opacity, rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, n_live};
+    if (z_fine) {      // mnrf_composite_sample_n: the resampling of mnrf_sample_fine behind the compositing, same launch
+        if (S < 3 || n_importance < 1) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_sample_n: bad size");
+        if (S > 256 || S + n_importance > SF_MAX)
+            return mnrf_fail(MNRF_ERR_UNSUPPORTED, "mnrf_composite_sample_n: needs S <= 256 and S + n_importance <= 512");
+        if (!u || !weights) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_sample_n: null pointer (u, weights)");
+        hipLaunchKernelGGL(composite_sample_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A, u, u_per_ray,
+                           n_importance, z_fine);
+        return mnrf_check_launch("mnrf_composite_sample_n");
+    }
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, A);
     return mnrf_check_launch("mnrf_composite");
 }
@@ -817,6 +904,18 @@ extern "C" int mnrf_composite_n(const float* rays, int64_t n_rays, int S, const 
                                 float* normal_dif, float* x_surface, const int32_t* n_live, void* stream) {
     return composite_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, opacity,
                           rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, n_live, stream);
+}
+
+extern "C" int mnrf_composite_sample_n(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
+                                       const float* noise, const float* rgb, const float* is_mirror, const float* pred_normal,
+                                       const float* normal, int white_back, float* weights, float* opacity, float* rgb_map,
+                                       float* depth, float* mirror_mask, float* surf_normal, float* surf_normal_grad,
+                                       float* normal_dif, float* x_surface, const float* u, int u_per_ray, int n_importance,
+                                       float* z_fine, const int32_t* n_live, void* stream) {
+    if (!z_fine) return mnrf_fail(MNRF_ERR_ARG, "mnrf_composite_sample_n: z_fine is null");
+    return composite_impl(rays, n_rays, S, sigma, z_vals, noise, rgb, is_mirror, pred_normal, normal, white_back, weights, opacity,
+                          rgb_map, depth, mirror_mask, surf_normal, surf_normal_grad, normal_dif, x_surface, n_live, stream, u, u_per_ray,
+                          n_importance, z_fine);
 }
 
 static int composite_backward_impl(const float* rays, int64_t n_rays, int S, const float* sigma, const float* z_vals,
@@ -1013,6 +1112,18 @@ extern "C" int mnrf_reflect_backward_n(const float* rays, const float* normal, c
                                        const float* g_sec, int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays,
                                        const int32_t* n_sec_live, void* stream) {
     return reflect_backward_impl(rays, normal, index, n_sec, g_sec, n_rays, g_x_surface, g_normal, g_rays, n_sec_live, stream);
+}
+
+extern "C" int mnrf_reflect_backward_gather_n(const float* rays, const float* normal, const int32_t* slot, const float* g_sec,
+                                              int64_t n_rays, float* g_x_surface, float* g_normal, float* g_rays, const int32_t* n_live,
+                                              void* stream) {
+    if (n_rays < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward_gather_n: bad size");
+    if (n_rays == 0) return MNRF_OK;
+    if (!rays || !normal || !slot || !g_sec || !g_x_surface || !g_normal || !g_rays)
+        return mnrf_fail(MNRF_ERR_ARG, "mnrf_reflect_backward_gather_n: null pointer");
+    hipLaunchKernelGGL(reflect_backward_gather_kernel, dim3(blocks_for(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rays, normal, slot,
+                       g_sec, (long long)n_rays, g_x_surface, g_normal, g_rays, n_live);
+    return mnrf_check_launch("mnrf_reflect_backward_gather_n");
 }
 
 static int blend_backward_impl(const float* g_out, const float* mask, const int32_t* index, int64_t n_sec, int64_t n, int c,

@@ -48,6 +48,20 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """A constant 1.0 on `device` to hand to `loss.backward(gradient=...)`: torch then makes no tensor of ones for the root (one fill
+    launch per step), and the fused loss recognises it by its address and returns its gradients unscaled (x 1.0 is the identity: one
+    multi-tensor launch per step less).  Any other gradient -- a GradScaler's scale -- takes the general path."""
+    key = str(device)
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 class _TotalLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, batch, keys, *tensors):
@@ -138,6 +152,9 @@ class _TotalLossFn(torch.autograd.Function):
         # device has nothing else queued)
         if g_sum is None:
             return (None, None, None) + (None,) * len(ctx.grads)
+        unit = _UNIT.get(str(g_sum.device))
+        if unit is not None and g_sum.data_ptr() == unit.data_ptr():      # losses.unit_gradient: the factor is exactly 1
+            return (None, None, None) + tuple(None if g is None else g.reshape(shape) for g, shape in zip(ctx.grads, ctx.shapes))
         have = [g for g in ctx.grads if g is not None]
         scaled = iter(torch._foreach_mul(have, g_sum) if have else [])
         outs = [None if g is None else next(scaled).reshape(shape) for g, shape in zip(ctx.grads, ctx.shapes)]

@@ -328,8 +328,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             mir = None
         if not getattr(model, "predict_normal", True):
             pn = None
-        weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
-            rays_c, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live)
+        fused_u = resample_u() if noise_key == "_noise_coarse" else None
+        if fused_u is not None:      # the resampling that follows this pass rides in the compositing launch (mnrf_composite_sample_n)
+            weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs, zf = CompositeFn.apply(
+                rays_c, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live,
+                (fused_u, N_importance))
+            results["_z_fine_fused"] = zf
+        else:
+            weights, opacity, rgb_map, depth, mask, sn, sng, nd, xs = CompositeFn.apply(
+                rays_c, sigma.view(N, S), z, noise, rgb, mir, pn, nrm, bool(white_back), comp_detach, keep_mirror, n_live)
         results[f"weights_{typ}"] = weights
         results[f"opacity_{typ}"] = opacity
         results[f"z_vals_{typ}"] = z
@@ -347,19 +354,36 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             results[f"normal_dif_{typ}"] = nd
         results[f"_x_surface_{typ}"] = xs
 
+    def given_u():
+        u = kwargs.get("_u")
+        if u is None and perturb == 0:
+            u = kwargs.get("_u_det")
+        if u is None and pool_u is not None:
+            u = pool_u[N * N_samples:].view(N, N_importance)
+        return u
+
+    def resample_u():
+        """The inverse-CDF positions of the resampling behind the first pass, when it will happen and can ride in that pass's
+        compositing launch (training; 3 <= S <= 256, S + N_importance <= 512: mnrf_sample_fine's limits); else None."""
+        will = N_importance > 0 and kwargs.get("_z_fine") is None and N and (
+            kwargs.get("current_epoch", 0) > kwargs.get("only_one_field_fine_epoch", 2) if kwargs.get("only_one_field", False) else has_fine)
+        if not will or not (3 <= N_samples <= 256 and N_samples + N_importance <= 512):
+            return None
+        u = given_u()
+        if u is None:
+            u = _linspace01(N_importance, dev) if perturb == 0 else torch.rand(N, N_importance, device=dev)
+        return u
+
     inference(models["coarse"], "coarse", z_vals, "_noise_coarse")
 
     if N_importance > 0:
         def fine_depths():
             if kwargs.get("_z_fine") is not None:     # tests: the fine depths of another run instead of sample_pdf's
                 return kwargs["_z_fine"].float().contiguous()
-            u = kwargs.get("_u")
-            if u is None and perturb == 0:
-                u = kwargs.get("_u_det")
-            if u is None and pool_u is not None:
-                u = pool_u[N * N_samples:].view(N, N_importance)
+            if "_z_fine_fused" in results:            # made by the first pass's compositing launch
+                return results.pop("_z_fine_fused")
             # weights are detached here, as in the reference (rendering.py:335, 353)
-            return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=u, n_live=n_live)
+            return sample_pdf(z_vals, results["weights_coarse"].detach(), N_importance, det=(perturb == 0), u=given_u(), n_live=n_live)
 
         if kwargs.get("only_one_field", False):                           # rendering.py:328-348
             if kwargs.get("current_epoch", 0) > kwargs.get("only_one_field_fine_epoch", 2):
@@ -367,6 +391,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         else:                                                             # rendering.py:349-360
             inference(models["fine"], "fine", fine_depths(), "_noise_fine")
 
+    results.pop("_z_fine_fused", None)
     for typ in ("coarse", "fine"):                                        # rendering.py:362-367
         xs = results.pop(f"_x_surface_{typ}", None)
         if f"depth_{typ}" in results:

@@ -38,6 +38,16 @@ _COLOR_MASK = []
 _COLOR_MASK_RAYS = {}      # (n, device) -> the (n, 8) zero tensor the fused loss takes as `rays` (read by the absent normal terms only)
 
 
+def _backward_unit(loss):
+    """loss.backward() with the constant 1.0 of losses.unit_gradient as the root gradient (no fill launch for the root, no scaling
+    launch inside the fused loss); any loss that is not a float32 CUDA scalar takes the plain call."""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        from .losses import unit_gradient
+        loss.backward(gradient=unit_gradient(loss.device))
+    else:
+        loss.backward()
+
+
 def color_mask_loss(res, target, gt_mask):
     """ColorLoss + MirrorMaskLoss of losses.py (7-51, 175-198) in their default form: the reference's TotalLoss restricted to the
     two terms that read no normal_* key (so the backward has no second-order pass), evaluated by the fused loss kernel
@@ -174,7 +184,7 @@ def train_step(system, optimizer, rays, target, gt_mask, loss_fn=color_mask_loss
             late = False
         loss = loss_fn(res, target, gt_mask, rays) if getattr(loss_fn, "needs_rays", False) else loss_fn(res, target, gt_mask)
         optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        _backward_unit(loss)
         return loss
     loss = fwd_bwd()
     if collective:
@@ -382,13 +392,21 @@ class FlatAdam:
         gw = (ctypes.c_void_p * max(1, len(guard_words)))(*[w.data_ptr() for w in guard_words]) if guard_words else None
         _lib.check(L.mnrf_adam_prep(self._hyper.data_ptr(), self._step_dev.data_ptr(), p(self._skipped[0]), p(gs), p(fi), gw,
                                     len(guard_words), p(self._state_dev), _lib.stream()), "mnrf_adam_prep")
-        for i, (m, fp) in enumerate(zip(self.modules, self.flats)):
+        grads = []
+        for m, fp in zip(self.modules, self.flats):
             flat = D._flat_bucket(m)
             if flat is None:
                 flat, _copied = D._module_message(m)
             fp.grad = flat
-            _lib.check(L.mnrf_adam_step_dev(p(fp.data), p(flat.contiguous()), p(self._m[i]), p(self._v[i]), fp.numel(),
-                                            p(self._state_dev), p(self._skipped[i]), _lib.stream()), "mnrf_adam_step_dev")
+            grads.append(flat.contiguous())
+        k = len(self.flats)
+        for i0 in range(0, k, 4):          # all models of the step in one launch (mnrf_adam_step_dev_n takes up to four tensors)
+            idx = range(i0, min(k, i0 + 4))
+            vp = lambda ts: (ctypes.c_void_p * len(idx))(*[t.data_ptr() for t in ts])  # noqa: E731
+            _lib.check(L.mnrf_adam_step_dev_n(len(idx), vp([self.flats[i].data for i in idx]), vp([grads[i] for i in idx]),
+                                              vp([self._m[i] for i in idx]), vp([self._v[i] for i in idx]),
+                                              (ctypes.c_int64 * len(idx))(*[self.flats[i].numel() for i in idx]), p(self._state_dev),
+                                              vp([self._skipped[i] for i in idx]), _lib.stream()), "mnrf_adam_step_dev_n")
         self._gs = self._fi = None
 
     def state_dict(self):
@@ -451,7 +469,7 @@ class GraphedTrainStep:
         fn = self.loss_fn
         loss = fn(res, self.target, self.gt, self.rays) if getattr(fn, "needs_rays", False) else fn(res, self.target, self.gt)
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        _backward_unit(loss)
         # a saturated step must not reach the weights: the guard words of the models' packed images veto the update inside the
         # Adam kernel (no torch ops to form a found_inf tensor)
         self._word_views = [m.__dict__["_mnrf_packed"].packed[-1:].view(torch.int32) for m in models]

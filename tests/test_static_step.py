@@ -353,3 +353,40 @@ def test_pack_weights_n_equals_one_by_one():
     many = pack_states(states, many)
     words = [int(t[-1:].view(torch.int32).item()) for t in many]
     assert words[1] != 0 and all(w == 0 for k, w in enumerate(words) if k != 1)
+
+
+def test_composite_sample_equals_composite_then_sample_fine():
+    """mnrf_composite_sample_n = mnrf_composite_n followed by mnrf_sample_fine_n on its weights, bit for bit (maps, weights, depths),
+    with a ragged last workgroup and with a live row count."""
+    from mirror_nerf_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    n, S, n_imp = 203, 64, 64
+    f = lambda *s: torch.empty(*s, device=DEV)  # noqa: E731
+    rays = torch.randn(n, 8, device=DEV, generator=g)
+    z = torch.sort(torch.rand(n, S, device=DEV, generator=g) * 4 + 0.5, dim=1)[0].contiguous()
+    sigma = torch.randn(n, S, device=DEV, generator=g) * 3
+    noise = torch.randn(n, S, device=DEV, generator=g)
+    rgb, pn, gn = (torch.rand(n * S, 3, device=DEV, generator=g) for _ in range(3))
+    mir = torch.rand(n * S, device=DEV, generator=g)
+    for u in (torch.rand(n, n_imp, device=DEV, generator=g), torch.linspace(0, 1, n_imp, device=DEV)):
+        for live in (None, 150):
+            nl = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+            outs = []
+            for fused in (False, True):
+                o = dict(w=f(n, S).fill_(-5), op=f(n).fill_(-5), c=f(n, 3).fill_(-5), d=f(n).fill_(-5), m=f(n).fill_(-5), sn=f(n, 3).fill_(-5),
+                         sg=f(n, 3).fill_(-5), nd=f(n).fill_(-5), xs=f(n, 3).fill_(-5), zf=f(n, S + n_imp).fill_(-5))
+                common = (p(rays), n, S, p(sigma), p(z), p(noise), p(rgb), p(mir), p(pn), p(gn), 0, p(o["w"]), p(o["op"]), p(o["c"]), p(o["d"]),
+                          p(o["m"]), p(o["sn"]), p(o["sg"]), p(o["nd"]), p(o["xs"]))
+                if fused:
+                    _lib.check(L.mnrf_composite_sample_n(*common, p(u), 1 if u.dim() == 2 else 0, n_imp, p(o["zf"]), p(nl), _lib.stream()), "fused")
+                else:
+                    _lib.check(L.mnrf_composite_n(*common, p(nl), _lib.stream()), "composite")
+                    _lib.check(L.mnrf_sample_fine_n(p(z), p(o["w"]), n, S, p(u), 1 if u.dim() == 2 else 0, n_imp, p(o["zf"]), p(nl), _lib.stream()),
+                               "sample_fine")
+                outs.append(o)
+            for k in outs[0]:
+                assert torch.equal(outs[0][k], outs[1][k]), (k, live)
+            rows = n if live is None else live
+            assert bool((outs[1]["zf"][:rows] > 0).all()) and (live is None or bool((outs[1]["zf"][rows:] == -5).all()))
