@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--table-grad", choices=("fixed", "fp32", "f16"), default="fixed", help="nerf_tcnn: how the table gradient is accumulated")
     ap.add_argument("--flat-adam", action="store_true", help="nerf: training.FlatAdam (mnrf_adam_step) instead of torch's fused Adam")
     ap.add_argument("--mlp-f16", action="store_true", help="nerf_tcnn: single-pass f16 MLPs in the forward kernel")
+    ap.add_argument("--route", choices=("host", "static", "graph"), default="host",
+                    help="nerf: host = the reference's control flow (reads the reflected-ray count on the host); static = the count stays on the "
+                         "device; graph = the whole step replayed as one hipGraph (training.GraphedTrainStep; implies --flat-adam)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     M.set_precision(a.precision)
@@ -61,6 +64,8 @@ def main():
     vr, vc, vm = SC.scene_views(1, 64, 64, held_out=True)
     vr_t, vc_t = torch.from_numpy(vr).to(dev), torch.from_numpy(vc).to(dev)
     gamma = 0.1 ** (1.0 / max(1, a.steps))
+    if a.route == "graph":
+        a.flat_adam = True
     if a.flat_adam and a.model == "nerf":
         opt = training.FlatAdam(list(system.models.values()), lr=a.lr)
 
@@ -82,10 +87,15 @@ def main():
         macc = float(((out["mirror_mask_fine"] > 0.5).float().cpu().numpy() == vm).mean())
         return -10 * np.log10(mse), macc
 
+    graphed = training.GraphedTrainStep(system, opt, a.batch, loss_fn, epoch=a.epoch, gt_valid=True) if (a.route == "graph" and a.model == "nerf") else None
     t0 = time.time()
     for it in range(a.steps):
         idx = torch.randint(0, rays_t.shape[0], (a.batch,), device=dev, generator=g)
-        loss = training.train_step(system, opt, rays_t[idx].contiguous(), rgbs_t[idx].contiguous(), masks_t[idx].contiguous(), loss_fn, epoch=a.epoch)
+        if graphed is not None:
+            loss = graphed(rays_t[idx], rgbs_t[idx], masks_t[idx])
+        else:
+            loss = training.train_step(system, opt, rays_t[idx].contiguous(), rgbs_t[idx].contiguous(), masks_t[idx].contiguous(), loss_fn, epoch=a.epoch,
+                                       gt_valid=True if a.route == "static" else None)      # (the analytic scene's masks are 0 / 1: valid)
         sched.step()
         if it % 1000 == 0 or it == a.steps - 1:
             p, macc = val()
