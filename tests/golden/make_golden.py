@@ -73,7 +73,7 @@ def save(name, meta, inputs, outputs, keep_per_sample=True):
             continue
         arrs["out__" + k] = np.asarray(v)
     arrs["meta"] = np.array(json.dumps(meta))
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("MNRF_GOLDEN_OUT", HERE), name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"  wrote {name}.npz  {os.path.getsize(path)/1024:.0f} KiB")
 
@@ -344,7 +344,12 @@ def eval_case(name, n_rays, tweaks, max_level, chunk=32768, rough=False, n_imp=6
 from make_golden_loss import first_order_loss, full_loss, grad_summary  # noqa: E402
 
 
-def grad_case(name, n_rays, loss_fn=None):
+# whole gradient tensors stored by g9_train_grads_full: first trunk layer, the skip layer (319 inputs), the density head, the
+# colour branch's first layer -- of both models (~1 MB)
+FULL_TENSORS = ("xyz_encoding_1.0.weight", "xyz_encoding_5.0.weight", "sigma.weight", "dir_encoding.0.weight")
+
+
+def grad_case(name, n_rays, loss_fn=None, full_tensors=False):
     loss_fn = loss_fn or first_order_loss
     import train as ref_train
 
@@ -369,6 +374,8 @@ def grad_case(name, n_rays, loss_fn=None):
     for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
         for pn_, p_ in mod.named_parameters():
             outs[f"grad__{mname}__{pn_}"] = grad_summary(p_.grad, p_)
+            if full_tensors and pn_ in FULL_TENSORS:      # entry-wise pin of whole tensors, not the 48-entry digest
+                outs[f"gradfull__{mname}__{pn_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).detach().numpy().copy()
     # the reference's own noise floor: the same step in float64
     g32 = {f"{mn}.{pn_}": (p_.grad.clone() if p_.grad is not None else torch.zeros_like(p_))
            for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)) for pn_, p_ in mod.named_parameters()}
@@ -384,6 +391,8 @@ def grad_case(name, n_rays, loss_fn=None):
             a = g32[f"{mn}.{pn_}"].double()
             if g64.abs().max() > 0:
                 floor = max(floor, float((a - g64).abs().max() / g64.abs().max()))
+            if full_tensors and pn_ in FULL_TENSORS:      # the same tensors from the float64 run: the truth both fp32 sides are measured against
+                outs[f"gradfull64__{mn}__{pn_}"] = g64.detach().numpy().astype(np.float32)
     print(f"  reference fp32-vs-fp64 gradient floor (relative to each tensor's max): {floor:.2e}")
     hp_o = dict(N_samples=64, use_disp=False, perturb=0, noise_std=0, N_importance=64, chunk=hp.chunk,
                 trace_secondary_rays=True, only_one_field=False, max_recursive_level=1,
@@ -445,7 +454,7 @@ def main():
         eval_case("g8b_rough_l2_partial", 40, W.STRADDLE, 2, rough=True, only_mirror_rays=True)
     if want("g9"):
         grad_case("g9_train_grads", 64)
-        grad_case("g9_train_grads_full", 64, full_loss)
+        grad_case("g9_train_grads_full", 64, full_loss, full_tensors=True)
 
 
 if __name__ == "__main__":

@@ -124,7 +124,7 @@ def run_case(name, seed, hp_over, stage, epoch, fine=True, invalid_gt=False, val
         arrs["out__" + k] = v
     meta = dict(hp=hp_over, stage=stage, epoch=epoch, seed=seed, rng_seed=1000 + seed)
     arrs["meta"] = np.array(json.dumps(meta))
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("MNRF_GOLDEN_OUT", HERE), name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"    wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
 

@@ -55,7 +55,7 @@ def truth(base):
     arrs = {"out64__" + k: v.astype(np.float64) for k, v in out.items() if k in fx.outputs}
     err = {k: float(np.max(np.abs(out[k] - fx.outputs[k].astype(np.float64)))) for k in out if k in fx.outputs and out[k].size}
     arrs["meta"] = np.array(json.dumps({"base": base, "ref32_err": err}))
-    path = os.path.join(HERE, f"g14_truth64_{base}.npz")
+    path = os.path.join(os.environ.get("MNRF_GOLDEN_OUT", HERE), f"g14_truth64_{base}.npz")
     np.savez_compressed(path, **arrs)
     print(f"wrote {os.path.basename(path)} {os.path.getsize(path) / 1024:.0f} KiB; reference fp32 vs fp64:",
           {k: f"{v:.1e}" for k, v in err.items()})
@@ -102,7 +102,7 @@ def truth_fine(base):
     err = {k: float(np.max(np.abs(out[k] - fx.outputs[k].astype(np.float64)))) for k in out
            if k in fx.outputs and k.endswith("_fine") and out[k].size}
     arrs["meta"] = np.array(json.dumps({"base": base, "ref32_err": err, "z_fine_max_diff": dz}))
-    path = os.path.join(HERE, f"g14_truth64_{base}.npz")
+    path = os.path.join(os.environ.get("MNRF_GOLDEN_OUT", HERE), f"g14_truth64_{base}.npz")
     np.savez_compressed(path, **arrs)
     print(f"wrote {os.path.basename(path)} {os.path.getsize(path) / 1024:.0f} KiB; reference fp32 vs fp64 at the same fine depths:",
           {k: f"{v:.1e}" for k, v in err.items()})
@@ -148,7 +148,7 @@ def truth_recursion_level0(base):
     arrs = {"out64__" + k: out[k].astype(np.float64) for k in keep}
     err = {k: float(np.max(np.abs(out[k] - fx.outputs[ref_key(k)].astype(np.float64)))) for k in keep}
     arrs["meta"] = np.array(json.dumps({"base": base, "ref32_err": err, "z_fine_max_diff": dz}))
-    path = os.path.join(HERE, f"g14_truth64_{base}.npz")
+    path = os.path.join(os.environ.get("MNRF_GOLDEN_OUT", HERE), f"g14_truth64_{base}.npz")
     np.savez_compressed(path, **arrs)
     print(f"wrote {os.path.basename(path)} {os.path.getsize(path) / 1024:.0f} KiB; reference fp32 (through NeRFSystem.forward) vs fp64 "
           "render_rays at the same fine depths:", {k: f"{v:.1e}" for k, v in err.items()})

@@ -274,6 +274,27 @@ def test_train_step_gradients_golden(name):
     tol = max(1e-3, (8 if name.startswith("g9b_detach_mask") or name.startswith("g9b_detach_outside") else 4) * floor)
     bad = [r for r in report if r[0] > tol or r[1] > tol]
     assert not bad, bad[:4]
+    # whole tensors, entry by entry (g9_train_grads_full: first trunk layer, skip layer, density head, colour branch's first layer
+    # of both models = 268 k entries instead of 8 x 48), against the reference's fp32 gradients AND its float64 run of the same
+    # step: within 1e-3 of the tensor's largest entry of the fp32 capture (or 4 x the capture's own distance from float64), and
+    # no further from the float64 truth than twice the reference's fp32 run is (+ 1e-3)
+    full = [k for k in fx.outputs if k.startswith("gradfull__")]
+    if name == "g9_train_grads_full":
+        assert len(full) == 8, full
+    for k in full:
+        _, mname, pn_ = k.split("__")
+        want32 = fx.outputs[k].astype(np.float64)
+        want64 = fx.outputs[k.replace("gradfull__", "gradfull64__")].astype(np.float64)
+        mod = system.nerf_coarse if mname == "coarse" else system.nerf_fine
+        got = dict(mod.named_parameters())[pn_].grad.detach().cpu().numpy().astype(np.float64)
+        assert got.shape == want32.shape, (k, got.shape, want32.shape)
+        scale = float(np.abs(want64).max())
+        own = float(np.abs(want32 - want64).max()) / scale
+        e32 = float(np.abs(got - want32).max()) / scale
+        e64 = float(np.abs(got - want64).max()) / scale
+        print(f"  full tensor {mname} {pn_}: vs fp32 capture {e32:.2e}, vs float64 {e64:.2e} (reference fp32 vs float64 {own:.2e})")
+        assert e32 <= max(1e-3, 4 * own), (k, e32, own)
+        assert e64 <= 2 * own + 1e-3, (k, e64, own)
 
 
 def test_field_second_order_backward_matches_double_backward():
