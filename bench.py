@@ -396,6 +396,8 @@ def main():
                     "telemetry": smi_other.summary() if smi_other is not None else None,
                     "frac_at_granted_clock": (other_tf / ((PEAK_FP32_MFMA_TFLOPS if split else PEAK_F16_MFMA_TFLOPS) * smi_other.median_sclk() / 2400.0)
                                               if (smi_other is not None and smi_other.median_sclk()) else None)}
+                res["fp32_rays_per_s" if split else "split_rays_per_s"] = other_rays
+                res["fp32_frac" if split else "split_frac"] = res["roofline"]["other_precision"]["frac"]
             if strong is not None:
                 res["strong_scaling"] = strong
             if host_maps is not None:
@@ -404,6 +406,17 @@ def main():
                 res["maps_only_fused"] = fused
             if train is not None:
                 res["train_step"] = train
+                # top level, so that a harness that keeps only the keys of nested objects keeps the numbers:
+                # ms per step of [colour + mask | TotalLoss | config-3 schedule 64 + 192 | run.sh recipe after / inside its geometry stage]
+                def g_(*ks):
+                    d = train
+                    for k in ks:
+                        d = d.get(k) if isinstance(d, dict) else None
+                    return d.get("ms_per_step") if isinstance(d, dict) else None
+                res["train_ms"] = [train.get("ms_per_step"), g_("with_total_loss"), g_("config3_64_plus_192"),
+                                   g_("run_sh_recipe", "after_geometry_stage"), g_("run_sh_recipe", "in_geometry_stage")]
+                res["train_route"] = train.get("route")
+                res["train_frac"] = (train.get("roofline") or {}).get("frac")
             if hash_grid is not None:
                 res["hash_grid_variant"] = hash_grid
             if rough is not None:
@@ -559,7 +572,17 @@ def main():
             train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
             train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
                                                                       "reflected_rays_per_step", "allreduce", "route")}
-        legs_done.append("train_step.with_total_loss + config3_64_plus_192")
+        if leg("run_sh"):
+            # run.sh:259-280 as the reference trains: --use_plane_consistent_loss --train_geometry_stage.  All five terms of TotalLoss
+            # (the plane term drawing on the device), after the geometry stage (reflections traced) and inside it (none), on the
+            # default route (the captured graph)
+            rs = {}
+            for key, name in (("after_geometry_stage", "run_sh"), ("in_geometry_stage", "run_sh_stage")):
+                t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name=name)
+                rs[key] = {k: t_[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline", "route", "reflected_rays_per_step",
+                                             "collectives_in_graph", "allreduce") if k in t_}
+            train["run_sh_recipe"] = rs
+        legs_done.append("train_step.with_total_loss + config3_64_plus_192 + run_sh_recipe")
 
     hash_grid = hash_grid_leg(dev, rays) if (not a.no_train and leg("hash_grid")) else None
     legs_done.append("hash_grid_variant")

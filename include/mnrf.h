@@ -570,6 +570,11 @@ int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float
 #define MNRF_LOSS_USE_MASK 32u                   /* epoch gates of TotalLoss.forward (losses.py:233-249) */
 #define MNRF_LOSS_USE_PLANE 64u
 #define MNRF_LOSS_USE_NORMAL 128u
+#define MNRF_LOSS_PLANE_ON_DEVICE 256u           /* PlaneConsistentLoss with no host read (round 6): the quadruples are drawn by the
+                                                    kernel as floor(plane_u * M) from M = the number of GT-mirror rows the count launch
+                                                    of the same call leaves in the workspace; M // 4 of the plane_cap quadruples are
+                                                    live (none when a GT entry is invalid, losses.py:116-119); plane_idx / plane_times
+                                                    are not read */
 typedef struct {
     const float* rgb[2];          /* (N,3) */
     float* mirror_mask[2];        /* (N)   */
@@ -586,6 +591,8 @@ typedef struct {
     int64_t n_rays;
     const int64_t* plane_idx[2];  /* (times,4) draws of torch.randint, rows of the GT-mirror subset */
     int64_t plane_times[2];
+    const float* plane_u[2];      /* MNRF_LOSS_PLANE_ON_DEVICE: (plane_cap,4) uniform numbers in [0,1); plane_cap >= n_rays / 4 */
+    int64_t plane_cap[2];
     float w_color, w_normal, w_normal_reg, w_mask, w_plane;
     unsigned flags;
     float* g_rgb[2];

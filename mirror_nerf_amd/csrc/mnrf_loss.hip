@@ -250,16 +250,27 @@ __global__ void sample_kernel(MnrfLossArgs A, int typ, const float* counts, floa
 }
 
 // PlaneConsistentLoss (losses.py:88-110): one thread per drawn quadruple of mirror-mask rows
-__global__ void plane_kernel(MnrfLossArgs A, int typ, const int* mirror_rows, float* partials) {
+// DEVICE: MNRF_LOSS_PLANE_ON_DEVICE -- the launch is sized for plane_cap quadruples, the live ones (M // 4) and M itself come from
+// the count launch's words; a draw is floor(u * M) (u < 1 in fp32; the product can still round up to M: clamped).
+template <bool DEVICE>
+__global__ void plane_kernel(MnrfLossArgs A, int typ, const float* counts, const int* mirror_rows, float* partials) {
     __shared__ float sh[TPB / 64];
     const long long q = (long long)blockIdx.x * TPB + threadIdx.x;
-    const long long times = A.plane_times[typ];
+    const int m = (int)counts[C_MIRROR];
+    const long long times = DEVICE ? (counts[C_INVALID] > 0.f ? 0 : (long long)(m / 4)) : A.plane_times[typ];
     float v = 0.f;
     if (q < times) {
         int r[4];
         float p[4][3];
         for (int k = 0; k < 4; ++k) {
-            r[k] = mirror_rows[A.plane_idx[typ][q * 4 + k]];
+            long long pick;
+            if (DEVICE) {
+                const int d = (int)(A.plane_u[typ][q * 4 + k] * (float)m);
+                pick = d < m - 1 ? d : m - 1;
+            } else {
+                pick = A.plane_idx[typ][q * 4 + k];
+            }
+            r[k] = mirror_rows[pick];
             for (int c = 0; c < 3; ++c) p[k][c] = A.x_surface[typ][(long long)r[k] * 3 + c];
         }
         float a[3], b[3], c3[3];
@@ -393,6 +404,9 @@ extern "C" int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void*
             return mnrf_fail(MNRF_ERR_ARG, "mnrf_total_loss: per-sample normals need weights and n_samples");
         if (A.plane_times[typ] > 0 && (!A.plane_idx[typ] || !A.x_surface[typ] || !A.gt_mask))
             return mnrf_fail(MNRF_ERR_ARG, "mnrf_total_loss: plane loss needs indices, x_surface and the GT mask");
+        if ((A.flags & MNRF_LOSS_PLANE_ON_DEVICE) && A.plane_u[typ] &&
+            (!A.x_surface[typ] || !A.gt_mask || A.plane_cap[typ] < A.n_rays / 4))
+            return mnrf_fail(MNRF_ERR_ARG, "mnrf_total_loss: plane loss on the device needs x_surface, the GT mask and n_rays / 4 quadruples of draws");
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = A.n_rays;
@@ -424,9 +438,13 @@ extern "C" int mnrf_total_loss(const MnrfLossArgs* args, float* workspace, void*
     }
     // losses.py:124: "fine" first
     for (int typ = 1; typ >= 0; --typ) {
-        if ((A.flags & MNRF_LOSS_USE_PLANE) && A.plane_times[typ] > 0) {
-            const int64_t blocks = (A.plane_times[typ] + TPB - 1) / TPB;
-            hipLaunchKernelGGL(plane_kernel, dim3((unsigned)blocks), dim3(TPB), 0, s, A, typ, mirror_rows, cursor);
+        const bool on_device = (A.flags & MNRF_LOSS_PLANE_ON_DEVICE) && A.plane_u[typ] && n / 4 > 0;
+        if ((A.flags & MNRF_LOSS_USE_PLANE) && (on_device || A.plane_times[typ] > 0)) {
+            const int64_t blocks = ((on_device ? n / 4 : A.plane_times[typ]) + TPB - 1) / TPB;
+            if (on_device)
+                hipLaunchKernelGGL(plane_kernel<true>, dim3((unsigned)blocks), dim3(TPB), 0, s, A, typ, counts, mirror_rows, cursor);
+            else
+                hipLaunchKernelGGL(plane_kernel<false>, dim3((unsigned)blocks), dim3(TPB), 0, s, A, typ, counts, mirror_rows, cursor);
             F.plane_partials[typ] = cursor;
             F.plane_blocks[typ] = (int)blocks;
             cursor += blocks;

@@ -10,6 +10,11 @@ node below only scales stored gradients.  No arithmetic in Python.
 graph.  PlaneConsistentLoss draws its point quadruples from the default CPU generator exactly like the reference
 (4*floor(M/4) draws of torch.randint(high=M), "fine" before "coarse"; losses.py:96-107, 124-129) -- one batched
 draw, the same sequence -- which costs one device->host read of M per step when that (optional) term is on.
+Round 6: on the static training route and inside a captured step (batch["_plane_on_device"], or a capturing stream)
+the term needs no host read: uniform numbers come from the DEVICE generator, sized for n_rays // 4 quadruples, and the
+kernel forms every pick as floor(u * M) with M and the live quadruple count M // 4 from the count words of its own
+call (MNRF_LOSS_PLANE_ON_DEVICE).  batch["_plane_u"] injects the numbers on either route (the host route then forms
+the same picks from them), which is how tests hold the two routes to the same loss.
 """
 import ctypes
 
@@ -27,7 +32,7 @@ class _Args(ctypes.Structure):
     _fields_ = [("rgb", _F * 2), ("mirror_mask", _F * 2), ("normal_dif", _F * 2), ("pred_normal", _F * 2),
                 ("weights", _F * 2), ("x_surface", _F * 2), ("normal_fine", _F), ("n_samples", ctypes.c_int * 2),
                 ("targets", _F), ("gt_mask", _F), ("rays", _F), ("valid_mask", _F), ("n_rays", ctypes.c_int64),
-                ("plane_idx", _F * 2), ("plane_times", ctypes.c_int64 * 2),
+                ("plane_idx", _F * 2), ("plane_times", ctypes.c_int64 * 2), ("plane_u", _F * 2), ("plane_cap", ctypes.c_int64 * 2),
                 ("w_color", ctypes.c_float), ("w_normal", ctypes.c_float), ("w_normal_reg", ctypes.c_float),
                 ("w_mask", ctypes.c_float), ("w_plane", ctypes.c_float), ("flags", ctypes.c_uint),
                 ("g_rgb", _F * 2), ("g_mirror_mask", _F * 2), ("g_normal_dif", _F * 2), ("g_pred_normal", _F * 2),
@@ -35,7 +40,7 @@ class _Args(ctypes.Structure):
 
 
 FLAG_GEOMETRY_STAGE, FLAG_WO_MASK, FLAG_ONLY_INSIDE, FLAG_EXT_GRAD, FLAG_TCNN_BCE = 1, 2, 4, 8, 16
-FLAG_USE_MASK, FLAG_USE_PLANE, FLAG_USE_NORMAL = 32, 64, 128
+FLAG_USE_MASK, FLAG_USE_PLANE, FLAG_USE_NORMAL, FLAG_PLANE_ON_DEVICE = 32, 64, 128, 256
 TERMS = ("color_loss", "mirror_mask_loss", "plane_consistent_loss", "normal_loss", "normal_reg_loss")
 
 # (dict key pattern, struct field, gradient field); order fixes the order of the autograd inputs
@@ -128,13 +133,36 @@ class _TotalLossFn(torch.autograd.Function):
         times = [0, 0]
         s_max = max(a.n_samples[0], a.n_samples[1], 1)
         if (cfg["flags"] & FLAG_USE_PLANE) and "mirror_mask" in batch and any(f"x_surface_{t}" in inputs for t in _TYPS):
-            ws0 = torch.empty(L.mnrf_loss_workspace_floats(n, 1, 1, 0), dtype=torch.float32, device=dev)
-            _lib.check(L.mnrf_loss_count(ctypes.byref(a), _lib.ptr(ws0), _lib.stream()), "mnrf_loss_count")
-            n_invalid, m = (int(v) for v in ws0[:2].tolist())      # the one host read of this term
-            if n_invalid == 0 and m // 4 > 0:
-                for ti, typ in ((1, "fine"), (0, "coarse")):       # losses.py:124: fine first
-                    if f"x_surface_{typ}" in inputs:
-                        idx = torch.randint(high=m, size=(4 * (m // 4),)).to(dev)
+            plane_typs = [(ti, typ) for ti, typ in ((1, "fine"), (0, "coarse")) if f"x_surface_{typ}" in inputs]      # losses.py:124: fine first
+            cap = n // 4
+            u = batch.get("_plane_u")      # injected draws: (2, 4 * (n // 4)) uniform numbers, row 0 for "fine" (tests; both routes)
+            if u is not None and (u.dtype != torch.float32 or tuple(u.shape) != (2, 4 * cap) or not u.is_cuda):
+                raise ValueError("batch['_plane_u']: a float32 CUDA tensor of shape (2, 4 * (n_rays // 4))")
+            on_device = bool(batch.get("_plane_on_device")) or torch.cuda.is_current_stream_capturing()
+            if on_device and cap > 0:
+                # no host read (static route, captured step): the kernel takes M = #GT-mirror rows from the count words of its own
+                # call, draws row floor(u * M) for every pick of the M // 4 live quadruples and divides by M // 4; an invalid GT entry
+                # switches the term off there (losses.py:116-119).  Draws: the DEVICE generator (the reference's are the CPU
+                # generator's torch.randint: another sequence of the same distribution up to the 2^-24 grid of u)
+                if u is None:
+                    u = torch.rand(2, 4 * cap, device=dev)
+                u = u.contiguous()
+                keep.append(u)
+                a.flags = cfg["flags"] | FLAG_PLANE_ON_DEVICE
+                for k, (ti, _typ) in enumerate(plane_typs):
+                    a.plane_u[ti] = u[k].data_ptr()
+                    a.plane_cap[ti] = cap
+                    times[ti] = cap
+            elif not on_device:
+                ws0 = torch.empty(L.mnrf_loss_workspace_floats(n, 1, 1, 0), dtype=torch.float32, device=dev)
+                _lib.check(L.mnrf_loss_count(ctypes.byref(a), _lib.ptr(ws0), _lib.stream()), "mnrf_loss_count")
+                n_invalid, m = (int(v) for v in ws0[:2].tolist())      # the one host read of this term
+                if n_invalid == 0 and m // 4 > 0:
+                    for k, (ti, typ) in enumerate(plane_typs):
+                        if u is not None:      # the kernel's own expression on the injected numbers (fp32 product, truncation, clamp)
+                            idx = (u[k, :4 * (m // 4)] * float(m)).to(torch.int64).clamp_(max=m - 1)
+                        else:
+                            idx = torch.randint(high=m, size=(4 * (m // 4),)).to(dev)
                         keep.append(idx)
                         a.plane_idx[ti] = _ptr(idx)
                         a.plane_times[ti] = times[ti] = m // 4
@@ -150,14 +178,20 @@ class _TotalLossFn(torch.autograd.Function):
     def backward(ctx, g_sum, _g_out):
         # one multi-tensor launch for all inputs (four separate multiplies sat at the very start of the backward pass, where the
         # device has nothing else queued)
+        if ctx.grads is None:
+            # the unit-gradient path hands the STORED gradient tensors to autograd (no copy): a second pass over this node
+            # (retain_graph=True) would alias buffers the first pass's consumers may have written in place
+            raise RuntimeError("mirror_nerf_amd.losses: the fused loss was already back-propagated once (its stored gradients were "
+                               "handed over); evaluate the loss again instead of retain_graph=True")
         if g_sum is None:
             return (None, None, None) + (None,) * len(ctx.grads)
+        grads, ctx.grads = ctx.grads, None
         unit = _UNIT.get(str(g_sum.device))
         if unit is not None and g_sum.data_ptr() == unit.data_ptr():      # losses.unit_gradient: the factor is exactly 1
-            return (None, None, None) + tuple(None if g is None else g.reshape(shape) for g, shape in zip(ctx.grads, ctx.shapes))
-        have = [g for g in ctx.grads if g is not None]
+            return (None, None, None) + tuple(None if g is None else g.reshape(shape) for g, shape in zip(grads, ctx.shapes))
+        have = [g for g in grads if g is not None]
         scaled = iter(torch._foreach_mul(have, g_sum) if have else [])
-        outs = [None if g is None else next(scaled).reshape(shape) for g, shape in zip(ctx.grads, ctx.shapes)]
+        outs = [None if g is None else next(scaled).reshape(shape) for g, shape in zip(grads, ctx.shapes)]
         return (None, None, None) + tuple(outs)
 
 

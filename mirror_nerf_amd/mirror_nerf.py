@@ -166,7 +166,9 @@ def guard_async_begin(modules):
     host.copy_(dev_words, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    return modules, host, ev, dev_words      # (dev_words: the flags on the device, for a device-side decision -- training.train_step)
+    # (dev_words: the flags on the device, for a device-side decision -- training.train_step; the gradient-scale reductions the
+    #  step was ISSUED with: guard_async_end ignores a backward overflow that a reduction made since has already answered)
+    return modules, host, ev, dev_words, [m.__dict__.get("_mnrf_seed_reduction", 0) for m in modules]
 
 
 def pin_fp32(modules):
@@ -206,10 +208,16 @@ def guard_async_end(token, adapt=False):
     if token is None:
         return False
     modules, host, ev = token[:3]
+    issued_with = token[4] if len(token) > 4 else [None] * len(modules)
     ev.synchronize()
     tripped = False
-    for m, w in zip(modules, host.tolist()):
+    for m, w, r0 in zip(modules, host.tolist(), issued_with):
         if w and precision_of(m).startswith("split"):
+            if adapt and r0 is not None and m.__dict__.get("_mnrf_seed_reduction", 0) > r0 and (w & 256) and not (w & (2 | 4 | 128 | 512)):
+                # the step behind this token was queued before the previous trip's adaptation took effect (flags are settled one
+                # step late): its backward overflowed at the OLD scale -- the update was vetoed on the device like the first one's,
+                # but it says nothing about the new scale.  Without this one overflow cost two adaptations.
+                continue
             m.__dict__["_mnrf_guard_trips"] = m.__dict__.get("_mnrf_guard_trips", 0) + 1
             if adapt and _lower_gradient_scale(m, w):
                 continue

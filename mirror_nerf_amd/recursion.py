@@ -275,7 +275,8 @@ def _static_level(models, embeddings, hp, rays_chunk, mirror_mask_prev, recur_le
     if getattr(hp, "detach_normal_in_reflection", False):
         nrm = nrm.detach()
     sec, index, _rdir, count = ReflectFn.apply(rays_chunk, r[f"x_surface_{sel}"], nrm, mask, bool(only_in), True, n_live)
-    r2 = render_rays_chunk_recursively(models, embeddings, hp, sec, mask, recur_level + 1, dict(extra_chunk, _n_live=count),
+    r2 = render_rays_chunk_recursively(models, embeddings, hp, sec, mask, recur_level + 1,
+                                       dict(extra_chunk, _n_live=count, _compacted=bool(only_in) or bool(extra_chunk.get("_compacted"))),
                                        white_back, train_geometry_stage)
     # train.py:263-296 for both typs in one launch (gather form through the compaction's inverse index: autograd.Blend2Fn)
     from .autograd import Blend2Fn

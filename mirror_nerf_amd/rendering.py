@@ -120,7 +120,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             mm = kwargs["mirror_mask"]
             gv = kwargs.get("_gt_valid")      # (static step: the caller knows; no device->host read)
             if (gv if gv is not None else not bool((mm < 0).any().item())):
-                if mm.shape[0] != N:
+                if mm.shape[0] != N or kwargs.get("_compacted"):
+                    # (static route: compacted reflected rays keep the chunk's CAPACITY, so the shapes agree while the rows do
+                    #  not -- the level-0 mask would steer the wrong rays without a word.  The count lives on the
+                    #  device, so this raises for every compacted level, also in the corner where every ray was a mirror ray.)
                     # the reference indexes the (N,S) weights with this mask and fails the same way when reflected rays
                     # were compacted (train.py:253-259 passes the un-compacted mask on, SURVEY 8a hazard 10)
                     raise IndexError(f"detach_density_outside_mirror_for_mask_loss: mirror_mask has {mm.shape[0]} entries "

@@ -140,6 +140,87 @@ GUARD_WORKER = textwrap.dedent('''
 ''')
 
 
+GRAPH_WORKER = textwrap.dedent('''
+    import os, sys, warnings
+    sys.path.insert(0, os.environ["MNRF_ROOT"])
+    import torch, torch.distributed as dist
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import dist as D, synthetic as SY, training as T
+    from mirror_nerf_amd.weights import params_of
+
+    rank, ws, dev = D.init_from_env()
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and (ws > 1 or D.forced())
+
+    def system():
+        torch.manual_seed(0)
+        s = M.NeRFSystem(T.default_hparams(perturb=0.0, noise_std=0.0)).to(dev)
+        with torch.no_grad():
+            for m in s.models.values():
+                m.sigma.weight.mul_(20.0); m.sigma.bias.fill_(1.0)
+        return s
+
+    g = torch.Generator(device=dev); g.manual_seed(1 + rank)
+    all_rays = SY.device_rays(64, 64, dev)
+    n = 256
+    batches = []
+    for i in range(4):
+        rays = all_rays[torch.randint(0, all_rays.shape[0], (n,), device=dev, generator=g)].contiguous()
+        batches.append((rays, torch.rand(n, 3, device=dev, generator=g), (torch.rand(n, device=dev, generator=g) < (0.0 if i == 1 else 0.3)).float()))
+
+    calls = []
+    real = dist.all_reduce
+    def counted(t, *a, **k):
+        calls.append((int(t.numel()), str(t.dtype), bool(torch.cuda.is_current_stream_capturing())))
+        return real(t, *a, **k)
+    dist.all_reduce = counted
+
+    # -- the step captured WITH its collectives: two bucket all-reduces from the backward hooks + the OR of the guard words
+    a = system()
+    opt_a = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    D.attach_overlap(a.models.values())
+    step = T.GraphedTrainStep(a, opt_a, n, gt_valid=True)
+    assert step.collective
+    snaps_a, losses_a, grads_a = [], [], None
+    for i, b in enumerate(batches):
+        la = step(*b)
+        torch.cuda.synchronize()
+        assert not step.ended and step.capture_error is None, step.capture_error
+        losses_a.append(float(la))
+        if i == 0:
+            grads_a = [D._flat_bucket(m).clone() for m in a.models.values()]
+        snaps_a.append([q.detach().clone() for m in a.models.values() for q in params_of(m)])
+    captured = [c for c in calls if c[2]]
+    n_flat = sum(q.numel() for q in params_of(a.nerf_fine))
+    assert sorted(c[0] for c in captured) == sorted([n_flat, n_flat, 2 * len(T.GraphedTrainStep._BITS)]), captured
+    n_calls = len(calls)
+    D.detach_overlap(list(a.models.values()))
+
+    # -- the same batches through train_step's static route (host-issued launches, host-issued collectives)
+    b_sys = system()
+    opt_b = T.FlatAdam(list(b_sys.models.values()), lr=5e-4)
+    D.attach_overlap(b_sys.models.values())
+    for i, b in enumerate(batches):
+        lb = T.train_step(b_sys, opt_b, *b, gt_valid=True)
+        torch.cuda.synchronize()
+        if i == 0:
+            assert float(lb) == losses_a[0], (float(lb), losses_a[0])
+            for ga, m in zip(grads_a, b_sys.models.values()):
+                assert torch.equal(ga, D._flat_bucket(m)), "gradients of the replayed step differ from train_step's"
+        assert abs(float(lb) - losses_a[i]) <= 1e-6 * max(1.0, abs(float(lb))), (i, float(lb), losses_a[i])
+        worst = max(float((qa - qb.detach()).abs().max()) for qa, qb in zip(snaps_a[i], (q for m in b_sys.models.values() for q in params_of(m))))
+        assert worst <= 2.5e-4 * (i + 1), (i, worst)      # (one ulp in a gradient near zero can flip an Adam step of lr)
+        print("step", i, "loss", float(lb), "max |w_graph - w_static|", worst)
+    assert len(calls) > n_calls          # (train_step issued its collectives from the host)
+    D.detach_overlap(list(b_sys.models.values()))
+    dist.all_reduce = real
+    # replays issue no Python-side collective: the 4 calls of the graphed run made 3 (capture) + 3 per warm-up rehearsal
+    assert n_calls == 3 * (1 + step.warmup), (n_calls, calls[:12])
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+''')
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -181,6 +262,19 @@ def _run(world, worker=None, **extra):
 
 def test_rccl_one_rank_group_runs_every_collective():
     _run(1)
+
+
+def test_graphed_step_with_forced_collectives():
+    """the bucket all-reduces and the guard-word reduction captured INSIDE the hipGraph of the training step
+    (RCCL, world size 1 with MNRF_FORCE_COLLECTIVES=1 -- the group a 1-GPU box can form).  Replays issue no collective from Python;
+    loss and gradients of the first replay are bit-identical to train_step's static route on the same batch, weights after four
+    steps to one Adam step's arithmetic.  DDP semantics: train.py:577-584."""
+    _run(1, GRAPH_WORKER)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_graphed_step_with_collectives_two_ranks():
+    _run(2, GRAPH_WORKER)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")

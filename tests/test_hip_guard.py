@@ -204,11 +204,10 @@ def test_frame_driver_and_training_step_fall_back():
             s.nerf_fine.xyz_encoding_2[0].weight.mul_(1e7)
         return s
     batch = (rays, torch.rand(rays.shape[0], 3, device=DEV), (torch.rand(rays.shape[0], device=DEV) < 0.3).float())
-    s1, s2 = system(), system()
+    s2 = system()
     hp = dict(perturb=0.0, noise_std=0.0)
-    for s in (s1, s2):
-        for k, v in hp.items():
-            setattr(s.hparams, k, v)
+    for k, v in hp.items():
+        setattr(s2.hparams, k, v)
     class NoStep:      # leaves the weights alone (SGD with lr = 0 turns an inf gradient into a NaN weight)
         def __init__(self, params):
             self.params = list(params)
@@ -219,26 +218,8 @@ def test_frame_driver_and_training_step_fall_back():
 
         def step(self):
             pass
-    o1 = NoStep(s1.parameters())
-    # MNRF_GUARD_MODE=async: train_step reads the flag asynchronously: the tripping step itself passes silently, the NEXT one
-    # reports it and runs (from then on) on the exact kernels -- only the model that tripped
-    old_mode, training.GUARD_MODE = training.GUARD_MODE, "async"
-    try:
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")
-            training.train_step(s1, o1, *batch)
-        with pytest.warns(RuntimeWarning, match="previous training step"):
-            l1 = training.train_step(s1, o1, *batch)
-    finally:
-        training.GUARD_MODE = old_mode
-    assert MN.precision_of(s1.nerf_fine) == "fp32" and MN.precision_of(s1.nerf_coarse) == "split"
     s2.nerf_fine.__dict__["_mnrf_precision"] = "fp32"
     l2 = training.train_step(s2, NoStep(s2.parameters()), *batch)
-    assert float(l1) == float(l2)
-    for (n, p), q in zip(s1.named_parameters(), s2.parameters()):
-        assert (p.grad is None) == (q.grad is None)
-        if p.grad is not None:
-            assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n
     # MNRF_GUARD_SYNC=1: the tripping step ITSELF is recomputed on the exact kernels before the optimizer sees it
     s4 = system()
     for k, v in hp.items():
@@ -249,7 +230,7 @@ def test_frame_driver_and_training_step_fall_back():
             l4 = training.train_step(s4, NoStep(s4.parameters()), *batch)
     finally:
         training.GUARD_MODE = old_mode
-    assert float(l4) == float(l2) and MN.precision_of(s4.nerf_fine) == "fp32"
+    assert float(l4) == float(l2) and MN.precision_of(s4.nerf_fine) == "fp32" and MN.precision_of(s4.nerf_coarse) == "split"      # only the model that tripped
     for (n, p), q in zip(s4.named_parameters(), s2.parameters()):
         if p.grad is not None:
             assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(q.grad)), n

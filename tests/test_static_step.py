@@ -390,3 +390,196 @@ def test_composite_sample_equals_composite_then_sample_fine():
                 assert torch.equal(outs[0][k], outs[1][k]), (k, live)
             rows = n if live is None else live
             assert bool((outs[1]["zf"][:rows] > 0).all()) and (live is None or bool((outs[1]["zf"][rows:] == -5).all()))
+
+
+# ------------------------------------------------------------------------------------------ round 6: run.sh:259-280's recipe
+def _recipe_loss(stage, epoch):
+    from types import SimpleNamespace
+    from mirror_nerf_amd import training as T
+    return T.total_loss_fn(SimpleNamespace(use_plane_consistent_loss=True), epoch=epoch, train_geometry_stage=stage)
+
+
+def _fwd_bwd_recipe(system, rays, target, gt, static, u, stage=False, epoch=5, gt_valid=True):
+    """One forward + TotalLoss (all five terms, --use_plane_consistent_loss) + backward with the plane term's uniform numbers
+    injected, so that the host route (one read of the mirror-ray count, picks formed on the host) and the static route (count and
+    picks on the device) draw the same quadruples."""
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.losses import get_loss
+    from types import SimpleNamespace
+    system.train_geometry_stage = stage
+    ex = dict(T.extra_info(system.hparams, gt, epoch, stage), _guard=False)
+    if static:
+        ex.update(_static=True, _gt_valid=gt_valid)
+    system.zero_grad(set_to_none=True)
+    tgt = T.stage_target(system.hparams, target, gt, gt_valid) if stage else target
+    res = system(rays, ex)
+    crit = get_loss(SimpleNamespace(use_plane_consistent_loss=True))
+    batch = {"rgbs": tgt, "mirror_mask": gt, "rays": rays, "_plane_u": u}
+    if static:
+        batch["_plane_on_device"] = True
+    total, terms = crit(res, batch, train_geometry_stage=stage, epoch=epoch)
+    total.backward()
+    return {k: float(v) for k, v in terms.items()}, float(total), _grads(system)
+
+
+@pytest.mark.parametrize("stage,epoch", [(False, 5), (True, 2)])
+def test_plane_consistent_loss_same_draws_on_host_and_static_route(stage, epoch):
+    """losses.py:80-127 without a host read.  Same uniform numbers on both routes -> the same quadruples -> every
+    term and the total bit for bit; gradients to the summation order of the GEMM (and of the plane term's atomics)."""
+    system = _system(perturb=0.0, noise_std=0.0)
+    rays, target, gt = _batch(n=256, frac=0.3)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(77)
+    u = torch.rand(2, 4 * (256 // 4), device=DEV, generator=g)
+    terms_h, loss_h, g_h = _fwd_bwd_recipe(system, rays, target, gt, False, u, stage, epoch)
+    terms_s, loss_s, g_s = _fwd_bwd_recipe(system, rays, target, gt, True, u, stage, epoch)
+    assert set(terms_h) == set(terms_s) == {"color_loss", "mirror_mask_loss", "plane_consistent_loss", "normal_loss", "normal_reg_loss"}
+    assert terms_h["plane_consistent_loss"] > 0.0
+    for k in terms_h:
+        assert terms_h[k] == terms_s[k], (k, terms_h[k], terms_s[k])
+    assert loss_h == loss_s
+    _cmp_grads(g_s, g_h, 2e-5)
+    system.train_geometry_stage = False
+
+
+def test_plane_term_on_the_device_switches_off_for_invalid_gt_and_for_fewer_than_four_mirror_rays():
+    """losses.py:116-119 (an invalid GT entry: no mask, no term) and losses.py:98-100 (times = M // 4 = 0) decided by the kernel from the
+    count words: the term is exactly 0 and x_surface receives no gradient from it."""
+    import mirror_nerf_amd as M
+    from types import SimpleNamespace
+    n = 64
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    res = {f"rgb_{t}": torch.rand(n, 3, device=DEV, generator=g) for t in ("coarse", "fine")}
+    xs = {t: torch.randn(n, 3, device=DEV, generator=g).requires_grad_(True) for t in ("coarse", "fine")}
+    res.update({f"x_surface_{t}": xs[t] * 1.0 for t in xs})
+    crit = M.get_loss(SimpleNamespace(use_plane_consistent_loss=True))
+    rays = torch.zeros(n, 8, device=DEV)
+    for name, gt in (("invalid", torch.cat([torch.full((1,), -1.0, device=DEV), torch.ones(n - 1, device=DEV)])),
+                     ("three mirror rays", torch.cat([torch.ones(3, device=DEV), torch.zeros(n - 3, device=DEV)]))):
+        total, terms = crit(res, {"rgbs": torch.rand(n, 3, device=DEV, generator=g), "mirror_mask": gt, "rays": rays,
+                                  "_plane_on_device": True}, train_geometry_stage=False, epoch=5)
+        assert float(terms["plane_consistent_loss"]) == 0.0, name
+    gt = (torch.rand(n, device=DEV, generator=g) < 0.5).float()
+    total, terms = crit(res, {"rgbs": torch.rand(n, 3, device=DEV, generator=g), "mirror_mask": gt, "rays": rays, "_plane_on_device": True},
+                        train_geometry_stage=False, epoch=5)
+    assert float(terms["plane_consistent_loss"]) > 0.0
+    total.backward()
+    # only mirror rows receive a gradient from the plane term (the colour term does not reach x_surface)
+    for t in xs:
+        assert float(xs[t].grad[gt == 0].abs().max()) == 0.0 and float(xs[t].grad[gt != 0].abs().max()) > 0.0
+
+
+def test_plane_term_on_the_device_against_the_oracle():
+    """The picks the kernel forms from its uniform numbers, restated on the host (floor(u * M) in fp32, clamped), handed to the
+    oracle's PlaneConsistentLoss (losses.py:88-110 restated): value to 2e-6, gradient of x_surface to 1e-6 of its largest entry --
+    the bar tests/test_loss.py holds the host route to against the reference's captured draws (G10)."""
+    import numpy as np
+    import mirror_nerf_amd as M
+    from oracle import mirror_nerf_oracle as O
+    from types import SimpleNamespace
+    n = 200
+    rs = np.random.RandomState(4)
+    res_np = {f"rgb_{t}": rs.uniform(size=(n, 3)).astype(np.float32) for t in ("coarse", "fine")}
+    res_np.update({f"x_surface_{t}": rs.normal(size=(n, 3)).astype(np.float32) for t in ("coarse", "fine")})
+    gt = (rs.uniform(size=n) < 0.4).astype(np.float32)
+    m = int(gt.sum())
+    u = rs.uniform(size=(2, 4 * (n // 4))).astype(np.float32)
+    batch_np = {"rgbs": rs.uniform(size=(n, 3)).astype(np.float32), "mirror_mask": gt, "rays": np.zeros((n, 8), np.float32)}
+    picks = {t: np.minimum((u[k, :4 * (m // 4)] * np.float32(m)).astype(np.int64), m - 1).reshape(m // 4, 4) for k, t in enumerate(("fine", "coarse"))}
+    hp = dict(O.LOSS_DEFAULTS, use_plane_consistent_loss=True)
+    want = float(O.plane_consistent_loss({k: v.copy() for k, v in res_np.items()}, batch_np, hp, picks))
+    t_in = {k: torch.from_numpy(v.copy()).to(DEV).requires_grad_(k.startswith("x_surface")) for k, v in res_np.items()}
+    crit = M.get_loss(SimpleNamespace(use_plane_consistent_loss=True, color_loss_weight=0.0))
+    tb = {k: torch.from_numpy(v).to(DEV) for k, v in batch_np.items()}
+    tb.update(_plane_on_device=True, _plane_u=torch.from_numpy(u).to(DEV))
+    total, terms = crit({k: v * 1.0 for k, v in t_in.items()}, tb, train_geometry_stage=False, epoch=5)
+    got = float(terms["plane_consistent_loss"])
+    assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (got, want)
+    total.backward()
+    # finite-difference check of the stored gradient along a random direction (the oracle has no gradients)
+    d = {t: rs.normal(size=(n, 3)).astype(np.float32) for t in ("coarse", "fine")}
+    eps = 1e-3
+    plus = {k: v + eps * d[k[10:]] if k.startswith("x_surface") else v for k, v in res_np.items()}
+    minus = {k: v - eps * d[k[10:]] if k.startswith("x_surface") else v for k, v in res_np.items()}
+    fd = (float(O.plane_consistent_loss(plus, batch_np, hp, picks)) - float(O.plane_consistent_loss(minus, batch_np, hp, picks))) / (2 * eps)
+    an = sum(float((t_in[f"x_surface_{t}"].grad.cpu().numpy().astype(np.float64) * d[t]).sum()) for t in d)
+    assert abs(fd - an) <= 2e-3 * max(abs(fd), 1e-3), (fd, an)
+
+
+def test_static_route_refuses_the_level_zero_mask_on_compacted_rays():
+    """--detach_density_outside_mirror_for_mask_loss with compacted reflected rays.  The reference (and the host
+    route) fail with an IndexError at the nested level (train.py:253-259 hands the un-compacted mask on); on the static route the
+    compacted rays keep the chunk's capacity, so the shapes agree -- it must refuse all the same instead of steering the wrong rows."""
+    system = _system(perturb=0.0, noise_std=0.0, detach_density_outside_mirror_for_mask_loss=True)
+    rays, target, gt = _batch(n=128, frac=0.3)
+    with pytest.raises(IndexError):
+        _fwd_bwd(system, rays, target, gt, static=False)
+    with pytest.raises(IndexError):
+        _fwd_bwd(system, rays, target, gt, static=True)
+    # without compaction the rows of the nested level ARE the rows of the mask: both routes run and agree
+    system = _system(perturb=0.0, noise_std=0.0, detach_density_outside_mirror_for_mask_loss=True, only_trace_rays_in_mirrors=False)
+    _r, loss_h, g_h = _fwd_bwd(system, rays, target, gt, static=False)
+    _r, loss_s, g_s = _fwd_bwd(system, rays, target, gt, static=True)
+    assert loss_h == loss_s
+    _cmp_grads(g_s, g_h, 2e-5)
+
+
+def _recipe_loss_with_draws(stage, epoch, u_buf):
+    """total_loss_fn's shape with the plane term's uniform numbers taken from `u_buf` (a static tensor the test refills per step):
+    the captured step forms its picks on the device, the host-driven step on the host -- from the same numbers."""
+    from types import SimpleNamespace
+    from mirror_nerf_amd.losses import get_loss
+    crit = get_loss(SimpleNamespace(use_plane_consistent_loss=True))
+
+    def fn(res, target, gt, rays, static=False):
+        batch = {"rgbs": target, "mirror_mask": gt, "rays": rays, "_plane_u": u_buf}
+        if static:
+            batch["_plane_on_device"] = True
+        return crit(res, batch, train_geometry_stage=stage, epoch=epoch)[0]
+    fn.needs_rays, fn.takes_static, fn.train_geometry_stage = True, True, stage
+    return fn
+
+
+@pytest.mark.parametrize("stage,epoch", [(False, 5), (True, 2)])
+def test_graphed_step_carries_the_run_sh_recipe(stage, epoch):
+    """GraphedTrainStep with TotalLoss's five terms (the plane term forming its picks on the device) after and inside the geometry
+    stage (run.sh:276-277): captured once, three replays; against train_step on the HOST-DRIVEN route (one read of the mirror-ray
+    count, picks formed on the host from the same numbers): the loss bit for bit on the first step, weights after every step to one
+    Adam step's arithmetic."""
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.weights import params_of
+    a = _system(perturb=0.0, noise_std=0.0)
+    b = _system(perturb=0.0, noise_std=0.0)
+    a.train_geometry_stage = b.train_geometry_stage = stage
+    opt_a = T.FlatAdam(list(a.models.values()), lr=5e-4)
+    opt_b = T.FlatAdam(list(b.models.values()), lr=5e-4)
+    n = 256
+    u_buf = torch.zeros(2, 4 * (n // 4), device=DEV)
+    with pytest.raises(ValueError):       # a loss built for the other stage (train.py:426 and 439-446 hand over the same flag)
+        T.GraphedTrainStep(a, opt_a, n, loss_fn=_recipe_loss(not stage, epoch), epoch=epoch)
+    step = T.GraphedTrainStep(a, opt_a, n, loss_fn=_recipe_loss_with_draws(stage, epoch, u_buf), epoch=epoch, gt_valid=True)
+    fn_b = _recipe_loss_with_draws(stage, epoch, u_buf)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(123)
+    graphs = []
+    for i in range(3):
+        rays, target, gt = _batch(n=n, frac=0.3, seed=20 + i)
+        u_buf.copy_(torch.rand(u_buf.shape, device=DEV, generator=g))
+        la = step(rays, target, gt)
+        graphs.append(step.graph)
+        lb = T.train_step(b, opt_b, rays, target, gt, fn_b, epoch=epoch)
+        torch.cuda.synchronize()
+        assert not step.ended
+        if i == 0:
+            assert float(la) == float(lb), (float(la), float(lb))
+        assert abs(float(la) - float(lb)) <= 2e-5 * max(1.0, abs(float(lb))), (i, float(la), float(lb))
+        for qa, qb in zip((q for m in a.models.values() for q in params_of(m)), (q for m in b.models.values() for q in params_of(m))):
+            assert float((qa - qb).abs().max()) <= 2.5e-4 * (i + 1), i
+    assert all(gr is graphs[0] for gr in graphs)
+    assert opt_a._calls == 3 and int(opt_a._step_dev.item()) == 3 and opt_a._steps == [3, 3]
+    # the stage ends (train.py:387-391): other launches -- the next call captures again, and the loss must be the other stage's
+    a.train_geometry_stage = b.train_geometry_stage = not stage
+    with pytest.raises(ValueError):
+        step(rays, target, gt)
+    a.train_geometry_stage = b.train_geometry_stage = False
