@@ -586,7 +586,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            # With a process group alive its watchdog thread polls the events of earlier collectives (the warm-up's) -- an "unsafe"
+            # call under the default GLOBAL capture mode, which then kills the process ("operation not permitted when stream is
+            # capturing", seen on the driver box whenever a collective had run shortly before the capture).  Thread-local mode
+            # checks the capturing thread only; the launches of the autograd threads are captured through the stream all the same.
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local" if self.collective else "global"):
                 self.loss = self._body()
         except Exception as e:            # noqa: BLE001
             if not self.collective:
