@@ -176,10 +176,14 @@ def hash_grid_leg(dev, rays):
             m.mlp_f16 = mlp16
         frame()
         torch.cuda.synchronize()
+        MN.LAUNCH_LOG = []
         t0 = time.perf_counter()
         frame()
         torch.cuda.synchronize()
         f16_table[key] = D.max_over_ranks(time.perf_counter() - t0, dev) * 1e3
+        log_w, MN.LAUNCH_LOG = MN.LAUNCH_LOG, None
+        if mlp16:
+            full_w = [(B, a_.elapsed_time(b_)) for (flags, B, a_, b_) in log_w if (flags & 0x1000) and not (flags & 1)]
     th, tflag = mfine._table()
     planes = torch.empty(32 * zf.numel(), device=dev)
     pr16 = lambda: _lib.check(_lib.lib().mnrf_tcnn_encode_flags(  # noqa: E731
@@ -329,12 +333,23 @@ def hash_grid_leg(dev, rays):
                          "traffic_source": (f"static profile: profiles/traffic.json, commit {tcommit or 'unrecorded'}, {tsrc}") if ttr else None,
                          "kernel": "mnrf::mf::tcnn_encode_kernel + mnrf::mf::tcnn_mfma_kernel<0,true> (full evaluation, fine pass)",
                          "avg_launch_ms": ms_full / max(1, len(full)), "launches": len(full), "bytes_per_sample": 1024 + 256,
+                         "survey_8d": _survey_roofline(full),
                          "algorithmic_bytes_per_launch": CHUNK * (N_SAMPLES + N_IMPORTANCE) * (1024 + 256),
                          "note": "ALGORITHMIC bytes (128 float2 table reads + the 128-byte encoding planes written and read once, per "
                                  "sample) over the time of the two launches; `traffic` = what reached the fabric in the encoding launch "
                                  "(PMC).  The table is cache-resident: gather_roofline (L2) is the ceiling that binds, this fraction "
                                  "is kept for the contract"},
             "f16_table": f16_table,
+            # the configuration BASELINE words ("hash-grid encoding variant ... with fp16 MLP"), on the storage SURVEY
+            # 8(d) prices (tinycudann's half2 entries): a named key with its own roofline on 8(d)'s algorithmic bytes
+            "as_baseline_words_it": {
+                "table": "half2 entries (module.table_f16; 4 B, tinycudann's storage)", "mlp": "single-pass f16 on the matrix pipe (module.mlp_f16)",
+                "rays_per_s": f16_table.get("rays_per_s_f16_mlp"), "frame_ms": f16_table.get("frame_ms_f16_mlp"),
+                "full_launch_ms": sum(t for _, t in full_w) / max(1, len(full_w)),
+                "roofline": _survey_roofline(full_w),
+                "parity": "fixture G17 (the reference's render over stand-in encoders) at 5e-3 of each output's scale: "
+                          "tests/test_hip_tcnn.py::test_g17_render_rays_with_f16_table_and_f16_mlps; the interpolation itself is unpinned "
+                          "(tinycudann absent)"},
             "f16_mlp": {"rays_per_s": world * n / dt_f16, "frame_ms": dt_f16 * 1e3,
                         "full_launch_ms": sum(t for _, t in full16) / max(1, len(full16)),
                         "sigma_only_launch_ms": sum(t for _, t in sig16) / max(1, len(sig16)),
@@ -346,6 +361,18 @@ def hash_grid_leg(dev, rays):
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
                     "downstream of the encoder pinned by fixtures G17, the encoder's interpolation unpinned (DESIGN.md 2.2); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
                     "sigma-only launches: the same two launches since round 4 (fp32 VALU kernel below 32768 samples)"}
+
+
+def _survey_roofline(launches):
+    """SURVEY 8(d)'s algorithmic bytes of a hash-grid sample: 16 levels x 8 corners x 4 B (half2 entries) = 512 B of gathers + 24 B
+    in (position, direction) = 536 B, over the time of the full-evaluation launches (encoding + MLP), against the HBM peak."""
+    ms = sum(t for _, t in launches)
+    if not launches or ms <= 0:
+        return None
+    gbs = sum(B for B, _ in launches) * 536 / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "bytes_per_sample": 536, "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+            "note": "SURVEY 8(d): 512 B of table gathers (half2) + 24 B in per sample; the table is cache-resident, so this is the "
+                    "contract's yardstick, not the binding limit (gather_roofline: L2 line fills)"}
 
 
 def trained_leg(dev):

@@ -17,12 +17,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=1024)
-ap.add_argument("--loss", choices=("color_mask", "total"), default="color_mask",
+ap.add_argument("--n-importance", type=int, default=None, help="--N_importance (default 64: run.sh:266; 128 = BASELINE config 3 as worded)")
+ap.add_argument("--loss", choices=("color_mask", "total", "run_sh", "run_sh_stage"), default="color_mask",
                 help="total = the reference's TotalLoss through the fused HIP loss kernels (reads normal_*: second-order pass on)")
 a = ap.parse_args()
 rank, world, dev = D.init_from_env()
 rays = SY.device_rays(800, 800, dev)
-r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch, loss_name=a.loss)
+kw = {} if a.n_importance is None else {"N_importance": a.n_importance}
+r = training.synthetic_train_bench(dev, rays, a.steps, a.warmup, a.batch, loss_name=a.loss, **kw)
 if rank == 0:
     r["n_gpus"] = world
     print(json.dumps(r))

@@ -1,0 +1,187 @@
+"""Experiment (CPU, the REFERENCE in float64; round 6): would the weight gradients hold the 1e-3 bar
+(1e-3 of each tensor's largest entry) with HALF the plane bytes?
+
+Today the producers store both operands of dW = sum_s dY[s] (x) X[s] as hi/lo f16 pairs (4 B per element each, 5.4 GB per step) and
+the GEMM contracts three products (hi.hi + lo.hi + hi.lo).  Candidates:
+  (i)   dY as ONE f16 (under the per-sample power-of-two scale the planes carry anyway), X as hi/lo: 3/4 of the bytes, two products
+  (ii)  both as one f16: half the bytes, one product
+each with the conversion the hardware offers: round toward zero (v_cvt_pkrtz_f16_f32: two values per instruction, what split2
+uses) or round to nearest (v_cvt_f16_f32).  The script runs the reference's NeRFSystem.forward + loss + backward in float64 on the
+inputs of the gradient fixtures (G9, G9 full loss, G16, G11 trained pair), records X and dY of every nn.Linear call with hooks,
+forms the FORWARD-USE weight gradient of every Linear exactly and with each candidate's rounding (float64 accumulation), and
+reports max |dW_candidate - dW_exact| / max |dW_total| per tensor.  The second-order term (the use of W inside the density-gradient
+graph) is left exact: the second-order planes would stay hi/lo.
+    PYTHONDONTWRITEBYTECODE=1 python scripts/exp_half_planes.py        (build container only: imports /root/reference)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import make_golden as MG  # noqa: E402  (installs the reference import stubs)
+import torch  # noqa: E402
+from make_golden_loss import first_order_loss, full_loss  # noqa: E402
+
+W, R = MG.W, MG.R
+torch.set_num_threads(8)
+
+
+def f16_rtz(x):
+    h = x.to(torch.float16)
+    hf = h.to(torch.float64)
+    over = hf.abs() > x.abs()
+    step = torch.nextafter(h.float(), torch.zeros_like(h.float())).to(torch.float16)      # one f16 step toward zero
+    # (nextafter on float32 values of f16 numbers moves by an f32 ulp: do it on the f16 bit pattern instead)
+    bits = h.view(torch.int16)
+    toward0 = torch.where(bits & 0x7fff != 0, bits - 1, bits).view(torch.float16)
+    del step
+    return torch.where(over, toward0, h).to(torch.float64)
+
+
+def f16_rtn(x):
+    return x.to(torch.float16).to(torch.float64)
+
+
+def split_hi_lo(x, cvt):
+    hi = cvt(x)
+    return hi, cvt(x - hi)
+
+
+class Tape:
+    """X and dY of every call of every nn.Linear of a model."""
+
+    def __init__(self, model, tag):
+        self.rec = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.Linear):
+                mod.register_forward_hook(self._hook(f"{tag}.{name}.weight"))
+
+    def _hook(self, key):
+        def fwd(mod, inp, out):
+            x = inp[0].detach()
+            slot = [x, None]
+            self.rec.setdefault(key, []).append(slot)
+            if out.requires_grad:
+                out.register_hook(lambda g, slot=slot: slot.__setitem__(1, g.detach()))
+        return fwd
+
+
+def candidates(x, dy):
+    """dict name -> dW (out, in) in float64 from one call's operands (rows = samples)."""
+    # the planes carry dY under a per-sample power-of-two scale (the sample's largest entry of this layer near 2^8 here; the kernels
+    # scale by the sample's largest SEED -- either way the halves stay clear of the f16 subnormals for all but negligible entries)
+    mx = dy.abs().amax(1, keepdim=True).clamp_min(1e-300)
+    sc = torch.exp2(8.0 - torch.ceil(torch.log2(mx)))
+    out = {"exact": dy.T @ x}
+    for cname, cvt in (("rtz", f16_rtz), ("rtn", f16_rtn)):
+        xh, xl = split_hi_lo(x, cvt)
+        yh, yl = split_hi_lo(dy * sc, cvt)
+        yh, yl = yh / sc, yl / sc
+        out[f"today_{cname}"] = yh.T @ xh + yl.T @ xh + yh.T @ xl
+        out[f"i_{cname}"] = yh.T @ xh + yh.T @ xl              # dY one f16, X hi/lo
+        out[f"ii_{cname}"] = yh.T @ xh                         # both one f16
+        out[f"iii_{cname}"] = yh.T @ xh + yl.T @ xh            # X one f16, dY hi/lo
+    return out
+
+
+def run(label, system, rays, gt, target, loss_fn):
+    system.double()
+    system.zero_grad()
+    tapes = [Tape(system.nerf_coarse, "coarse"), Tape(system.nerf_fine, "fine")]
+    extra = {"mirror_mask": torch.from_numpy(gt.copy()).double(), "is_eval": False, "train_geometry_stage": False}
+    res = system(torch.from_numpy(rays).double(), extra)
+    loss_fn(res, torch.from_numpy(target).double(), torch.from_numpy(gt).double()).backward()
+    total = {f"{mn}.{pn}": p.grad.detach().clone() for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine))
+             for pn, p in mod.named_parameters() if p.grad is not None and pn.endswith("weight")}
+    worst = {}
+    rows = []
+    for tape in tapes:
+        for key, calls in tape.rec.items():
+            if key not in total:
+                continue
+            acc = None
+            n = 0
+            for x, dy in calls:
+                if dy is None:
+                    continue
+                c = candidates(x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]))
+                acc = c if acc is None else {k: acc[k] + v for k, v in c.items()}
+                n += x.reshape(-1, x.shape[-1]).shape[0]
+            if acc is None:
+                continue
+            scale = float(total[key].abs().max())
+            if scale == 0.0:
+                continue
+            # how much of the tensor's gradient is the forward-use term (the rest: the second-order use inside the gradient graph)
+            share = float((total[key] - acc["exact"]).abs().max()) / scale
+            errs = {k: float((v - acc["exact"]).abs().max()) / scale for k, v in acc.items() if k != "exact"}
+            rows.append((key, n, share, errs))
+            for k, v in errs.items():
+                worst[k] = max(worst.get(k, 0.0), v)
+    print(f"== {label}: worst over {len(rows)} weight tensors, error / tensor max (bar 1e-3)")
+    for k in sorted(worst):
+        print(f"   {k:12s} {worst[k]:.2e}")
+    rows.sort(key=lambda r: -r[3]["ii_rtz"])
+    for key, n, share, errs in rows[:4]:
+        print(f"   worst tensors for (ii) rtz: {key:40s} samples {n:7d}  second-order share {share:.1e}  "
+              + "  ".join(f"{k} {errs[k]:.1e}" for k in ("i_rtz", "i_rtn", "ii_rtz", "ii_rtn", "iii_rtn")))
+    return worst
+
+
+def g9_system(tweaks=None, trained=False):
+    import train as ref_train
+    hp = R.get_hparams(predict_normal=True, predict_mirror_mask=True, trace_secondary_rays=True, N_samples=64, N_importance=64,
+                       perturb=0, noise_std=0, only_trace_rays_in_mirrors=True, max_recursive_level=1)
+    torch.manual_seed(0)
+    system = ref_train.NeRFSystem(hp)
+    if trained:
+        import make_golden_trained_capture as C
+        _, sds = C.trained_models(0, 2, [])
+    else:
+        _, sds = MG.ref_models(0, 2, W.OPAQUE)
+    system.nerf_coarse.load_state_dict({k: torch.from_numpy(v) for k, v in sds[0].items()})
+    system.nerf_fine.load_state_dict({k: torch.from_numpy(v) for k, v in sds[1].items()})
+    system.train_dataset = types.SimpleNamespace(white_back=False)
+    return system
+
+
+def g16_system():
+    import train as ref_train
+    hp = R.get_hparams(predict_normal=True, predict_mirror_mask=True, trace_secondary_rays=True, N_samples=64, N_importance=64,
+                       perturb=0, noise_std=0, only_trace_rays_in_mirrors=True, max_recursive_level=1, N_emb_xyz=6, N_emb_dir=2)
+    torch.manual_seed(0)
+    system = ref_train.NeRFSystem(hp)
+    sds = W.make_state_dict(0, 2, in_xyz=39, in_dir=15)
+    for mod, sd in zip((system.nerf_coarse, system.nerf_fine), sds):
+        W.apply_tweaks(sd, W.OPAQUE)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    system.train_dataset = types.SimpleNamespace(white_back=False)
+    return system
+
+
+def batch(n_rays, ray_seed, rs_seed, rays_fn=None):
+    rays = (rays_fn or MG.pick_rays)(n_rays, ray_seed)
+    rs = np.random.RandomState(rs_seed)
+    gt = (rs.uniform(size=n_rays) < 0.3).astype(np.float32)
+    target = rs.uniform(size=(n_rays, 3)).astype(np.float32)
+    return rays, gt, target
+
+
+if __name__ == "__main__":
+    out = {}
+    out["g9_train_grads"] = run("G9 (first-order loss, random init + opaque)", g9_system(), *batch(64, 9, 99), first_order_loss)
+    out["g9_train_grads_full"] = run("G9 full loss (second-order term exact)", g9_system(), *batch(64, 9, 99), full_loss)
+    out["g16"] = run("G16 (6 / 2 bands)", g16_system(), *batch(64, 21, 211), first_order_loss)
+    import make_golden_trained_capture as C
+    out["g11_trained_grads_full"] = run("G11 trained pair, full loss", g9_system(trained=True), *batch(64, 9, 99, C.scene_rays), full_loss)
+    import json
+    path = os.path.join(ROOT, "profiles", "r06_half_planes_emulation.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
