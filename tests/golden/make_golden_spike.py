@@ -50,6 +50,12 @@ def system_for(dtype):
     system.train_geometry_stage = False
     if dtype == torch.float64:
         system.double()
+        # losses.py:194 casts the GT mask with .float() whatever the prediction's dtype, which nn.BCELoss refuses in a float64 run
+        # ("Found dtype Float but expected Double"): the same BCE with the target cast to the prediction's dtype
+        class BCE64(torch.nn.Module):
+            def forward(self, p, t):
+                return torch.nn.functional.binary_cross_entropy(p, t.to(p.dtype), reduction="none")
+        system.loss.mirror_mask_loss.loss = BCE64()
     return system
 
 
@@ -96,7 +102,6 @@ def main():
         for mn in ("coarse", "fine"):
             meta[f"ratio_{mn}_{name}"] = meta[f"spike_{name}"][f"{mn}_norm"] / meta[f"median_{name}"][f"{mn}_norm"]
     print("  spike / median gradient norm:", {k: round(v, 3) for k, v in meta.items() if k.startswith("ratio_")})
-    # where the spike comes from: the same batch with the normal terms switched off (epoch 0 of a geometry stage has neither)
     MG.save("g18_grad_spike", meta, {}, {"spike_batch": np.array(spike), "median_batch": np.array(median)})
 
 

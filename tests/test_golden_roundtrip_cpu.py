@@ -27,6 +27,7 @@ CASES = [
     ("make_golden_totalloss", "G.run_case('g10_loss_default', 1, dict(use_plane_consistent_loss=True), False, 5)", ["g10_loss_default"]),
     ("make_golden_truth64", "G.truth('g3_coarse64_train')", ["g14_truth64_g3_coarse64_train"]),
     ("make_golden_trained_capture", "sys.argv[1:] = ['g11_trained_psnr']; G.main()", ["g11_trained_psnr"]),
+    ("make_golden_spike", "G.main()", ["g18_grad_spike"]),
 ]
 
 

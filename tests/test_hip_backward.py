@@ -867,3 +867,52 @@ def test_flat_adam_takes_the_same_steps_as_torch_adam(kernel):
     # the parameters still are what state_dict / checkpoints see, and are views of the flat tensors
     sd = sa.nerf_fine.state_dict()
     assert torch.equal(sd["sigma.weight"], sa.nerf_fine.sigma.weight.detach())
+
+
+def test_gradient_spike_is_the_reference_s():
+    """Fixture G18 (tests/golden/make_golden_spike.py): on the committed trained pair, the batch of the analytic
+    scene with the largest TotalLoss gradient of a 400-batch scan (profiles/r06_spike_scan.json) against a median batch, through the
+    REFERENCE's NeRFSystem.forward + TotalLoss + backward in float32 and float64 (train.py:102-348, 439-446, losses.py:54-78).
+    The HIP step must show the reference's numbers: per-model gradient norms of both batches within the reference's own float32-vs-
+    float64 distance (the median batch's fine-model gradient is noise-dominated in the reference itself: its float32 norm is 37 % off
+    its float64 norm), the loss to 2e-4, and the spike -- fine-model gradient >= 2.5 x the median batch's -- where the reference has it."""
+    import sys
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.weights import params_of
+    from tests.golden import fixtures as FX
+    sys.path.insert(0, FX.HERE)
+    import make_golden_trained as SC
+    fx = FX.Fixture("g18_grad_spike")
+    m = fx.meta
+    hp = T.default_hparams(**{k: v for k, v in m["hp"].items()})
+    system = M.NeRFSystem(hp)
+    z = np.load(f"{FX.HERE}/{m['weights_file']}")
+    for name, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        mod.load_state_dict({k[len(name) + 2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "__")})
+    system.to(DEV)
+    rays, rgbs, masks = SC.scene_views(*m["views"])
+    loss_fn = T.total_loss_fn(SimpleNamespace(model_type="nerf"), epoch=m["epoch"])
+    got = {}
+    for which in ("spike", "median"):
+        idx = np.random.RandomState(m[f"{which}_batch"]).randint(rays.shape[0], size=1024)
+        r, c, k = (torch.from_numpy(a[idx].copy()).to(DEV) for a in (rays, rgbs, masks))
+        system.zero_grad(set_to_none=True)
+        res = system(r, T.extra_info(system.hparams, k, m["epoch"]))
+        loss = loss_fn(res, c, k, r)
+        loss.backward()
+        want32, want64 = m[f"{which}_f32"], m[f"{which}_f64"]
+        assert abs(float(loss) - want32["loss"]) <= 2e-4 * max(1.0, abs(want32["loss"])) + abs(want32["loss"] - want64["loss"]), (which, float(loss), want32["loss"])
+        for mn, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+            g = torch.cat([q.grad.reshape(-1) for q in params_of(mod)]).double()
+            norm = float(g.norm())
+            own = abs(want32[f"{mn}_norm"] - want64[f"{mn}_norm"]) / want64[f"{mn}_norm"]
+            err = abs(norm - want32[f"{mn}_norm"]) / want64[f"{mn}_norm"]
+            print(f"  {which:6s} {mn:6s} |g| HIP {norm:.4e}  reference f32 {want32[f'{mn}_norm']:.4e}  f64 {want64[f'{mn}_norm']:.4e}  (own distance {own:.1e})")
+            assert err <= max(2e-2, 1.5 * own), (which, mn, norm, want32[f"{mn}_norm"], want64[f"{mn}_norm"])
+            got[(which, mn)] = norm
+    ratio = got[("spike", "fine")] / got[("median", "fine")]
+    lo, hi = sorted((m["ratio_fine_f32"], m["ratio_fine_f64"]))
+    print(f"  fine-model gradient, spike / median batch: HIP {ratio:.2f}, reference f32 {m['ratio_fine_f32']:.2f}, f64 {m['ratio_fine_f64']:.2f}")
+    assert lo >= 2.5 and ratio >= 2.5 and 0.8 * lo <= ratio <= 1.2 * hi, (ratio, lo, hi)
