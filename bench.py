@@ -572,6 +572,22 @@ def main():
             train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
             train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
                                                                       "reflected_rays_per_step", "allreduce", "route")}
+        if world == 1 and leg("half_planes"):
+            # opt-in, NOT exact (MNRF_DW_PLANES_HALF; include/mnrf.h MNRF_PLANES_Y_HALF): dY reaches the weight-gradient GEMM as one
+            # f16 per element.  Reported beside the default, never instead of it.
+            from mirror_nerf_amd import autograd as AG
+            AG.DW_PLANES_HALF = True
+            try:
+                t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024)
+            finally:
+                AG.DW_PLANES_HALF = False
+            train["opt_in_half_dy_planes"] = {
+                "ms_per_step": t_["ms_per_step"], "value": t_["value"], "route": t_["route"], "roofline": t_["roofline"],
+                "note": "MNRF_DW_PLANES_HALF=1: the activation gradients travel to the weight-gradient GEMM as ONE f16 per element under "
+                        "the planes' per-sample scale (the producer's lo tiles are dropped by a zero-record buffer descriptor, the GEMM "
+                        "fetches and multiplies hi tiles only: 3/4 of its bytes).  Not exact: within 1e-3 of each weight tensor's largest "
+                        "entry of the default route on G9 / G16 / G11 (tests/test_hip_backward.py::test_half_dy_planes_hold_the_gradient_bar), "
+                        "1.2e-4 .. 7.4e-4 against float64 in the emulation on the reference (profiles/r06_half_planes_emulation.json)"}
         if leg("run_sh"):
             # run.sh:259-280 as the reference trains: --use_plane_consistent_loss --train_geometry_stage.  All five terms of TotalLoss
             # (the plane term drawing on the device), after the geometry stage (reflections traced) and inside it (none), on the

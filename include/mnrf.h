@@ -319,6 +319,12 @@ int mnrf_field_composite_fused(float* packed, int64_t n_rays, const float* rays,
  * rays ...: train.py:253-259 evaluates the same models at every recursion level).
  * Autograd equivalent: loss.backward() through models/mirror_nerf.py:101-212, .grad accumulated over the evaluations. */
 #define MNRF_TRAIN_PLANES 256u     /* mnrf_field_forward_train: `save_x` is a planes buffer of mnrf_train_planes_bytes(B) bytes */
+#define MNRF_PLANES_Y_HALF 0x100000u   /* round 6, OPT-IN (flags of mnrf_field_backward_planes; bit 12 = 0x1000 of the evaluation's kinds[e]
+                                          entry of mnrf_dw_planes2): dY travels as ONE f16 per element under the planes' per-sample
+                                          scale instead of a hi/lo pair -- the producer's lo tiles never reach memory, the GEMM fetches
+                                          and multiplies the hi tiles only (3/4 of the GEMM's bytes, half the producer's stores).
+                                          NOT exact: 1.2e-4 .. 7.4e-4 of each weight tensor's largest entry against float64 on the
+                                          gradient fixtures (profiles/r06_half_planes_emulation.json; bar 1e-3).  Ring GEMM only. */
 int64_t mnrf_train_planes_bytes(int64_t B);      /* X planes of B samples (bytes) */
 int64_t mnrf_train_dy_planes_bytes(int64_t B);   /* dY planes of B samples (bytes) */
 

@@ -34,6 +34,7 @@ MNRF_CUT_NORMAL_HEAD = 32
 MNRF_CUT_MIRROR_HEAD = 64
 MNRF_DW_ACCUMULATE = 128
 MNRF_TRAIN_PLANES = 256
+MNRF_PLANES_Y_HALF = 0x100000
 MNRF_TCNN_GRAD_F16 = 16
 MNRF_DETACH_W_MASK = 1
 MNRF_DETACH_W_NORMAL = 2

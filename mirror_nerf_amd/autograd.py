@@ -13,6 +13,11 @@ FOLD_GRADS = os.environ.get("MNRF_FOLD_GRADS", "1") != "0"
 # set of bf16 x 6 GEMM launches per evaluation) instead of operand planes + ONE GEMM launch per module and pass (mnrf_dwp.h)
 RAY_GRADS_KERNEL = os.environ.get("MNRF_RAY_GRADS", "1") != "0"      # 0: the torch ops it replaced (A/B measurements)
 DW_PLANES = os.environ.get("MNRF_DW_PLANES", "1") != "0"
+# MNRF_DW_PLANES_HALF=1 (round 6, opt-in, NOT exact): the activation gradients travel to the weight-gradient GEMM as one f16 per
+# element instead of a hi/lo pair (include/mnrf.h MNRF_PLANES_Y_HALF): half the backward kernel's plane traffic, 3/4 of the GEMM's.
+# Emulated on the reference in float64 first (scripts/exp_half_planes.py): 1.2e-4 .. 7.4e-4 of a tensor's largest entry, inside the
+# 1e-3 bar of the gradient fixtures with a margin of 1.3 x at worst -- which is why it is not the default.
+DW_PLANES_HALF = os.environ.get("MNRF_DW_PLANES_HALF", "0") == "1"
 DW2_PLANES = os.environ.get("MNRF_DW2_PLANES", "1") != "0"    # 0: the second-order term on fp32 rows (mnrf_field_backward2)
 
 
@@ -235,9 +240,11 @@ class FieldFn(torch.autograd.Function):
             seed = torch.empty(1, dtype=torch.int32, device=dev)
             _lib.check(L.mnrf_field_backward_planes_n(
                 p(packed), B, p(xyz), xs, p(rays), p(z_vals), spr, p(g_sigma), p(g_rgb), p(g_pn), p(g_m), p(rgb), p(pn),
-                p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror), ctx.cut | (red << 16),
+                p(mir), p(save_mask), p(save_inv), p(dy), p(seed), p(d_xyz), p(d_dir), p(ctx.keep_mirror),
+                ctx.cut | (red << 16) | (_lib.MNRF_PLANES_Y_HALF if DW_PLANES_HALF else 0),
                 p(ctx.n_live), _lib.stream()), "mnrf_field_backward_planes")
-            st.tape.append((save_x, dy, B, seed, red << 8, ctx.n_live, spr))      # (kind 0 | the gradient-scale reduction of this launch)
+            # (kind 0 | the gradient-scale reduction of this launch | dY as one f16)
+            st.tape.append((save_x, dy, B, seed, (red << 8) | (0x1000 if DW_PLANES_HALF else 0), ctx.n_live, spr))
         elif B:
             ws = f(max(1, L.mnrf_train_workspace_floats(B)))
             _lib.check(L.mnrf_field_backward(

@@ -39,6 +39,8 @@ struct DwpEval {
     const char* X;            // X planes of the evaluation  [n_sb][PLX_FB][2][1 KiB]
     const char* Y;            // dY planes                   [n_sb][PLY_FB][2][1 KiB]
     const unsigned* seedmax;  // bits of the largest |seed| of the evaluation (float), see mnrf_dwp.h "scale"
+    int y_half;               // round 6, opt-in (kinds bit 12 / MNRF_DW_PLANES_HALF): the producer stored the hi tiles of dY only -- the lo
+                              // half-tiles are neither fetched (lanes 32-63 of a dY piece stay out of the LDS-DMA) nor multiplied
 };
 struct DwpArgs {
     DwpEval ev[DWP_MAX_EVAL];
@@ -196,12 +198,13 @@ __device__ __forceinline__ u32x4 read_operand2(const char* half0, const char* ha
 
 template <int MB, int KB, int NA, int NX>
 __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, const char* __restrict__ Xb, long long ysb, long long xsb,
-                                                  int s_lo, int s_hi, bool bias, float* __restrict__ slot) {
+                                                  int s_lo, int s_hi, bool bias, float* __restrict__ slot, bool y_half) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wk = wave >> 2;
     const int lane8 = lane * 8;
     const bool has_a = wn * MB < NA;
+    const bool skip_lo = y_half && lane >= 32;   // dY pieces: the lo half-tile (lanes 32-63 of the instruction) does not exist
     constexpr int NP = NA + NX;                  // feature blocks = (hi, lo) half-tile pairs per half-stage = KiB per ring slot
     constexpr int Q = (NP + 7) / 8;              // LDS-DMA instructions per wave and half-stage
     constexpr int SLOT = NP * 1024;
@@ -234,8 +237,11 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
             if (pr >= NP) pr -= NP;
             const char* src = pr < NA ? ya + pr * PL_FB_BYTES : xa + (pr - NA) * PL_FB_BYTES;
             char* dst = base + pr * 1024;        // [dY half-tile pairs: NA KiB][X half-tile pairs: NX KiB]
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, PL_LOAD_AUX);
+            // (y_half: the instruction is issued by every wave all the same -- the counted waits count instructions -- with half
+            //  its lanes switched off: 512 bytes instead of 1 KiB)
+            if (!(skip_lo && pr < NA))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, PL_LOAD_AUX);
         }
     };
 
@@ -245,8 +251,9 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
         if (pr >= NP) pr -= NP;
         const char* src = pr < NA ? Yb + (long long)s * ysb + (hs & 1) * 512 + lsrc + pr * PL_FB_BYTES
                                   : Xb + (long long)s * xsb + (hs & 1) * 512 + lsrc + (pr - NA) * PL_FB_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + ring_slot * SLOT + pr * 1024), 16, 0, PL_LOAD_AUX);
+        if (!(skip_lo && pr < NA))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + ring_slot * SLOT + pr * 1024), 16, 0, PL_LOAD_AUX);
     };
     // PACED (default since the end of round 4): the 2 Q requests that refill a stage's slots are spread over the KB column blocks
     // of the stage's MFMAs instead of leaving as one burst of 8 waves x 2 Q instructions right after the barrier, and the X
@@ -297,6 +304,7 @@ __device__ __forceinline__ void dwp_segment_run_h(const char* __restrict__ Yb, c
             for (int mb = 0; mb < MB; ++mb) {
                 ah[mb] = read_operand2(A0 + (wn * MB + mb) * 1024, A1 + (wn * MB + mb) * 1024, lane8);
                 al[mb] = read_operand2(A0 + (wn * MB + mb) * 1024 + 512, A1 + (wn * MB + mb) * 1024 + 512, lane8);
+                if (y_half) al[mb] = u32x4{0u, 0u, 0u, 0u};      // (what the LDS holds there is whatever an earlier job left)
             }
             // the X operands one column block ahead of the MFMAs that consume them, requested after the first row block's MFMAs
             // of the block before: their LDS round trip runs under the other 3 (MB - 1) MFMAs.  (The compiler's own schedule read
@@ -395,14 +403,15 @@ __global__ __launch_bounds__(DWP_WG_THREADS, 1) void dwp_gemm_kernel(DwpArgs A) 
             const char* Yb = A.ev[e].Y + (long long)jb.ya * PL_FB_BYTES;
             const char* Xb = A.ev[e].X + (long long)jb.xa * PL_FB_BYTES;
             float* slot = A.part + (long long)(g + j * hd.n_eval + e) * DWP_SLOT_FLOATS;
+            const bool y_half = kind == 0 && A.ev[e].y_half != 0;      // (the second-order planes stay hi / lo)
             if constexpr (HALF) {
                 switch (jb.shape) {
-                case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
-                case 1: dwp_segment_run_h<4, 2, 16, 4>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
-                case 2: dwp_segment_run_h<2, 8, 8, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
-                case 3: dwp_segment_run_h<2, 1, 8, 2>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
-                case 4: dwp_segment_run_h<1, 8, 1, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
-                default: dwp_segment_run_h<1, 4, 1, 8>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot); break;
+                case 0: dwp_segment_run_h<4, 8, 16, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
+                case 1: dwp_segment_run_h<4, 2, 16, 4>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
+                case 2: dwp_segment_run_h<2, 8, 8, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
+                case 3: dwp_segment_run_h<2, 1, 8, 2>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
+                case 4: dwp_segment_run_h<1, 8, 1, 16>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
+                default: dwp_segment_run_h<1, 4, 1, 8>(Yb, Xb, ysb, xsb, s_lo, s_hi, jb.bias, slot, y_half); break;
                 }
             } else {
                 switch (jb.shape) {
@@ -728,8 +737,12 @@ static int dwp_run(const DwpPlan& plan, const DwpDevPlan* dev, int n_eval, const
     DwpArgs A;
     A.plan = plan;
     A.dev = dev;
-    for (int e = 0; e < n_eval; ++e) A.ev[e] = DwpEval{(const char*)x_planes[e], (const char*)dy_planes[e], seedmax[e]};
-    for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr};
+    bool any_half = false;
+    for (int e = 0; e < n_eval; ++e) {
+        A.ev[e] = DwpEval{(const char*)x_planes[e], (const char*)dy_planes[e], seedmax[e], (kinds && (kinds[e] & 0x1000)) ? 1 : 0};
+        any_half |= A.ev[e].y_half != 0;
+    }
+    for (int e = n_eval; e < DWP_MAX_EVAL; ++e) A.ev[e] = DwpEval{nullptr, nullptr, nullptr, 0};
     A.part = part;
     static const bool once = [] {
         (void)hipFuncSetAttribute((const void*)dwp_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DWP_LDS);
@@ -741,6 +754,7 @@ static int dwp_run(const DwpPlan& plan, const DwpDevPlan* dev, int n_eval, const
     (void)once;
     // the ring of half-stages (dwp_segment_run_h) is the default; MNRF_DWP_RING=0 (read once) selects the two-buffer version
     static const bool ring = [] { const char* e = getenv("MNRF_DWP_RING"); return !(e && atoi(e) == 0); }();
+    if (any_half && !ring) return -2;      // (the two-buffer loop fetches whole stages)
     const int G = dev ? dwp_cus() : plan.G;
     if (dev) {
         if (ring) hipLaunchKernelGGL((dwp_gemm_kernel<true, true>), dim3(G), dim3(DWP_WG_THREADS), DWP_RING_LDS, s, A);

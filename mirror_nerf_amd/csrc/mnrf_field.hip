@@ -347,6 +347,7 @@ static int field_backward_planes_impl(float* packed, int64_t B, const float* xyz
                    flags & (MNRF_CUT_NORMAL_HEAD | MNRF_CUT_MIRROR_HEAD), keep_mirror, (char*)dy_planes, seedmax,
                    6 - (int)((flags >> 16) & 0xfu)};
     A.n_live = n_live;
+    A.y_half = (flags & MNRF_PLANES_Y_HALF) ? 1 : 0;
     if (launch_split_bwd(A, s) != 0)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_field_backward_planes: too many samples for one launch");
     return mnrf_check_launch("mnrf_field_backward_planes");

@@ -81,6 +81,7 @@ struct FieldBwdArgs {
     // weight-gradient GEMM's finish kernel must be told the same number (mnrf_dw_planes2: kinds)
     int seed_log2;
     const int* n_live;          // live rows (B = capacity): see FieldArgs::n_live; planes route only
+    int y_half;                 // round 6, opt-in (MNRF_PLANES_Y_HALF): only the hi tiles of the dY planes reach memory
 };
 // second-order pass (gradient through the density-gradient normal)
 struct FieldBwd2Args {

@@ -208,6 +208,10 @@ def test_field_backward_ray_mode_accumulates_over_samples():
 @pytest.mark.parametrize("name", ["g9_train_grads", "g9_train_grads_full", "g9b_detach_mask", "g9b_detach_outside_mirror",
                                   "g9b_detach_normal", "g9b_detach_ref_color", "g16_nemb_6_2_train_grads", "g11_trained_grads_full"])
 def test_train_step_gradients_golden(name):
+    _golden_gradients(name)
+
+
+def _golden_gradients(name):
     """G9: gradients of a first-order loss through the whole train-semantics render (coarse + fine
     pass, GT mirror mask, compacted reflected rays, blend) against the reference's autograd,
     captured by tests/golden/make_golden.py.  Tolerance: 1e-3 of each tensor's largest gradient.
@@ -295,6 +299,33 @@ def test_train_step_gradients_golden(name):
         print(f"  full tensor {mname} {pn_}: vs fp32 capture {e32:.2e}, vs float64 {e64:.2e} (reference fp32 vs float64 {own:.2e})")
         assert e32 <= max(1e-3, 4 * own), (k, e32, own)
         assert e64 <= 2 * own + 1e-3, (k, e64, own)
+    return {f"{mname}.{pn_}": p_.grad.detach().clone() for mname, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine))
+            for pn_, p_ in mod.named_parameters() if p_.grad is not None}
+
+
+@pytest.mark.parametrize("name", ["g9_train_grads", "g9_train_grads_full", "g16_nemb_6_2_train_grads", "g11_trained_grads_full"])
+def test_half_dy_planes_hold_the_gradient_bar(name, monkeypatch):
+    """MNRF_DW_PLANES_HALF=1 (round 6, opt-in; include/mnrf.h MNRF_PLANES_Y_HALF): the activation gradients reach the weight-gradient
+    GEMM as ONE f16 per element -- the producer's lo tiles are dropped by a zero-record buffer descriptor, the GEMM fetches and
+    multiplies the hi tiles only.  The reference's captured gradients are met at the fixtures' own tolerances, and every tensor is
+    within 1e-3 of its largest entry of the exact (hi/lo) route -- what scripts/exp_half_planes.py predicted from the reference in
+    float64 (profiles/r06_half_planes_emulation.json: 1.2e-4 .. 7.4e-4)."""
+    from mirror_nerf_amd import autograd as AG
+    exact = _golden_gradients(name)
+    monkeypatch.setattr(AG, "DW_PLANES_HALF", True)
+    half = _golden_gradients(name)
+    worst = 0.0
+    for k, g in exact.items():
+        scale = float(g.abs().max())
+        if scale == 0.0:
+            continue
+        err = float((half[k] - g).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-3, (k, err)
+    from mirror_nerf_amd import mirror_nerf as MN
+    if MN.PRECISION.startswith("split"):      # (the fp32 arithmetic has no operand planes: the flag means nothing there)
+        assert worst > 1e-7, "the half route produced the exact route's bits: the flag did not reach the kernels"
+    print(f"  {name}: dY as one f16 vs hi/lo planes, worst tensor {worst:.2e} of its largest entry")
 
 
 def test_field_second_order_backward_matches_double_backward():
