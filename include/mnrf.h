@@ -557,6 +557,23 @@ int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double
                                          (mirror_nerf_tcnn.py:186-190, 196-199); MNRF_TCNN_GRAD_F16: see there */,
                        void* stream);
 
+/* Round 6 -- live row counts for the hash-grid field (config 5 on the static training route, see "live row counts on the device"
+ * below): ray mode only; B = the capacity the buffers (and the [level][B] planes) are sized for, the kernels evaluate / differentiate
+ * the first *n_live * spr samples; rows past them are neither read nor written and add nothing to any gradient.  n_live null =
+ * mnrf_tcnn_forward / mnrf_tcnn_backward. */
+int mnrf_tcnn_forward_n(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                        int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
+                        const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
+                        const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                        float* is_mirror, float* normal, float* geo_feat, float* enc_workspace, const int32_t* n_live, void* stream);
+int mnrf_tcnn_backward_n(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                         int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
+                         int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
+                         int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                         const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                         float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
+                         const int32_t* n_live, void* stream);
+
 /* Pin-hole ray generation on device (datasets/ray_utils.py:6-53): rays (H*W, 8). */
 int mnrf_generate_rays(int H, int W, float focal, const float* c2w_host12, float near, float far,
                        float* rays, void* stream);

@@ -99,6 +99,10 @@ SIGNATURES = {
                                  _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _str]),
     "mnrf_tcnn_backward": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _i64,
                                   _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 11 + [_u32, _str]),
+    "mnrf_tcnn_forward_n": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _u32, _i64, _c_f, _i64,
+                                   _c_f, _c_f, _int, _c_f, _i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _str]),
+    "mnrf_tcnn_backward_n": (_int, [_c_f, ctypes.POINTER(ctypes.c_int64), ctypes.c_double, _int, _flt, _c_f, _i64, _c_f, _i64,
+                                    _c_f, _c_f, _int, _c_f, _i64] + [_c_f] * 11 + [_u32, _c_i, _str]),
     "mnrf_tcnn_backward_workspace_floats": (_i64, [ctypes.POINTER(ctypes.c_int64)]),
     "mnrf_tcnn_backward_workspace_floats2": (_i64, [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint]),
     "mnrf_tcnn_backward_workspace_floats3": (_i64, [ctypes.POINTER(ctypes.c_int64), ctypes.c_uint, _i64]),

@@ -65,7 +65,19 @@ struct TcnnArgs {
     float* sigma; float* rgb; float* pred_normal; float* is_mirror; float* normal; float* geo_feat;
     float* enc;                   // level-major encoding planes [NL][B] float2 (caller's workspace) or null
     unsigned table_f16;           // MNRF_TCNN_TABLE_F16: `table` holds half2 entries (4 B: tinycudann's storage) instead of float2
+    // live row count (round 6; include/mnrf.h "live row counts on the device"): B is the CAPACITY the buffers and the plane strides
+    // (Bs) are sized for, the kernels evaluate the first *n_live * spr samples (ray mode); null: all B exist
+    const int* n_live;
+    long long Bs;                 // = the capacity B (set by the launcher): stride of the [NL][Bs] planes
 };
+// first thing in every kernel that walks the samples: B becomes what exists
+__device__ __forceinline__ void live_rows(TcnnArgs& A) {
+    if (A.n_live) {
+        long long bl = (long long)*A.n_live * A.spr;
+        bl = bl < 0 ? 0 : bl;
+        if (bl < A.B) A.B = bl;
+    }
+}
 
 // one table entry (two features) by storage type.  The flag is a kernel argument: a wave-uniform branch next to a gather.
 __device__ __forceinline__ float2 tab_fetch(const float* table, unsigned f16, unsigned long long idx) {
@@ -231,6 +243,8 @@ __device__ __forceinline__ void encode_level(const TcnnArgs& A, int lv, const fl
 
 template <bool SIGMA_ONLY, bool GRAD>
 __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
+    live_rows(A);
+    if ((long long)blockIdx.x * TPB >= A.B) return;
     const cptr WC = as_const(A.weights);
     long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     const bool live = i < A.B;
@@ -407,7 +421,19 @@ __global__ __launch_bounds__(TPB) void tcnn_kernel(TcnnArgs A) {
 //     per 2.1 M; the full evaluation without the normal -- the fine pass of every eval render -- 2.83 vs 5.46 ms.
 namespace mf {
 
-constexpr int WAVES = 6;                            // 2 workgroups x 6 waves per CU: 3 waves per SIMD at <= 168 registers
+// Waves per workgroup.  Round 6: EIGHT (was six).  A CU has four SIMDs and a workgroup's waves are dealt to them in turn: six waves
+// leave two SIMDs with two waves and two with one, and the kernel -- bound by its own VALU / MFMA instruction stream, not by memory
+//  -- then runs at the pace of the loaded pair.  One 32768-ray chunk's fine pass, encoding + MLP launch, alternating
+// libraries on one box (scripts/exp_tcnn_mlp_parts.py, profiles/r06_tcnn_waves.txt): 6 waves 2.24 ms (hi/lo) / 1.76 (f16 MLPs),
+// 4 waves 2.10 / 1.72, **8 waves 2.05 / 1.63**, 10 waves 2.12 / 1.73, 12 waves 2.02 / 1.66, 16 waves 2.03 / 1.62: every multiple
+// of four beats its neighbours; 8 is the smallest workgroup of the fast group for both arithmetics.
+#ifndef MNRF_EXP_TCNN_WAVES
+#define MNRF_EXP_TCNN_WAVES 8
+#endif
+#ifndef MNRF_EXP_TCNN_MINWG
+#define MNRF_EXP_TCNN_MINWG 2
+#endif
+constexpr int WAVES = MNRF_EXP_TCNN_WAVES;
 constexpr int NG = 2;                               // groups of 16 samples per wave iteration (4: 800 B/lane of spills at 256 registers)
 constexpr int TILE = WAVES * NG * 16;               // samples per workgroup iteration
 constexpr int NT_FWD = 29;                          // tile pairs
@@ -591,9 +617,10 @@ __device__ __forceinline__ void encode_level_p(const float* table, const LevelP&
 #endif
 constexpr int ENC_PATCH_RAYS = MNRF_EXP_ENC_PATCH_RAYS;
 __global__ __launch_bounds__(256) void tcnn_encode_kernel(TcnnArgs A) {
+    live_rows(A);
     const int lv = blockIdx.y;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (ENC_PATCH_RAYS > 1 && !A.xyz && A.spr % (256 / ENC_PATCH_RAYS) == 0 && (A.B / A.spr) % ENC_PATCH_RAYS == 0) {
+    if (ENC_PATCH_RAYS > 1 && !A.xyz && A.spr % (256 / ENC_PATCH_RAYS) == 0 && (A.Bs / A.spr) % ENC_PATCH_RAYS == 0) {
         constexpr int PS = 256 / ENC_PATCH_RAYS;                  // depths per patch
         const int groups = A.spr / PS;                            // patches along a ray
         long long patch = blockIdx.x;
@@ -634,12 +661,15 @@ __global__ __launch_bounds__(256) void tcnn_encode_kernel(TcnnArgs A) {
     }
     float a0, a1, g0[3], g1[3];
     encode_level_p<false>(A.table, L, u, oob, a0, a1, g0, g1, A.table_f16);
-    __builtin_nontemporal_store(a0, A.enc + 2 * ((long long)lv * A.B + i));
-    __builtin_nontemporal_store(a1, A.enc + 2 * ((long long)lv * A.B + i) + 1);
+    __builtin_nontemporal_store(a0, A.enc + 2 * ((long long)lv * A.Bs + i));
+    __builtin_nontemporal_store(a1, A.enc + 2 * ((long long)lv * A.Bs + i) + 1);
 }
 
 template <int MODE, bool PLANES = false>
-__global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
+__global__ __launch_bounds__(64 * WAVES, MNRF_EXP_TCNN_MINWG) void tcnn_mfma_kernel(TcnnArgs A, int n_tiles) {
+    live_rows(A);
+    if (A.n_live) n_tiles = (int)((A.B + TILE - 1) / TILE);
+    if (n_tiles <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     // ---- weight tiles (hi | lo) and the few fp32 rows used outside the GEMMs
@@ -709,7 +739,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void tcnn_mfma_kernel(TcnnArgs A, in
 #ifdef MNRF_EXP_TCNN_NO_PLANE_LOADS      // experiment: the MLP launch without its input traffic
                     const float2 v = make_float2(0.01f * (float)((idx[gi] + q) & 63), 0.02f * (float)((idx[gi] >> 3) & 31));
 #else
-                    const float2 v = ((const float2*)A.enc)[(long long)(4 * g + q) * A.B + idx[gi]];
+                    const float2 v = ((const float2*)A.enc)[(long long)(4 * g + q) * A.Bs + idx[gi]];
 #endif
                     f8[2 * q] = v.x; f8[2 * q + 1] = v.y;
                 } else {
@@ -1046,6 +1076,7 @@ __device__ __forceinline__ void scatter_corners(const TcnnBwdArgs& P, int lv, co
 }
 
 __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
+    live_rows(P.f);
     const TcnnArgs& A = P.f;
     __shared__ double wg_ssum[NL];        // MNRF_TCNN_GRAD_FIXED: this workgroup's sum of max(|e0|, |e1|) per level
     if (threadIdx.x < NL) wg_ssum[threadIdx.x] = 0.0;
@@ -1338,7 +1369,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 #pragma unroll 1
             for (int lv = 0; lv < NL; ++lv) {
                 const float e0 = active ? GR(2 * lv) : 0.f, e1 = active ? GR(2 * lv + 1) : 0.f;
-                if (live) P.genc[(long long)lv * A.B + i] = float2{e0, e1};
+                if (live) P.genc[(long long)lv * A.Bs + i] = float2{e0, e1};
                 float mx = fmaxf(fabsf(e0), fabsf(e1));
                 if (!(mx < 1.0e30f)) mx = 1.0e30f;                      // (inf / nan upstream: a finite scale; the sums are garbage either way)
 #pragma unroll
@@ -1429,6 +1460,7 @@ __global__ __launch_bounds__(BT) void tcnn_bwd_kernel(TcnnBwdArgs P) {
 // One thread per sample, same LDS layout and tile helpers as tcnn_bwd_kernel; three gather passes (features for the mask,
 // derivatives for J, derivatives again for the scatter); runs before tcnn_fold_kernel and ADDS to d_table / d_weights / d_xyz.
 __global__ __launch_bounds__(BT) void tcnn_bwd2_kernel(TcnnBwdArgs P) {
+    live_rows(P.f);
     const TcnnArgs& A = P.f;
     for (int k = threadIdx.x; k < W_TOTAL; k += BT) wlds[k] = A.weights[k];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1604,6 +1636,7 @@ __device__ __forceinline__ float fx_scale(double S) {
 // MNRF_TCNN_GRAD_FIXED: the scatter as its own launch over the planes tcnn_bwd_kernel wrote.  One thread per sample, all levels;
 // levels with private copies add fp32 into them as before, the others one packed 64-bit integer atomic per corner.
 __global__ __launch_bounds__(256) void tcnn_scatter_fx_kernel(TcnnBwdArgs P) {
+    live_rows(P.f);
     const TcnnArgs& A = P.f;
     const int lane = threadIdx.x & 63;
     const long long ntiles = (A.B + 255) / 256;
@@ -1631,7 +1664,7 @@ __global__ __launch_bounds__(256) void tcnn_scatter_fx_kernel(TcnnBwdArgs P) {
         const bool active = live && !oob;
 #pragma unroll 1
         for (int lv = 0; lv < NL; ++lv) {
-            const float2 e = active ? P.genc[(long long)lv * A.B + i] : float2{0.f, 0.f};
+            const float2 e = active ? P.genc[(long long)lv * A.Bs + i] : float2{0.f, 0.f};
             const float scale = A.scale[lv];
             const unsigned res = A.res[lv];
             const unsigned hsize = A.off[lv + 1] - A.off[lv];
@@ -1775,11 +1808,12 @@ extern "C" int mnrf_tcnn_pack_weights(const float* const* params, float* weights
     return mnrf_check_launch("mnrf_tcnn_pack_weights");
 }
 
-extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
-                                 int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
-                                 const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
-                                 const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
-                                 float* is_mirror, float* normal, float* geo_feat, float* enc_workspace, void* stream) {
+static int tcnn_forward_impl(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                             int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
+                             const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
+                             const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                             float* is_mirror, float* normal, float* geo_feat, float* enc_workspace, const int32_t* n_live, void* stream) {
+    if (n_live && xyz) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward_n: a live row count needs ray mode (rays + z_vals)");
     if (!table || !offsets17_host || !weights) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: null pointer");
     if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: negative sample count");
     if (B == 0) return MNRF_OK;
@@ -1790,6 +1824,7 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     if (grad && !normal) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: GRAD_NORMAL needs the normal output");
     if (bound <= 0.f) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: bound must be positive");
     TcnnArgs A;
+    A.n_live = n_live; A.Bs = B;
     A.table = table; A.weights = weights; A.B = B; A.xyz = xyz; A.xyz_stride = xyz_stride; A.rays = rays;
     A.z_vals = z_vals; A.spr = spr; A.dirs = dirs; A.dir_stride = dir_stride; A.bound = bound;
     for (int l = 0; l < NL; ++l) {
@@ -1830,7 +1865,7 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
             return true;
         }();
         (void)attr;
-        const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two 6-wave workgroups per CU
+        const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two workgroups per CU
         if (A.enc) {      // level-major encoding into the caller's planes, then the MLPs from the planes
             const long long nb = (B + 255) / 256;
             if (nb > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
@@ -1849,6 +1884,22 @@ extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_ho
     else if (!grad) hipLaunchKernelGGL((tcnn_kernel<false, false>), grid, block, lds, s, A);
     else hipLaunchKernelGGL((tcnn_kernel<false, true>), grid, block, lds, s, A);
     return mnrf_check_launch("mnrf_tcnn_forward");
+}
+extern "C" int mnrf_tcnn_forward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                 int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
+                                 const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
+                                 const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                 float* is_mirror, float* normal, float* geo_feat, float* enc_workspace, void* stream) {
+    return tcnn_forward_impl(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, flags, B, xyz, xyz_stride, rays,
+                             z_vals, spr, dirs, dir_stride, sigma, rgb, pred_normal, is_mirror, normal, geo_feat, enc_workspace, nullptr, stream);
+}
+extern "C" int mnrf_tcnn_forward_n(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                   int base_resolution, float bound, const float* weights, unsigned flags, int64_t B,
+                                   const float* xyz, int64_t xyz_stride, const float* rays, const float* z_vals, int spr,
+                                   const float* dirs, int64_t dir_stride, float* sigma, float* rgb, float* pred_normal,
+                                   float* is_mirror, float* normal, float* geo_feat, float* enc_workspace, const int32_t* n_live, void* stream) {
+    return tcnn_forward_impl(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, flags, B, xyz, xyz_stride, rays,
+                             z_vals, spr, dirs, dir_stride, sigma, rgb, pred_normal, is_mirror, normal, geo_feat, enc_workspace, n_live, stream);
 }
 
 // d_table += g16 / scale for the entries [e0, e1) of the levels that accumulated in half2 (MNRF_TCNN_GRAD_F16)
@@ -1893,13 +1944,14 @@ extern "C" int64_t mnrf_tcnn_backward_workspace_floats3(const int64_t* offsets17
     return mnrf_tcnn_backward_workspace_floats(offsets17_host) + 2 * offsets17_host[NL] + 32 * (B > 0 ? B : 0) + 32;
 }
 
-extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
-                                  int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
-                                  int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
-                                  int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
-                                  const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
-                                  float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
-                                  void* stream) {
+static int tcnn_backward_impl(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                              int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
+                              int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
+                              int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                              const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                              float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
+                              const int32_t* n_live, void* stream) {
+    if (n_live && xyz) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward_n: a live row count needs ray mode (rays + z_vals)");
     if (!table || !offsets17_host || !weights || !d_table || !d_weights)
         return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: null pointer");
     if (B < 0) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: negative sample count");
@@ -1910,6 +1962,7 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
     if (bound <= 0.f) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_backward: bound must be positive");
     TcnnBwdArgs P;
     TcnnArgs& A = P.f;
+    A.n_live = n_live; A.Bs = B;
     A.table = table; A.weights = weights; A.B = B; A.xyz = xyz; A.xyz_stride = xyz_stride; A.rays = rays;
     A.z_vals = z_vals; A.spr = spr; A.dirs = dirs; A.dir_stride = dir_stride; A.bound = bound;
     for (int l = 0; l < NL; ++l) {
@@ -1981,6 +2034,28 @@ extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_h
                                (float2*)d_table, e0, e1, 1.f / P.g16_scale, (unsigned*)(P.g16 + offsets17_host[NL]));
     }
     return mnrf_check_launch("mnrf_tcnn_backward");
+}
+extern "C" int mnrf_tcnn_backward(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                  int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
+                                  int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
+                                  int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                  const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                                  float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
+                                  void* stream) {
+    return tcnn_backward_impl(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, B, xyz, xyz_stride, rays, z_vals,
+                              spr, dirs, dir_stride, g_sigma, g_rgb, g_pred_normal, g_is_mirror, g_normal, workspace, d_table, d_weights,
+                              d_xyz, d_dir, keep_mirror, flags, nullptr, stream);
+}
+extern "C" int mnrf_tcnn_backward_n(const float* table, const int64_t* offsets17_host, double log2_per_level_scale,
+                                    int base_resolution, float bound, const float* weights, int64_t B, const float* xyz,
+                                    int64_t xyz_stride, const float* rays, const float* z_vals, int spr, const float* dirs,
+                                    int64_t dir_stride, const float* g_sigma, const float* g_rgb, const float* g_pred_normal,
+                                    const float* g_is_mirror, const float* g_normal, float* workspace, float* d_table,
+                                    float* d_weights, float* d_xyz, float* d_dir, const float* keep_mirror, unsigned flags,
+                                    const int32_t* n_live, void* stream) {
+    return tcnn_backward_impl(table, offsets17_host, log2_per_level_scale, base_resolution, bound, weights, B, xyz, xyz_stride, rays, z_vals,
+                              spr, dirs, dir_stride, g_sigma, g_rgb, g_pred_normal, g_is_mirror, g_normal, workspace, d_table, d_weights,
+                              d_xyz, d_dir, keep_mirror, flags, n_live, stream);
 }
 
 

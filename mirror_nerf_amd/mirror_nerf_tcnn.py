@@ -94,15 +94,17 @@ class TcnnFieldFn(torch.autograd.Function):
     def forward(ctx, module, spr, xyz6, rays, z_vals, dirs, want_normal, table, *params):
         # `want_normal` may be a tuple (want_normal, cut_flags, keep_mirror) like FieldFn's: the --detach_density_* options
         # (models/mirror_nerf_tcnn.py:186-215) make normal_net / is_mirror_net see geo_feat.detach()
-        ctx.cut, ctx.keep_mirror = 0, None
+        ctx.cut, ctx.keep_mirror, ctx.n_live = 0, None, None
         if isinstance(want_normal, tuple):
-            want_normal, ctx.cut, km = want_normal[0], int(want_normal[1]), want_normal[2]
+            wn = want_normal
+            want_normal, ctx.cut, km = wn[0], int(wn[1]), wn[2]
             ctx.keep_mirror = None if km is None else km.detach().float().contiguous()
+            ctx.n_live = wn[3] if len(wn) > 3 else None      # live rows of `rays` (static training route: recursion.py)
         B = xyz6.shape[0] if xyz6 is not None else rays.shape[0] * spr
         c = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
         xyz6, rays, z_vals, dirs = c(xyz6), c(rays), c(z_vals), c(dirs)
         o = module.field(B, xyz=xyz6, xyz_stride=6, rays=rays, z_vals=z_vals, spr=spr, dirs=dirs,
-                         grad_normal=bool(want_normal), want_geo=True)
+                         grad_normal=bool(want_normal), want_geo=True, n_live=ctx.n_live)
         ctx.module, ctx.spr, ctx.B = module, spr, B
         ctx.save_for_backward(xyz6, rays, z_vals, dirs)
         ctx.set_materialize_grads(False)
@@ -127,8 +129,10 @@ class TcnnFieldFn(torch.autograd.Function):
         d_blob = torch.zeros(_lib.lib().mnrf_tcnn_weight_floats(), dtype=torch.float32, device=dev)
         want_x = (xyz6 is not None and need[2]) or (rays is not None and need[3])
         want_d = (xyz6 is not None and need[2]) or (dirs is not None and need[5]) or (dirs is None and rays is not None and need[3])
-        d_xyz = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_x else None
-        d_dir = torch.empty(B, 3, dtype=torch.float32, device=dev) if want_d else None
+        # (with a live row count the rows past it are not written: zeros, so that the per-ray sums below stay finite there)
+        mk = torch.zeros if ctx.n_live is not None else torch.empty
+        d_xyz = mk(B, 3, dtype=torch.float32, device=dev) if want_x else None
+        d_dir = mk(B, 3, dtype=torch.float32, device=dev) if want_d else None
         offs = _offsets17(m.cfg)
         # table_grad_f16 (module attribute; env MNRF_TCNN_GRAD_F16=1 sets the default): the big hashed levels accumulate their
         # gradient in half2 with one packed atomic per entry -- tinycudann's gradient precision, 26 % off the step
@@ -147,11 +151,11 @@ class TcnnFieldFn(torch.autograd.Function):
             _check_f16_overflow(m)      # the previous backward's overflow word (its copy finished long ago: no queue drain)
         p = _lib.ptr
         if B:
-            _lib.check(_lib.lib().mnrf_tcnn_backward(
+            _lib.check(_lib.lib().mnrf_tcnn_backward_n(
                 read_table.data_ptr(), offs, m.cfg["S"], m.cfg["H"], float(m.bound), p(m._weights()), B, p(xyz6), 6,
                 p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3, p(g_sigma), p(g_rgb), p(g_pn),
                 p(g_m), p(g_normal), p(ws), p(d_table), p(d_blob), p(d_xyz), p(d_dir), p(ctx.keep_mirror), flags | tflag,
-                _lib.stream()), "mnrf_tcnn_backward")
+                p(ctx.n_live), _lib.stream()), "mnrf_tcnn_backward")
         if B and (flags & _lib.MNRF_TCNN_GRAD_F16):
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             host.copy_(ws[-4:-3].view(torch.int32), non_blocking=True)
@@ -259,8 +263,9 @@ class MirrorNeRFTcnn(nn.Module):
         return self.__dict__["_table_half"], _lib.MNRF_TCNN_TABLE_F16
 
     def field(self, B, *, xyz=None, xyz_stride=6, rays=None, z_vals=None, spr=1, dirs=None, sigma_only=False,
-              grad_normal=False, want_geo=False):
-        """Run the fused kernel; returns flat per-sample tensors like mirror_nerf.field_forward."""
+              grad_normal=False, want_geo=False, n_live=None):
+        """Run the fused kernel; returns flat per-sample tensors like mirror_nerf.field_forward.
+        n_live (round 6; ray mode): a device int32 -- B is the capacity, the first *n_live * spr samples exist (mnrf_tcnn_forward_n)."""
         table, tflag = self._table()
         dev = table.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -291,11 +296,11 @@ class MirrorNeRFTcnn(nn.Module):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if B:
-            _lib.check(_lib.lib().mnrf_tcnn_forward(
+            _lib.check(_lib.lib().mnrf_tcnn_forward_n(
                 table.data_ptr(), offs, self.cfg["S"], self.cfg["H"], float(self.bound), p(self._weights()), flags, B,
                 p(xyz), xyz_stride, p(rays), p(z_vals), spr, p(dirs), dirs.shape[1] if dirs is not None else 3,
                 p(out["sigma"]), p(out.get("rgb")), p(out["pred_normal"]), p(out.get("is_mirror")), p(out.get("normal")),
-                p(out.get("geo_feat")), p(enc), _lib.stream()), "mnrf_tcnn_forward")
+                p(out.get("geo_feat")), p(enc), p(n_live), _lib.stream()), "mnrf_tcnn_forward")
         if log is not None:
             e1.record()
             log.append((flags | 0x1000, B, e0, e1))       # 0x1000: hash-grid field

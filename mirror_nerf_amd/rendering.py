@@ -106,8 +106,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     train = torch.is_grad_enabled() and (rays.requires_grad or any(
         q.requires_grad for mdl in models.values() for q in params_of(mdl)))
     n_live = kwargs.get("_n_live")
-    if n_live is not None and (not train or hashgrid or test_time):
-        raise NotImplementedError("_n_live (device-side ray count) is a feature of the training path of the MirrorNeRF field")
+    if n_live is not None and (not train or test_time):
+        raise NotImplementedError("_n_live (device-side ray count) is a feature of the training path")
 
     # gradient steering (values are unaffected): rendering.py:223-247 for the compositing weights,
     # mirror_nerf.py:154-183 for what the normal / mirror heads send into geo_feat
@@ -308,8 +308,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if hashgrid:
             from .mirror_nerf_tcnn import TcnnFieldFn
             want = bool(compute_normal)
-            if cut_heads or keep_mirror is not None:
-                want = (want, cut_heads, keep_mirror)
+            if cut_heads or keep_mirror is not None or n_live is not None:
+                want = (want, cut_heads, keep_mirror, n_live)
             sigma, rgb, pn, mir, normal, _geo = TcnnFieldFn.apply(model, S, None, rays, z, dir_emb, want,
                                                                   model.encoder.embeddings, *model.mlp_params())
         else:

@@ -103,11 +103,15 @@ def stage_target(hparams, target, gt_mask, gt_valid):
 
 def static_step_ok(system):
     """Can `system` take the static training route (recursion.render_rays_chunk_recursively "STATIC STEP": the reflected-ray
-    count never visits the host)?  MirrorNeRF fields on the split arithmetic with operand planes; a model the range guard has
-    pinned to fp32, the hash-grid field and MNRF_DW_PLANES=0 use the host-driven route."""
+    count never visits the host)?  MirrorNeRF fields on the split arithmetic with operand planes, or -- round 6 -- hash-grid fields
+    (mnrf_tcnn_forward_n / _backward_n); a model the range guard has pinned to fp32 and MNRF_DW_PLANES=0 use the host-driven route."""
     from . import autograd as AG
     from .mirror_nerf import MirrorNeRF, precision_of
-    return AG.DW_PLANES and all(isinstance(m, MirrorNeRF) and precision_of(m) == "split" for m in system.models.values())
+    from .mirror_nerf_tcnn import MirrorNeRFTcnn
+    models = list(system.models.values())
+    if models and all(isinstance(m, MirrorNeRFTcnn) for m in models):
+        return True      # round 6: the hash-grid field takes the live count too (mnrf_tcnn_forward_n / _backward_n)
+    return AG.DW_PLANES and all(isinstance(m, MirrorNeRF) and precision_of(m) == "split" for m in models)
 
 
 # MNRF_STATIC_STEP=0: train_step keeps the host-driven route (one device->host read of the reflected-ray count per level and step,

@@ -583,3 +583,75 @@ def test_graphed_step_carries_the_run_sh_recipe(stage, epoch):
     with pytest.raises(ValueError):
         step(rays, target, gt)
     a.train_geometry_stage = b.train_geometry_stage = False
+
+
+# ------------------------------------------------------------------------------------------ round 6: config 5 on the static route
+def test_hash_grid_model_takes_the_static_route():
+    """VERDICT r5 "missing" #4 / item 4b: MirrorNeRFTcnn through the recursion's static route (mnrf_tcnn_forward_n / _backward_n: the
+    reflected rays keep the batch's capacity, the kernels take the count as their live row count).  Against the host-driven route
+    (train.py:102-348 with one device->host read per level) on the same weights and rays: every per-ray map bit for bit, the table
+    gradient to 1e-6 of its largest entry (fixed-point scatter on the hashed levels, fp32 atomics on the coarse ones), the MLP
+    gradients to the order of their atomics;
+    with 25 %, no and only mirror rays; train_step(gt_valid=True) takes the route and updates the weights like the host route."""
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import training as T
+    from oracle import mirror_nerf_oracle as O
+    hp = SimpleNamespace(model_type="nerf_tcnn", bound=2.0, predict_normal=True, predict_mirror_mask=True, N_samples=24,
+                         N_importance=24, use_disp=False, perturb=0, noise_std=0, chunk=4096, only_one_field=False,
+                         trace_secondary_rays=True, max_recursive_level=1, only_trace_rays_in_mirrors=True, for_vis=False)
+
+    def system():
+        torch.manual_seed(4)
+        s = M.NeRFSystem(hp)
+        with torch.no_grad():
+            for mdl in (s.nerf_coarse, s.nerf_fine):
+                mdl.encoder.embeddings.uniform_(-0.05, 0.05)
+                mdl.encoder.embeddings[int(mdl.cfg["offsets"][5]):] = 0      # (smooth field: see test_tcnn_train_recursion_matches_torch_field)
+                mdl.sigma_net[1].weight[0] *= 10.0
+        return s.to(DEV)
+    s = system()
+    assert T.static_step_ok(s)
+    rays = torch.from_numpy(O.synthetic_rays(16, 16)).to(DEV)
+    rays[:, 6], rays[:, 7] = 2.5, 5.5
+    N = rays.shape[0]
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run(gt, static):
+        s.zero_grad(set_to_none=True)
+        ex = {"mirror_mask": gt, "is_eval": False, "train_geometry_stage": False}
+        if static:
+            ex.update(_static=True, _gt_valid=True)
+        res = s(rays, ex)
+        loss = ((res["rgb_fine"] - target) ** 2).mean() + ((res["rgb_coarse"] - target) ** 2).mean() \
+            + 0.05 * ((res["mirror_mask_fine"] - gt) ** 2).mean()
+        loss.backward()
+        return res, float(loss), {k: (None if v.grad is None else v.grad.clone()) for k, v in s.named_parameters()}
+
+    for name, gt in (("a third", (torch.arange(N, device=DEV) % 3 == 0).float()), ("none", torch.zeros(N, device=DEV)),
+                     ("all", torch.ones(N, device=DEV))):
+        res_h, loss_h, g_h = run(gt, False)
+        res_s, loss_s, g_s = run(gt, True)
+        for k in ("rgb_coarse", "rgb_fine", "depth_fine", "mirror_mask_fine", "opacity_fine", "x_surface_fine"):
+            assert torch.equal(res_h[k], res_s[k]), (name, k)
+        assert loss_h == loss_s, name
+        for k in g_h:
+            assert (g_h[k] is None) == (g_s[k] is None), (name, k)
+            if g_h[k] is None:
+                continue
+            scale = float(g_h[k].abs().max())
+            err = float((g_h[k] - g_s[k]).abs().max())
+            # (table: the hashed levels accumulate in fixed point -- exact integer sums -- the coarse levels in fp32 private copies,
+            #  whose atomics arrive in another order when the launch is sized for the capacity)
+            assert err <= (1e-6 if k.endswith("encoder.embeddings") else 2e-5) * scale + 1e-12, (name, k, err, scale)
+    # the whole step: train_step(gt_valid=True) takes the static route for this model as well
+    a, b = system(), system()
+    oa = torch.optim.Adam(list(a.parameters()), lr=1e-3, fused=True)
+    ob = torch.optim.Adam(list(b.parameters()), lr=1e-3, fused=True)
+    gt = (torch.arange(N, device=DEV) % 3 == 0).float()
+    for _ in range(2):
+        la = T.train_step(a, oa, rays, target, gt, gt_valid=True)
+        lb = T.train_step(b, ob, rays, target, gt)
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    for (k, qa), qb in zip(a.named_parameters(), b.parameters()):
+        assert float((qa - qb).abs().max()) <= 2 * 1e-3 + 1e-6, k
