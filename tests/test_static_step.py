@@ -655,3 +655,66 @@ def test_hash_grid_model_takes_the_static_route():
         assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     for (k, qa), qb in zip(a.named_parameters(), b.parameters()):
         assert float((qa - qb).abs().max()) <= 2 * 1e-3 + 1e-6, k
+
+
+def test_captured_loop_crosses_scale_lowering_recapture_and_fp32_pin():
+    """ONE run through every state of the guard machine around the captured step.  Trained weights (fixture G11),
+    TotalLoss, batches of the analytic scene named by integers (tests/golden/make_golden_spike.py): batch 284's backward outgrows the
+    f16 range at the default gradient scale -> its update is skipped on the device, the scale is lowered by 2^4 and the step is
+    captured AGAIN (the model stays on the split arithmetic); later a batch whose rays start 100 units away trips the encoding range
+    -> nothing to adapt: that update is skipped too, the models are pinned to fp32 and the loop continues on train_step.  At the end:
+    one capture per gradient scale used (two or three), finite weights that moved, the skipped updates counted."""
+    import sys
+    from types import SimpleNamespace
+    import numpy as np
+    import warnings
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import training as T
+    from mirror_nerf_amd.mirror_nerf import precision_of
+    from tests.golden import fixtures as FX
+    sys.path.insert(0, FX.HERE)
+    import make_golden_trained as SC
+    system = M.NeRFSystem(T.default_hparams(N_importance=64, perturb=0.0, noise_std=0.0))
+    z = np.load(f"{FX.HERE}/g11_trained_weights.npz")
+    for name, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        mod.load_state_dict({k[len(name) + 2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "__")})
+    system.to(DEV)
+    rays, rgbs, masks = (torch.from_numpy(a).to(DEV) for a in SC.scene_views(48, 100, 100))
+    opt = T.FlatAdam(list(system.models.values()), lr=1e-5)
+    loss_fn = T.total_loss_fn(SimpleNamespace(model_type="nerf"), epoch=5)
+    step = T.GraphedTrainStep(system, opt, 1024, loss_fn=loss_fn, epoch=5, gt_valid=True)
+    captures = []
+    real_capture = step.capture
+    step.capture = lambda: (captures.append(len(captures)), real_capture())[1]
+    w0 = [fp.detach().clone() for fp in opt.flats]
+    far_at = 40
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for i in range(60):
+            idx = torch.from_numpy(np.random.RandomState(284 if i == 0 else 1000 + i).randint(rays.shape[0], size=1024)).to(DEV)
+            r = rays[idx].contiguous()
+            if i == far_at:
+                r[:, :3] += 100.0
+            loss = step(r, rgbs[idx].contiguous(), masks[idx].contiguous())
+            if i in (5, far_at + 5, 59):
+                torch.cuda.synchronize()
+                assert bool(torch.isfinite(loss).all()), i
+            if i == far_at - 1:
+                torch.cuda.synchronize()
+                red = max(m.__dict__.get("_mnrf_seed_reduction", 0) for m in system.models.values())
+                # one capture per gradient scale in use: 2^-4 after batch 284, and 2^-8 if a later batch outgrows that too (the
+                # ladder has two rungs; a third trip of this kind would pin fp32 and end the graph)
+                assert not step.ended and red in (4, 8) and len(captures) == 1 + red // 4, (step.ended, red, captures)
+                assert all(precision_of(m) == "split" for m in system.models.values())
+                n_captures_before_pin = len(captures)
+    torch.cuda.synchronize()
+    msgs = [str(w.message) for w in caught]
+    assert any("gradient scale is lowered" in m for m in msgs), msgs[:5]
+    assert any("captured training step" in m and "fp32" in m for m in msgs), msgs[:5]
+    assert step.ended and len(captures) == n_captures_before_pin
+    assert all(precision_of(m) == "fp32" for m in system.models.values())
+    skipped = sum(int(t.item()) for t in opt._skipped)
+    assert skipped >= 2, skipped                      # (the tripping replays; a replay queued before its trip was read trips as well)
+    for fp, w in zip(opt.flats, w0):
+        assert bool(torch.isfinite(fp).all()) and float((fp.detach() - w).abs().max()) > 0.0
+    assert opt._calls == 60
