@@ -282,3 +282,41 @@ def test_guard_costs_no_accuracy_on_clean_models():
     d = MN.verify_split(_models(SY.OPAQUE)["fine"])
     assert max(d.values()) < 2e-5, d
     assert np.isfinite(list(d.values())).all()
+
+
+def test_one_backward_overflow_costs_one_adaptation_on_the_static_route():
+    """on the static route (one rank, skip mode) the guard flags of step N are read after step N+1 has been queued --
+    with the OLD gradient scale, so step N+1 overflows as well.  Its token remembers the scale it was issued with and says nothing
+    about the new one: ONE overflow event lowers the scale ONCE (2^-4), not twice.  Trained weights (fixture G11), TotalLoss, batch
+    284 of the analytic scene (tests/golden/make_golden_spike.py), whose backward outgrows the f16 range at the default scale."""
+    import sys
+    from types import SimpleNamespace
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import mirror_nerf as MN
+    from mirror_nerf_amd import training as T
+    from tests.golden import fixtures as FX
+    sys.path.insert(0, FX.HERE)
+    import make_golden_trained as SC
+    if not MN.PRECISION.startswith("split"):
+        pytest.skip("the gradient scale belongs to the split arithmetic")
+    system = M.NeRFSystem(T.default_hparams(N_importance=64, perturb=0.0, noise_std=0.0))
+    z = np.load(f"{FX.HERE}/g11_trained_weights.npz")
+    for name, mod in (("coarse", system.nerf_coarse), ("fine", system.nerf_fine)):
+        mod.load_state_dict({k[len(name) + 2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "__")})
+    system.to(DEV)
+    rays, rgbs, masks = (torch.from_numpy(a).to(DEV) for a in SC.scene_views(48, 100, 100))
+    opt = T.FlatAdam(list(system.models.values()), lr=1e-6)
+    loss_fn = T.total_loss_fn(SimpleNamespace(model_type="nerf"), epoch=5)
+    idx = torch.from_numpy(np.random.RandomState(284).randint(rays.shape[0], size=1024)).to(DEV)
+    batch = (rays[idx].contiguous(), rgbs[idx].contiguous(), masks[idx].contiguous())
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(5):      # the same overflowing batch five times: trip, (stale trip), then clean at the lowered scale
+            T.train_step(system, opt, *batch, loss_fn, epoch=5, gt_valid=True)
+        torch.cuda.synchronize()
+        T.train_step(system, opt, *batch, loss_fn, epoch=5, gt_valid=True)
+    reds = [m.__dict__.get("_mnrf_seed_reduction", 0) for m in system.models.values()]
+    assert max(reds) == 4, reds
+    assert all(MN.precision_of(m) == "split" for m in system.models.values())
+    assert sum("gradient scale is lowered" in str(w.message) for w in caught) == sum(r == 4 for r in reds)
+    assert 1 <= sum(int(t.item()) for t in opt._skipped) <= 4      # (the tripping step and the one queued behind it, per model)
