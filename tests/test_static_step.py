@@ -701,10 +701,11 @@ def test_captured_loop_crosses_scale_lowering_recapture_and_fp32_pin():
                 assert bool(torch.isfinite(loss).all()), i
             if i == far_at - 1:
                 torch.cuda.synchronize()
-                red = max(m.__dict__.get("_mnrf_seed_reduction", 0) for m in system.models.values())
-                # one capture per gradient scale in use: 2^-4 after batch 284, and 2^-8 if a later batch outgrows that too (the
-                # ladder has two rungs; a third trip of this kind would pin fp32 and end the graph)
-                assert not step.ended and red in (4, 8) and len(captures) == 1 + red // 4, (step.ended, red, captures)
+                reds = [m.__dict__.get("_mnrf_seed_reduction", 0) for m in system.models.values()]
+                # a new capture per adaptation event: the fine model after batch 284, the coarse model when a later batch outgrows
+                # ITS scale (each model has its own two-rung ladder; two models adapting at one settle share a capture)
+                n_adapt = sum(r // 4 for r in reds)
+                assert not step.ended and max(reds) in (4, 8) and 2 <= len(captures) <= 1 + n_adapt, (step.ended, reds, captures)
                 assert all(precision_of(m) == "split" for m in system.models.values())
                 n_captures_before_pin = len(captures)
     torch.cuda.synchronize()
