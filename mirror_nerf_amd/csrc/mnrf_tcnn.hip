@@ -434,7 +434,10 @@ namespace mf {
 #define MNRF_EXP_TCNN_MINWG 2
 #endif
 constexpr int WAVES = MNRF_EXP_TCNN_WAVES;
-constexpr int NG = 2;                               // groups of 16 samples per wave iteration (4: 800 B/lane of spills at 256 registers)
+#ifndef MNRF_EXP_TCNN_NG
+#define MNRF_EXP_TCNN_NG 2
+#endif
+constexpr int NG = MNRF_EXP_TCNN_NG;                // groups of 16 samples per wave iteration (4: 800 B/lane of spills at 256 registers)
 constexpr int TILE = WAVES * NG * 16;               // samples per workgroup iteration
 constexpr int NT_FWD = 29;                          // tile pairs
 constexpr int PAIR_B = 2048;
@@ -479,6 +482,8 @@ __device__ __forceinline__ float tile_value(const float* W, int id, int lane, in
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    // (the two subtractions as one v_pk_add_f32 -- 1811 -> 1729 VALU instructions in the kernel -- measured no faster, round 6:
+    //  the launch is bound by the dependent MFMA -> convert -> MFMA chain of a 16-sample group, not by VALU issue)
     const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
@@ -1865,7 +1870,9 @@ static int tcnn_forward_impl(const float* table, const int64_t* offsets17_host, 
             return true;
         }();
         (void)attr;
-        const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);       // persistent: two workgroups per CU
+        // persistent: two workgroups per CU (round 6, alternating on one box: 256 workgroups 2.09 ms per chunk / 1.72 with f16 MLPs,
+        // 512: 2.04 / 1.62, 768 and 1024: the same)
+        const dim3 g2((unsigned)(n_tiles < 512 ? n_tiles : 512)), b2(64 * mf::WAVES);
         if (A.enc) {      // level-major encoding into the caller's planes, then the MLPs from the planes
             const long long nb = (B + 255) / 256;
             if (nb > 0x7fffffff) return mnrf_fail(MNRF_ERR_ARG, "mnrf_tcnn_forward: too many samples for one launch");
