@@ -299,7 +299,9 @@ def hash_grid_leg(dev, rays):
     for m in models.values():
         m.table_grad_f16 = False
     n = rays.shape[0]
+    recursion = _tcnn_recursion_step(dev, rays) if world == 1 else None
     return {"rays_per_s": world * n / dt_f, "samples_per_s": world * n * (2 * N_SAMPLES + N_IMPORTANCE) / dt_f, "frame_ms": dt_f * 1e3,
+            "train_step_with_reflections": recursion,
             "n_gpus": world, "scaling": "weak (every rank renders the frame / draws its own 1024-ray batch)",
             "train_ms_per_step": dt_t * 1e3, "train_rays_per_s": world * 1024 / dt_t, "allreduce": allreduce,
             "table_gradient_sparsity": sparse,
@@ -361,6 +363,46 @@ def hash_grid_leg(dev, rays):
             "note": "MirrorNeRFTcnn pair, random init; primary rays only (a random-init mask head predicts no mirror); parity "
                     "downstream of the encoder pinned by fixtures G17, the encoder's interpolation unpinned (DESIGN.md 2.2); full evaluations: MLPs as hi/lo f16 tiles on the matrix pipe, "
                     "sigma-only launches: the same two launches since round 4 (fp32 VALU kernel below 32768 samples)"}
+
+
+def _tcnn_recursion_step(dev, rays, steps=20):
+    """Config 5 through the WHOLE training path of the reference (train.py:102-348 with MODEL_TYPE=nerf_tcnn: coarse + fine pass, 25 % GT
+    mirror rays reflected once, blend), colour + mask loss, torch's fused Adam: train_step on the host-driven route (one device->host
+    read of the reflected-ray count per level and step) against the static route (round 6: mnrf_tcnn_forward_n / _backward_n)."""
+    import torch
+    import mirror_nerf_amd as M
+    from mirror_nerf_amd import training as T
+    out = {}
+    for route in ("host", "static"):
+        torch.manual_seed(0)
+        hp = T.default_hparams(model_type="nerf_tcnn", bound=6.0, N_emb_xyz=0, N_emb_dir=0, perturb=1.0, noise_std=1.0)
+        system = M.NeRFSystem(hp).to(dev)
+        with torch.no_grad():
+            for m in system.models.values():
+                m.sigma_net[1].weight[0] *= 10.0       # opaque enough for surfaces (and reflected rays) to exist
+        opt = torch.optim.Adam(list(system.parameters()), lr=5e-4, fused=True)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        batches = []
+        for _ in range(steps + 3):
+            idx = torch.randint(0, rays.shape[0], (1024,), device=dev, generator=g)
+            batches.append((rays[idx].contiguous(), torch.rand(1024, 3, device=dev, generator=g),
+                            (torch.rand(1024, device=dev, generator=g) < 0.25).float()))
+        it = iter(batches)
+        for _ in range(3):
+            T.train_step(system, opt, *next(it), gt_valid=True if route == "static" else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = T.train_step(system, opt, *next(it), gt_valid=True if route == "static" else None)
+        torch.cuda.synchronize()
+        out[route + "_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        out["loss_" + route] = float(loss.detach())
+        del system, opt
+    out["note"] = ("NeRFSystem(model_type='nerf_tcnn').forward with reflections (1024 rays, 64 + 128 samples, ~256 reflected rays) + colour / "
+                   "mask loss + backward + fused Adam through training.train_step: host-driven route vs static route (the reflected-ray count "
+                   "stays on the device; the hash-grid kernels take it as their live row count)")
+    return out
 
 
 def _survey_roofline(launches):
