@@ -551,9 +551,14 @@ def main():
                          "of the final pass are not produced; to_cpu=\"maps\" (with_host_maps) takes the same kernels"}
 
     train = None
+    # More than one rank: the contract's legs run on the STATIC route (host-issued launches, host-issued collectives: the path every
+    # multi-rank test has exercised); the captured step WITH its collectives (round 6) is measured after the complete line is out, as an
+    # optional last leg -- it has only ever run on a 1-rank RCCL group, and a collective that cannot be captured on some stack must
+    # not cost the run its line.  MNRF_TRAIN_ROUTE overrides.
+    rk = {"_route": "static"} if (multi and not os.environ.get("MNRF_TRAIN_ROUTE")) else {}
     if not a.no_train and leg("train"):
         from mirror_nerf_amd import training
-        train = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024)
+        train = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, **rk)
         legs_done.append("train_step")
         if world == 1 and leg("train_routes"):
             # the same step on the reference's shape (the host reads the reflected-ray count in the middle of the step,
@@ -563,13 +568,13 @@ def main():
                 t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, _route=r_)
                 train["routes_ms_per_step"][r_] = t_["ms_per_step"]
         if leg("train_total"):
-            train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total")
+            train_total = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name="total", **rk)
             train["with_total_loss"] = {k: train_total[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline", "route")
                                         if k in train_total}
         if leg("config3"):
             # BASELINE config 3 as worded ("same config" as config 2: 64 coarse + 128 importance samples); the default above is
             # run.sh:266's training schedule (--N_importance 64)
-            train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128)
+            train_c3 = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, N_importance=128, **rk)
             train["config3_64_plus_192"] = {k: train_c3[k] for k in ("value", "ms_per_step", "samples_per_ray", "N_importance", "roofline",
                                                                       "reflected_rays_per_step", "allreduce", "route")}
         if world == 1 and leg("half_planes"):
@@ -594,7 +599,7 @@ def main():
             # default route (the captured graph)
             rs = {}
             for key, name in (("after_geometry_stage", "run_sh"), ("in_geometry_stage", "run_sh_stage")):
-                t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name=name)
+                t_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, loss_name=name, **rk)
                 rs[key] = {k: t_[k] for k in ("value", "ms_per_step", "loss", "loss_fn", "roofline", "route", "reflected_rays_per_step",
                                              "collectives_in_graph", "allreduce") if k in t_}
             train["run_sh_recipe"] = rs
@@ -611,6 +616,27 @@ def main():
     if deadline is not None:
         deadline.cancel()
     emit()
+    if multi and train is not None and not os.environ.get("MNRF_TRAIN_ROUTE") and os.environ.get("MNRF_BENCH_GRAPH_ACROSS_RANKS", "1") != "0" \
+            and dist.get_backend() == "nccl":
+        # optional last leg (see above): the step captured with its RCCL collectives inside.  The complete line is out; if this leg
+        # does not finish within MNRF_BENCH_GRAPH_DEADLINE seconds (default 300) the process leaves with code 0 and says so on stderr.
+        import threading
+
+        def _give_up():
+            sys.stderr.write("bench.py: the optional leg train_step.graph_across_ranks did not finish (the complete line above stands)\n")
+            sys.stderr.flush()
+            os._exit(0)
+        t_opt = threading.Timer(float(os.environ.get("MNRF_BENCH_GRAPH_DEADLINE", "300")), _give_up)
+        t_opt.daemon = True
+        t_opt.start()
+        from mirror_nerf_amd import training
+        g_ = training.synthetic_train_bench(dev, rays, steps=30, warmup=5, batch=1024, _route="graph")
+        t_opt.cancel()
+        train["graph_across_ranks"] = {k: g_[k] for k in ("value", "ms_per_step", "route", "collectives_in_graph", "allreduce", "roofline") if k in g_}
+        train["graph_across_ranks"]["note"] = ("the colour + mask step as ONE hipGraph per rank with its collectives inside (bucket all-reduces from "
+                                               "the backward hooks, guard words OR-ed over the ranks); `route` says \"static (...)\" if the capture "
+                                               "failed on this stack and the leg fell back")
+        emit()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -371,3 +371,9 @@ def test_bench_spawns_its_own_ranks():
     hg = line["hash_grid_variant"]                                                    # config 5 with its collectives
     assert hg["allreduce"]["messages_per_step"] == 4 and hg["allreduce"]["bytes_per_step"] > 90e6 and hg["train_ms_per_step"] > 0
     assert 0 < hg["table_gradient_sparsity"]["touched_fraction"][1] < 1.0
+    # round 6: the contract's training legs run on the static route across ranks; the step captured WITH its collectives is the
+    # optional last leg, measured after the complete line went out (two "complete" lines: the last one carries it)
+    assert line["train_step"]["route"] == "static" and line["line"] == "complete"
+    g = line["train_step"]["graph_across_ranks"]
+    assert g["route"] == "graph" and g["collectives_in_graph"] is True and g["ms_per_step"] > 0, g
+    assert sum(l.startswith("{") and '"line": "complete"' in l for l in r.stdout.splitlines()) == 2
