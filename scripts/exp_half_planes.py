@@ -48,6 +48,15 @@ def f16_rtn(x):
     return x.to(torch.float16).to(torch.float64)
 
 
+def fp8(x, mbits):
+    """round to nearest with `mbits` mantissa bits (e4m3: 3, e5m2: 2); exponent range wide enough for the scaled residuals
+    (|r| < 2^11 * 2^-10 * |hi| ...): the emulation ignores saturation / subnormals of the 8-bit formats"""
+    ax = x.abs().clamp_min(1e-300)
+    e = torch.floor(torch.log2(ax))
+    step = torch.exp2(e - mbits)
+    return torch.where(x == 0, torch.zeros_like(x), torch.round(x / step) * step)
+
+
 def split_hi_lo(x, cvt):
     hi = cvt(x)
     return hi, cvt(x - hi)
@@ -87,6 +96,12 @@ def candidates(x, dy):
         out[f"i_{cname}"] = yh.T @ xh + yh.T @ xl              # dY one f16, X hi/lo
         out[f"ii_{cname}"] = yh.T @ xh                         # both one f16
         out[f"iii_{cname}"] = yh.T @ xh + yl.T @ xh            # X one f16, dY hi/lo
+        # dY as hi (f16) + an 8-bit lo (e4m3 / e5m2 of the residual, scaled by 2^11 so that it sits in the formats' normal range):
+        # 3 bytes per element instead of 4
+        r = (dy * sc - cvt(dy * sc)) * 2048.0
+        for fmt, bits in (("e4m3", 3), ("e5m2", 2)):
+            q = fp8(r, bits) / 2048.0 / sc
+            out[f"lo8{fmt}_{cname}"] = yh.T @ xh + q.T @ xh + yh.T @ xl
     return out
 
 
@@ -130,7 +145,7 @@ def run(label, system, rays, gt, target, loss_fn):
     rows.sort(key=lambda r: -r[3]["ii_rtz"])
     for key, n, share, errs in rows[:4]:
         print(f"   worst tensors for (ii) rtz: {key:40s} samples {n:7d}  second-order share {share:.1e}  "
-              + "  ".join(f"{k} {errs[k]:.1e}" for k in ("i_rtz", "i_rtn", "ii_rtz", "ii_rtn", "iii_rtn")))
+              + "  ".join(f"{k} {errs[k]:.1e}" for k in ("i_rtz", "i_rtn", "ii_rtz", "lo8e4m3_rtz", "lo8e5m2_rtz")))
     return worst
 
 
@@ -181,7 +196,7 @@ if __name__ == "__main__":
     import make_golden_trained_capture as C
     out["g11_trained_grads_full"] = run("G11 trained pair, full loss", g9_system(trained=True), *batch(64, 9, 99, C.scene_rays), full_loss)
     import json
-    path = os.path.join(ROOT, "profiles", "r06_half_planes_emulation.json")
+    path = os.path.join(ROOT, "profiles", os.environ.get("MNRF_EMU_OUT", "r06_half_planes_emulation.json"))
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)
