@@ -111,7 +111,7 @@ def main():
         # gradients of a train step (make_golden.grad_case uses weights.OPAQUE by name: the trained pair is opaque already)
         W_OPAQUE, MG.W.OPAQUE = MG.W.OPAQUE, []
         try:
-            MG.grad_case("g11_trained_grads_full", 64, MG.full_loss)
+            MG.grad_case("g11_trained_grads_full", 64, MG.full_loss, full_tensors=True)
         finally:
             MG.W.OPAQUE = W_OPAQUE
 
